@@ -1,0 +1,140 @@
+"""Generate golden fixtures by importing the REFERENCE's own loss.py / dataset.py.
+
+Run in the build container only (needs /root/reference; it never travels):
+
+    python tests/golden/make_golden.py
+
+Recipe: the reference modules import torchvision /
+diffusers / wandb / comet_ml at module level, none of which is installed; they
+are satisfied with MagicMock stubs that are never *called* by the functions
+used here (R-coefficient tables, LossFn with a fake scheduler object and an
+analytic stand-in model, box triggers / box targets / masks).  Only numbers
+produced by the reference's own arithmetic are stored; no reference source.
+
+Outputs (committed): loss_tables.npz, loss_batch.npz, backdoor_boxes.npz.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import datasets  # noqa: F401  (must precede the torchvision stub: it probes torchvision.__spec__)
+    for m in ["torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.datasets",
+              "diffusers", "comet_ml", "wandb"]:
+        sys.modules[m] = MagicMock()
+    import torch  # noqa: F401
+    import loss as ref_loss
+    import dataset as ref_dataset
+    return ref_loss, ref_dataset
+
+
+class FakeVPSched:
+    """Scheduler-like object exposing only what loss.py:830-834,924 touches."""
+
+    def __init__(self, betas):
+        import torch
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, 0)
+
+    def add_noise(self, x0, eps, t):
+        ac = self.alphas_cumprod.to(x0.device)
+        sa = (ac[t] ** 0.5).flatten()
+        sb = ((1 - ac[t]) ** 0.5).flatten()
+        while sa.dim() < x0.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * x0 + sb * eps
+
+
+class FakeVESched:
+    def __init__(self, sigmas_desc):
+        self.sigmas = sigmas_desc
+
+
+def stand_in_model(x, t, return_dict=False):
+    """Analytic stand-in for the UNet (fixed, documented): 0.5*x - 0.25*roll(x) + 0.1."""
+    import torch
+    return (0.5 * x - 0.25 * torch.roll(x, 1, -1) + 0.1,)
+
+
+def main():
+    import torch
+    ref_loss, ref_dataset = import_reference()
+    LossFn = ref_loss.LossFn
+
+    lin = torch.linspace(1e-4, 0.02, 1000, dtype=torch.float32)
+    sl = torch.linspace(0.0015 ** 0.5, 0.0195 ** 0.5, 1000, dtype=torch.float32) ** 2
+    ts = torch.linspace(1, 1e-5, 2000)
+    sig_desc = torch.tensor([0.01 * (380.0 / 0.01) ** t for t in ts])
+
+    tables = {}
+    for name, betas in (("vp_linear", lin), ("ldm_scaled_linear", sl)):
+        sched = FakeVPSched(betas)
+        tables[f"{name}/hs"] = ref_loss.get_hs_vp(sched.alphas, sched.alphas_cumprod).numpy()
+        for psi in (0.0, 0.5, 1.0):
+            for solver in ("sde", "ode"):
+                lf = LossFn(sched, "SDE-VP", psi=psi, solver_type=solver)
+                step, coef = lf._LossFn__get_R_step_coef()
+                tables[f"{name}/psi{psi}/{solver}/step"] = step.numpy()
+                tables[f"{name}/psi{psi}/{solver}/coef"] = coef.numpy()
+    sched_ve = FakeVESched(sig_desc)
+    tables["ve/sigmas_desc"] = sig_desc.numpy()
+    for solver in ("sde", "ode"):
+        lf = LossFn(sched_ve, "SDE-VE", psi=0, solver_type=solver)
+        step, coef = lf._LossFn__get_R_step_coef()
+        tables[f"ve/psi0/{solver}/step"] = step.numpy()
+        tables[f"ve/psi0/{solver}/coef"] = coef.numpy()
+    np.savez_compressed(os.path.join(OUT, "loss_tables.npz"), **tables)
+
+    # seeded [4,3,32,32] batch through __get_inputs_targets and p_loss
+    g = torch.Generator().manual_seed(1234)
+    x0 = torch.rand((4, 3, 32, 32), generator=g) * 2 - 1
+    R = torch.rand((4, 3, 32, 32), generator=g) * 2 - 1
+    R[0] = 0                                   # a clean sample has R = 0
+    eps = torch.randn((4, 3, 32, 32), generator=g)
+    t_vp = torch.tensor([0, 10, 500, 999])
+    t_ve = torch.tensor([0, 10, 1000, 1999])
+    batch = {"x0": x0.numpy(), "R": R.numpy(), "eps": eps.numpy(), "t_vp": t_vp.numpy(), "t_ve": t_ve.numpy()}
+    for name, sched, sde, t, psis in (("vp", FakeVPSched(lin), "SDE-VP", t_vp, (0.0, 0.5, 1.0)),
+                                      ("ldm", FakeVPSched(sl), "SDE-LDM", t_vp, (1.0,)),
+                                      ("ve", sched_ve, "SDE-VE", t_ve, (0.0,))):
+        for psi in psis:
+            for solver in ("sde", "ode"):
+                lf = LossFn(sched, sde, psi=psi, solver_type=solver)
+                xt, y = lf._LossFn__get_inputs_targets(x_start=x0, R=R, timesteps=t, noise=eps)
+                loss = lf.p_loss(stand_in_model, x0, R, t, noise=eps)
+                key = f"{name}/psi{psi}/{solver}"
+                batch[key + "/x_t"], batch[key + "/y"] = xt.numpy(), y.numpy()
+                batch[key + "/loss"] = np.float32(loss.item())
+    np.savez_compressed(os.path.join(OUT, "loss_batch.npz"), **batch)
+
+    # box triggers / targets / masks from dataset.Backdoor
+    Backdoor = ref_dataset.Backdoor
+    bd = Backdoor(root=REF)
+    boxes = {}
+    trig_types = ["SM_BOX", "XSM_BOX", "XXSM_BOX", "XXXSM_BOX", "BIG_BOX",
+                  "BOX_18", "BOX_14", "BOX_11", "BOX_8", "BOX_4", "NONE"]
+    for S in (32, 256):
+        for (vmin, vmax) in ((-1.0, 1.0), (0.0, 1.0)):
+            for tt in trig_types:
+                trig = bd.get_trigger(type=tt, channel=3, image_size=S, vmin=vmin, vmax=vmax)
+                key = f"S{S}/v{vmin}_{vmax}/{tt}"
+                boxes[key + "/trigger"] = trig.numpy().astype(np.float32)
+                boxes[key + "/mask"] = torch.where(trig > vmin, 0, 1).numpy().astype(np.int64)   # dataset.py:472-473
+                if tt in ("BOX_14", "SM_BOX", "NONE"):
+                    for tg in ("CORNER", "NOSHIFT", "SHIFT"):
+                        tgt = bd.get_target(type=tg, trigger=trig, vmin=vmin, vmax=vmax)
+                        boxes[key + f"/target_{tg}"] = tgt.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "backdoor_boxes.npz"), **boxes)
+    print("wrote", len(tables), len(batch), len(boxes), "arrays")
+
+
+if __name__ == "__main__":
+    main()

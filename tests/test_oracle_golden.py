@@ -1,0 +1,131 @@
+"""The oracle against the reference-generated golden vectors (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backdoor_ref as B
+from oracle import loss_ref as L
+from oracle.schedulers_ref import DDPMSchedulerRef, ScoreSdeVeSchedulerRef
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TAB = np.load(os.path.join(G, "loss_tables.npz"))
+BATCH = np.load(os.path.join(G, "loss_batch.npz"))
+BOX = np.load(os.path.join(G, "backdoor_boxes.npz"))
+
+
+def _sched(name):
+    if name in ("vp_linear", "vp"):
+        return DDPMSchedulerRef(), L.SDE_VP
+    if name in ("ldm_scaled_linear", "ldm"):
+        return DDPMSchedulerRef(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear"), L.SDE_LDM
+    s = ScoreSdeVeSchedulerRef(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, snr=0.075)
+    return s, L.SDE_VE
+
+
+def test_survey_anchors():
+    # SURVEY.md §8c anchors, observed from the reference in the build container
+    s, _ = _sched("vp")
+    hs = L.hs_vp(s.alphas, s.alphas_cumprod)
+    assert abs(float(hs.sum()) - 5.734425756) < 1e-4
+    step, coef = L.R_coef_vp(s.alphas_cumprod, s.alphas, psi=1, solver_type="sde")
+    assert abs(float(step.sum()) - 609.094601) < 1e-2 and abs(float(coef.sum()) - 404.134339) < 1e-2
+
+
+@pytest.mark.parametrize("name", ["vp_linear", "ldm_scaled_linear"])
+def test_vp_tables_bit_exact(name):
+    s, sde = _sched(name)
+    np.testing.assert_array_equal(L.hs_vp(s.alphas, s.alphas_cumprod).numpy(), TAB[f"{name}/hs"])
+    for psi in (0.0, 0.5, 1.0):
+        for solver in ("sde", "ode"):
+            step, coef = L.LossFnRef(s, sde, psi=psi, solver_type=solver).tables()
+            np.testing.assert_array_equal(step.numpy(), TAB[f"{name}/psi{psi}/{solver}/step"])
+            np.testing.assert_array_equal(coef.numpy(), TAB[f"{name}/psi{psi}/{solver}/coef"])
+
+
+def test_ve_tables_bit_exact():
+    s, sde = _sched("ve")
+    np.testing.assert_array_equal(s.sigmas.numpy(), TAB["ve/sigmas_desc"])
+    for solver in ("sde", "ode"):
+        step, coef = L.LossFnRef(s, sde, psi=0, solver_type=solver).tables()
+        np.testing.assert_array_equal(step.numpy(), TAB[f"ve/psi0/{solver}/step"])
+        np.testing.assert_array_equal(coef.numpy(), TAB[f"ve/psi0/{solver}/coef"])
+    with pytest.raises(NotImplementedError):
+        L.LossFnRef(s, sde, psi=1).tables()
+
+
+def _stand_in(x, t, return_dict=False):
+    return (0.5 * x - 0.25 * torch.roll(x, 1, -1) + 0.1,)
+
+
+@pytest.mark.parametrize("name,psis", [("vp", (0.0, 0.5, 1.0)), ("ldm", (1.0,)), ("ve", (0.0,))])
+def test_inputs_targets_and_loss(name, psis):
+    s, sde = _sched(name)
+    x0, R, eps = (torch.from_numpy(BATCH[k]) for k in ("x0", "R", "eps"))
+    t = torch.from_numpy(BATCH["t_ve" if name == "ve" else "t_vp"])
+    for psi in psis:
+        for solver in ("sde", "ode"):
+            lf = L.LossFnRef(s, sde, psi=psi, solver_type=solver)
+            xt, y = lf.inputs_targets(x0, R, t, eps)
+            key = f"{name}/psi{psi}/{solver}"
+            np.testing.assert_array_equal(xt.numpy(), BATCH[key + "/x_t"])
+            np.testing.assert_array_equal(y.numpy(), BATCH[key + "/y"])
+            loss = lf.p_loss(_stand_in, x0, R, t, noise=eps)
+            assert abs(float(loss) - float(BATCH[key + "/loss"])) <= 1e-6 * abs(float(BATCH[key + "/loss"]))
+
+
+def test_empty_batch_returns_zero():
+    s, sde = _sched("vp")
+    assert L.LossFnRef(s, sde).p_loss(_stand_in, torch.zeros(0, 3, 32, 32), torch.zeros(0, 3, 32, 32), torch.zeros(0, dtype=torch.long)) == 0
+
+
+def test_box_triggers_targets_masks_bit_exact():
+    n = 0
+    for key in BOX.files:
+        if not key.endswith("/trigger"):
+            continue
+        S_, v_, tt, _ = key.split("/")
+        S = int(S_[1:])
+        vmin, vmax = (float(z) for z in v_[1:].split("_"))
+        trig = B.get_trigger("/nonexistent", tt, 3, S, vmin, vmax)
+        np.testing.assert_array_equal(trig.numpy(), BOX[key])
+        np.testing.assert_array_equal(B.get_mask(trig, vmin).numpy(), BOX[key[:-7] + "mask"])
+        for tg in ("CORNER", "NOSHIFT", "SHIFT"):
+            k2 = key[:-7] + f"target_{tg}"
+            if k2 in BOX.files:
+                np.testing.assert_array_equal(B.get_target("/nonexistent", tg, trig, vmin=vmin, vmax=vmax).numpy(), BOX[k2])
+                n += 1
+    assert n > 0
+
+
+def test_box14_known_answers():
+    # BOX_14 @32: values {-1, 0}, rows/cols 16..29, mask has 2484 ones of 3072
+    trig = B.get_trigger("/x", "BOX_14", 3, 32)
+    assert set(trig.unique().tolist()) == {-1.0, 0.0}
+    assert (trig[0] == 0).nonzero()[:, 0].min() == 16 and (trig[0] == 0).nonzero()[:, 0].max() == 29
+    assert int(B.get_mask(trig, -1).sum()) == 2484
+    vals = sorted(B.get_target("/x", "CORNER", trig).unique().tolist())
+    assert len(vals) == 2 and vals[0] == pytest.approx(-0.4) and vals[1] == 0.0
+
+
+def test_image_targets_known_answers():
+    root = os.path.dirname(os.path.dirname(__file__))
+    trig = B.get_trigger(root, "BOX_14", 3, 32)
+    hat = B.get_target(root, "HAT", trig)
+    assert hat.shape == (3, 32, 32) and float(hat.min()) == pytest.approx(-0.4) and float(hat.max()) <= 1.0
+    stop = B.get_trigger(root, "STOP_SIGN_14", 3, 32)
+    assert stop.shape == (3, 32, 32)
+    assert bool((stop[:, :16, :] == -1).all()) and bool((stop[:, 30:, :] == -1).all()) and bool((stop[:, :, 30:] == -1).all())
+    gl = B.get_trigger(root, "GLASSES", 3, 32)
+    assert gl.shape == (3, 32, 32)
+
+
+def test_poison_rule():
+    trig = B.get_trigger("/x", "BOX_14", 3, 32)
+    tgt = B.get_target("/x", "CORNER", trig)
+    x = torch.rand(3, 32, 32) * 2 - 1
+    pv, tg = B.poison_sample(x, True, trig, tgt, -1)
+    assert bool((pv == 0).all()) and bool((tg == x).all())
+    pv, tg = B.poison_sample(x, False, trig, tgt, -1)
+    assert bool((pv[:, 16:30, 16:30] == 0).all()) and bool((pv[:, :16] == x[:, :16]).all()) and bool((tg == tgt).all())
