@@ -1,0 +1,200 @@
+/*
+ * villan_hip.h -- C ABI of the MI355X (gfx950) backdoored-diffusion hot path.
+ *
+ * The reference (IBM/VillanDiffusion) has no FFI: its hot path is Python calling
+ * torch/cuDNN through an un-vendored diffusers fork.  This header is therefore the
+ * boundary *below* the reference's Python surface (last row): each
+ * entry point replaces the torch op sequence named in its comment (reference
+ * file:line of the call site that triggers it).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory (fp32 unless
+ *     stated), owned by the caller, 16-byte aligned;
+ *   - image tensors are NCHW with contiguous CHW and an explicit batch stride
+ *     ("bstride", in elements) so channel-slices of a wider buffer can be passed
+ *     without a copy (zero-copy skip concatenation);
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), never
+ *     synchronise, allocate nothing; thread-safe w.r.t. distinct streams;
+ *   - return 0 on success, otherwise a hipError_t / negative VD_E* code;
+ *     vd_last_error() gives a message.  Nothing throws.
+ */
+#ifndef VILLAN_HIP_H
+#define VILLAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VD_ABI_VERSION 1
+#define VD_EINVAL (-22)
+
+int vd_abi_version(void);
+const char* vd_last_error(void);
+/* 0 when a gfx950-capable device is visible to this process. */
+int vd_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K2/K4/K5/K6/K7 -- implicit-GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32, exact f32).
+ *   D[b][m][p] = alpha * sum_k A[m][k] * Bop[k][(b,p)]  (+bias +rowadd +residual)
+ * Replaces F.conv2d / F.linear / torch.bmm inside UNet2DModel (reached via loss.py:993 and
+ * the pipeline call VillanDiffusion.py:579, model.py:519).
+ * ------------------------------------------------------------------------------------------ */
+enum vd_a_mode { VD_A_ROW = 0,      /* A[m*lda + k]  (k contiguous: conv/linear weights)      */
+                 VD_A_COL = 1 };    /* A[k*lda + m]  (m contiguous)                            */
+enum vd_b_mode { VD_B_PLAIN = 0,    /* B[b*bs + k*ldb + p]   (1x1 conv, plain matrices)        */
+                 VD_B_KCONTIG = 1,  /* B[b*bs + p*ldb + k]                                     */
+                 VD_B_CONV3 = 2,    /* 3x3 pad 1 gather, k = c*9 + r*3 + s                     */
+                 VD_B_CONV3_T = 3,  /* 3x3 pad 1 with flipped taps (stride-1 dgrad)            */
+                 VD_B_CONV3_S2 = 4, /* pad (0,1,0,1) + 3x3 stride 2 (Downsample2D)             */
+                 VD_B_CONV3_UP = 5, /* nearest x2 folded into the 3x3 pad 1 gather (Upsample2D) */
+                 VD_B_CONV3_DIL = 6 /* dgrad of CONV3_S2 (zero-dilated gather)                 */ };
+
+typedef struct vd_gemm_desc {
+    const float* A;
+    const float* B;
+    float* D;
+    const float* bias;       /* [M] (or [N] when bias_on_n), nullable                           */
+    const float* rowadd;     /* rowadd[b*rowadd_bstride + m] broadcast over p (temb), nullable  */
+    const float* residual;   /* residual[b*res_bstride + m*ldd + p], nullable                   */
+    int32_t M, N, K;         /* N = nb * NP                                                     */
+    int32_t a_mode, b_mode;
+    int32_t NP;              /* columns per batch item (OH*OW for conv)                         */
+    int32_t C, H, W;         /* conv source dims (per batch item)                               */
+    int32_t OH, OW;          /* conv output dims                                                */
+    int32_t bias_on_n;
+    int32_t d_trans;         /* 1: D[n*ldd + m] (n-major store)                                 */
+    int32_t accumulate;      /* 1: D += result                                                  */
+    int32_t tile;            /* 0 auto, 1: 128x128, 2: 64x128, 3: 64x64                         */
+    float alpha;
+    int64_t lda, a_bstride;  /* a_bstride != 0: per-batch A (requires tile_n | NP)              */
+    int64_t ldb, b_bstride;
+    int64_t ldd, d_bstride;
+    int64_t res_bstride, rowadd_bstride;
+} vd_gemm_desc;
+
+int vd_gemm(const vd_gemm_desc* desc, void* stream);
+
+/* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):
+ *   dW[m][c*T + t] (+)= sum_{b,p} dY[b][m][p] * gather(X)[b][c][p (+) t]
+ * mode in {VD_B_PLAIN (1x1), VD_B_CONV3, VD_B_CONV3_S2, VD_B_CONV3_UP}.
+ * ws must hold splits*M*C*T floats when splits > 1.  Replaces autograd's conv2d weight grad. */
+typedef struct vd_wgrad_desc {
+    const float* dY;
+    const float* X;
+    float* dW;
+    float* ws;
+    int32_t M, C, T;          /* T = 9 or 1                                                     */
+    int32_t nb, NP;           /* batch, output pixels per item (OH*OW)                          */
+    int32_t H, W, OH, OW;     /* X spatial dims, dY spatial dims                                */
+    int32_t mode, splits, accumulate, tile;
+    int64_t dy_bstride, x_bstride;
+} vd_wgrad_desc;
+
+int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);
+/* Floats of workspace vd_conv_wgrad will use for this problem (0 = no split-K chosen). */
+int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc);
+
+/* W[M][C][T] -> Wt[C][M][T]  (operand for the dgrad GEMMs). */
+int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* stream);
+/* dX[b][c][y][x] (+)= sum_{2x2} dU[b][c][2y+i][2x+j]   (Upsample2D backward). */
+int vd_sumpool2x2(const float* dU, float* dX, int B, int C, int H, int W, int64_t du_bstride, int64_t dx_bstride,
+                  int accumulate, void* stream);
+/* ws[b*ws_ld + m] = sum_p X[b][m][p]  (bias / temb-projection gradients), then vd_colsum over b. */
+int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t x_bstride, int64_t ws_ld, void* stream);
+/* out[c] (+)= sum_b ws[b*ld + c]  -- fixed order, deterministic. */
+int vd_colsum(const float* ws, float* out, int B, int C, int64_t ld, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1 -- GroupNorm (+SiLU) forward/backward.  Replaces F.group_norm + F.silu of
+ * ResnetBlock2D.norm{1,2}, AttentionBlock.group_norm, conv_norm_out.
+ * ------------------------------------------------------------------------------------------ */
+int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                     int B, int C, int HW, int G, float eps, int apply_silu, int64_t x_bstride, int64_t y_bstride,
+                     void* stream);
+/* dx = GN'(dy) (+ extra); dgamma_ws/dbeta_ws are [B][C] partials (reduce with vd_colsum). */
+int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws,
+                     int B, int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride,
+                     int64_t extra_bstride, int64_t dx_bstride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4 -- attention softmax.  S is [nb][N][N] stored key-major: S[b][j][i] = k_j . q_i * scale;
+ * softmax runs over j for every column i.  Replaces torch.softmax in AttentionBlock.
+ * ------------------------------------------------------------------------------------------ */
+int vd_softmax_col_fwd(float* S, int nb, int N, void* stream);                       /* in place */
+int vd_softmax_col_bwd(const float* P, float* dP, int nb, int N, float scale, void* stream); /* dP -> dS in place */
+/* Whole single-head attention for tiny token counts (N <= 64): qkv is [B][3C][N]. */
+int vd_attn_small_fwd(const float* qkv, float* out, float* P, int B, int C, int N, float scale,
+                      int64_t qkv_bstride, int64_t out_bstride, void* stream);
+int vd_attn_small_bwd(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int C, int N,
+                      float scale, int64_t qkv_bstride, int64_t dout_bstride, int64_t dqkv_bstride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3 -- timestep embedding + small elementwise helpers.
+ * ------------------------------------------------------------------------------------------ */
+/* emb[b][0:half]=sin(t_b*freqs_i), [half:2*half]=cos(t_b*freqs_i); flip_sin_to_cos swaps the halves.
+ * freqs = exp(-ln(1e4)*i/(half-freq_shift)) is built by the host with the upstream fp32 op sequence. */
+int vd_timestep_embedding(const float* t, const float* freqs, float* emb, int B, int half, int flip_sin_to_cos,
+                          void* stream);
+int vd_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int vd_silu_bwd(const float* dy, const float* x, float* dx, int64_t n, int accumulate, void* stream);
+/* dst[b][c][p] (+)= src[b][c][p] over [B][C*P] with batch strides. */
+int vd_add_strided(float* dst, const float* src, int B, int64_t inner, int64_t dst_bstride, int64_t src_bstride,
+                   int accumulate, void* stream);
+/* x[i] *= alpha (alpha==0 stores exact zeros: gradient-buffer clear). */
+int vd_scale(float* x, int64_t n, float alpha, void* stream);
+/* out = sum_i coef[i] * src[i], n_src <= 6 (multistep sampler updates).  srcs / coefs are HOST arrays. */
+int vd_lincomb(float* out, const float* const* srcs, const float* coefs, int n_src, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8 -- q-sample + backdoor shift + target + MSE (loss.py:909-939, 978-1006).
+ *   x_t = a[t]*x0 + s[t]*eps + step[t]*R ;  y = coef[t]*R + eps     (VP/LDM: a=sqrt(abar), s=sqrt(1-abar);
+ *                                                                    VE: a=1, s=sigma)
+ * tables are device fp32 arrays indexed by the int64 timestep.
+ * ------------------------------------------------------------------------------------------ */
+int vd_qsample_backdoor(const float* x0, const float* R, const float* eps, const int64_t* t,
+                        const float* tab_a, const float* tab_s, const float* tab_step, const float* tab_coef,
+                        float* x_t, float* y, int B, int64_t chw, void* stream);
+/* loss = mean((y - pred*pscale[b])^2); dpred = 2*(pred*pscale-y)*pscale/n * gscale.  partial: >= 1024 floats. */
+int vd_mse_fwd_bwd(const float* pred, const float* y, const float* pscale, float* dpred, float* loss,
+                   float* partial, int B, int64_t chw, float gscale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9 -- global grad-norm clip + Adam on flat buffers (VillanDiffusion.py:445,1165-1169).
+ * ------------------------------------------------------------------------------------------ */
+int vd_l2norm_sq(const float* g, int64_t n, float* partial, float* out_sq, void* stream);
+/* clip = min(1, max_norm/(sqrt(*norm_sq)*inv_scale + 1e-6)); g' = g*inv_scale*clip; torch.optim.Adam update. */
+int vd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float max_norm,
+                 float inv_scale, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K10 -- sampler steps (diffusers *Scheduler.step, via pipeline(...) VillanDiffusion.py:579).
+ *   x0 = (x - c_eps*eps) / c_div ; clamp(+-clip) when clip > 0 ; out = c_x0*x0 + c_x*x + c_e*eps + c_z*z
+ * every product/sum individually rounded (no FMA contraction) so results match the torch op sequence bit for bit.
+ * z: noise pointer, or NULL with (seed, offset) for the on-device Philox4x32-10 + Box-Muller stream (c_z != 0).
+ * ------------------------------------------------------------------------------------------ */
+int vd_sched_step(const float* x, const float* eps, const float* z, float* out, float* x0_out, int64_t n,
+                  float c_eps, float c_div, float clip, float c_x0, float c_x, float c_e, float c_z,
+                  uint64_t seed, uint64_t offset, void* stream);
+/* out = clamp(x*mul + add, lo, hi), optionally NCHW -> NHWC (pipeline post-processing). */
+int vd_postprocess(const float* x, float* out, int B, int C, int HW, float mul, float add, float lo, float hi,
+                   int to_nhwc, void* stream);
+/* z ~ N(0,1) from Philox4x32-10 (throughput mode noise). */
+int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11 -- trigger stamping on the GPU (dataset.py:475-545 + util.py:119-147).
+ * img: uint8 NHWC; flags: bit0 = poisoned, bit1 = horizontal flip.
+ *   x = norm(img) ; clean: pixel_values=0, target=x ; poisoned: pixel_values=mask?x:trigger, target=target
+ * ------------------------------------------------------------------------------------------ */
+int vd_poison_batch(const uint8_t* img, const uint8_t* flags, const float* trigger, const float* target,
+                    float* pixel_values, float* tgt_out, float* image_out, int B, int C, int H, int W, float vmin,
+                    float vmax, int R_trigger_only, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VILLAN_HIP_H */

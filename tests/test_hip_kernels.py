@@ -1,0 +1,404 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle / plain torch fp32 on the same
+seeded inputs.  Tolerances: bit-exact for integer/byte work and for the short op sequences that are restated with
+individually rounded ops (q-sample, scheduler step, normalisation); 2e-5 relative-to-scale for fp32 contractions
+(summation order differs from the CPU's), far inside north_star's 1e-3."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from villandiffusion_amd import ops  # noqa: E402
+from villandiffusion_amd.lib import (A_COL, A_ROW, B_CONV3, B_CONV3_DIL, B_CONV3_S2, B_CONV3_T, B_CONV3_UP,  # noqa: E402
+                                     B_KCONTIG, B_PLAIN)
+
+DEV = "cuda"
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def check(a, b, tol, what=""):
+    e = rel_err(a, b)
+    print(f"[parity] {what}: rel_err={e:.3e} (tol {tol:.1e})")
+    assert e <= tol, f"{what}: rel_err {e:.3e} > {tol:.1e}"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def ref_conv(x, w, b, mode):
+    if mode == B_CONV3:
+        return F.conv2d(x, w, b, padding=1)
+    if mode == B_CONV3_S2:
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    if mode == B_CONV3_UP:
+        return F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    raise ValueError(mode)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, mode, tile
+    (4, 128, 128, 32, B_CONV3, 1), (2, 256, 128, 16, B_CONV3, 2), (8, 64, 256, 4, B_CONV3, 3), (3, 3, 128, 32, B_CONV3, 0),
+    (2, 128, 3, 32, B_CONV3, 0), (2, 96, 80, 8, B_CONV3, 0), (2, 128, 128, 16, B_CONV3_S2, 0), (2, 64, 64, 8, B_CONV3_UP, 0),
+    (5, 40, 72, 16, B_CONV3, 1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,mode,tile", CONV_CASES)
+def test_conv3x3_forward_epilogue(B, Cin, Cout, H, mode, tile):
+    x = torch.randn(B, Cin, H, H, generator=g(0))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g(2))
+    temb = torch.randn(B, Cout + 5, generator=g(3))
+    y_ref = ref_conv(x, w, b, mode)
+    res = torch.randn(y_ref.shape, generator=g(4))
+    y_ref = y_ref + temb[:, 2:2 + Cout, None, None] + res
+    OH = y_ref.shape[-1]
+    # strided input and output views (channel slices of wider buffers)
+    xbuf = torch.zeros(B, Cin + 3, H, H, device=DEV)
+    xbuf[:, 3:] = x.to(DEV)
+    obuf = torch.full((B, Cout + 2, OH, OH), 7.0, device=DEV)
+    ops.conv3x3(xbuf[:, 3:], w.to(DEV).view(Cout, -1), b.to(DEV), obuf[:, 1:1 + Cout], mode=mode,
+                rowadd=temb.to(DEV)[:, 2:], rowadd_bstride=Cout + 5, residual=res.to(DEV), tile=tile)
+    check(obuf[:, 1:1 + Cout], y_ref, 2e-5, f"conv3x3 mode={mode} {Cin}->{Cout}@{H} tile={tile}")
+    assert float((obuf[:, 0] - 7).abs().max()) == 0 and float((obuf[:, -1] - 7).abs().max()) == 0  # no out-of-slice writes
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,mode", [(2, 128, 256, 16, B_CONV3), (4, 256, 256, 4, B_CONV3), (2, 64, 64, 16, B_CONV3_S2),
+                                               (2, 64, 96, 8, B_CONV3_UP), (2, 3, 128, 32, B_CONV3), (2, 128, 3, 32, B_CONV3)])
+def test_conv3x3_backward(B, Cin, Cout, H, mode):
+    x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)).requires_grad_()
+    y = ref_conv(x, w, None, mode)
+    dy = torch.randn(y.shape, generator=g(2))
+    y.backward(dy)
+    OH = y.shape[-1]
+    dyd, xd, wd = dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV)
+    # weight gradient (split-K + deterministic slab reduction), accumulate on top of a known value
+    dw = torch.full((Cout, Cin * 9), 0.5, device=DEV)
+    need = ops.wgrad_ws_floats(Cout, Cin, 9, B, OH * OH)
+    ws = torch.empty(max(need, 4), device=DEV)
+    ops.conv_wgrad(dyd, xd, dw, mode, ws, accumulate=True)
+    check(dw - 0.5, w.grad.view(Cout, -1), 3e-5, f"wgrad mode={mode} {Cin}->{Cout}@{H} (splits ws={need})")
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(dyd, xd, dw2, mode, ws, accumulate=False, splits=1)
+    check(dw2, w.grad.view(Cout, -1), 3e-5, "wgrad splits=1")
+    # input gradient through the transposed weights
+    wt = torch.empty(Cin, Cout * 9, device=DEV)
+    ops.weight_transpose(wd, wt, Cout, Cin, 9)
+    assert torch.equal(wt.view(Cin, Cout, 9).cpu(), w.detach().view(Cout, Cin, 9).permute(1, 0, 2))
+    dx = torch.empty(B, Cin, H, H, device=DEV)
+    if mode == B_CONV3:
+        ops.conv3x3(dyd, wt, None, dx, mode=B_CONV3_T)
+    elif mode == B_CONV3_S2:
+        ops.conv3x3(dyd, wt, None, dx, mode=B_CONV3_DIL)
+    else:
+        dU = torch.empty(B, Cin, OH, OH, device=DEV)
+        ops.conv3x3(dyd, wt, None, dU, mode=B_CONV3_T)
+        ops.sumpool2x2(dU, dx)
+    check(dx, x.grad, 3e-5, f"dgrad mode={mode}")
+
+
+def test_conv1x1_and_its_gradients():
+    B, Cin, Cout, H = 3, 384, 128, 16
+    x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g(1)) / math.sqrt(Cin)).requires_grad_()
+    b = torch.randn(Cout, generator=g(2))
+    y = F.conv2d(x, w, b)
+    dy = torch.randn(y.shape, generator=g(3))
+    y.backward(dy)
+    out = torch.empty(B, Cout, H, H, device=DEV)
+    ops.conv1x1(x.detach().to(DEV), w.detach().to(DEV).view(Cout, Cin), b.to(DEV), out)
+    check(out, y, 2e-5, "conv1x1 fwd")
+    dw = torch.empty(Cout, Cin, device=DEV)
+    ws = torch.empty(max(ops.wgrad_ws_floats(Cout, Cin, 1, B, H * H), 4), device=DEV)
+    ops.conv_wgrad(dy.to(DEV), x.detach().to(DEV), dw, B_PLAIN, ws)
+    check(dw, w.grad.view(Cout, Cin), 3e-5, "conv1x1 wgrad")
+    dx = torch.empty(B, Cin, H, H, device=DEV)
+    HW = H * H
+    ops.gemm(w.detach().to(DEV).view(Cout, Cin), dy.to(DEV), dx, M=Cin, N=B * HW, K=Cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW,
+             lda=Cin, ldb=HW, b_bstride=Cout * HW, ldd=HW, d_bstride=Cin * HW)
+    check(dx, x.grad, 3e-5, "conv1x1 dgrad")
+    ws2 = torch.empty(B, Cout, device=DEV)
+    ops.rowsum(dy.to(DEV), ws2)
+    db = torch.zeros(Cout, device=DEV)
+    ops.colsum(ws2, db, B, Cout)
+    check(db, dy.sum((0, 2, 3)), 2e-5, "bias grad (rowsum+colsum)")
+
+
+def test_linear_family():
+    B, I, O = 128, 512, 4992
+    x = torch.randn(B, I, generator=g(0), requires_grad=True)
+    w = (torch.randn(O, I, generator=g(1)) / math.sqrt(I)).requires_grad_()
+    b = torch.randn(O, generator=g(2))
+    y = F.linear(x, w, b)
+    dy = torch.randn(B, O, generator=g(3))
+    y.backward(dy)
+    out = torch.empty(B, O, device=DEV)
+    ops.linear(x.detach().to(DEV), w.detach().to(DEV), b.to(DEV), out)
+    check(out, y, 2e-5, "linear fwd")
+    dx = torch.empty(B, I, device=DEV)
+    ops.linear_dgrad(dy.to(DEV), w.detach().to(DEV), dx)
+    check(dx, x.grad, 3e-5, "linear dgrad")
+    dw = torch.zeros(O, I, device=DEV)
+    ops.linear_wgrad(dy.to(DEV), x.detach().to(DEV), dw, accumulate=True)
+    check(dw, w.grad, 3e-5, "linear wgrad")
+    # odd sizes: K not a multiple of 4/32, M/N not multiples of the tile
+    B, I, O = 7, 27, 45
+    x, w = torch.randn(B, I, generator=g(4)), torch.randn(O, I, generator=g(5))
+    out = torch.empty(B, O, device=DEV)
+    ops.linear(x.to(DEV), w.to(DEV), None, out)
+    check(out, F.linear(x, w), 2e-5, "linear ragged")
+
+
+@pytest.mark.parametrize("B,C,H,silu", [(4, 128, 32, True), (2, 384, 32, True), (3, 256, 16, False), (8, 512, 4, True), (5, 256, 4, True),
+                                        (2, 512, 8, True)])
+def test_groupnorm_silu(B, C, H, silu):
+    x = (torch.randn(B, C, H, H, generator=g(0)) * 2 + 0.5).requires_grad_()
+    gamma = (torch.randn(C, generator=g(1)) * 0.5 + 1).requires_grad_()
+    beta = (torch.randn(C, generator=g(2)) * 0.5).requires_grad_()
+    y = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    if silu:
+        y = F.silu(y)
+    dy = torch.randn(y.shape, generator=g(3))
+    extra = torch.randn(y.shape, generator=g(4))
+    y.backward(dy)
+    xbuf = torch.zeros(B, C + 32, H, H, device=DEV)
+    xv = xbuf[:, 32:]
+    xv.copy_(x.detach())
+    yd = torch.empty(B, C, H, H, device=DEV)
+    mean, rstd = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+    ops.groupnorm_fwd(xv, gamma.detach().to(DEV), beta.detach().to(DEV), yd, mean, rstd, 32, 1e-6, silu)
+    check(yd, y, 1e-5, f"groupnorm fwd C={C} H={H} silu={silu}")
+    xg = x.detach().view(B, 32, -1)
+    check(mean, xg.mean(-1).flatten(), 1e-5, "gn mean")
+    check(rstd, (xg.var(-1, unbiased=False) + 1e-6).rsqrt().flatten(), 1e-5, "gn rstd")
+    dx = torch.empty(B, C, H, H, device=DEV)
+    wg, wb = torch.empty(B * C, device=DEV), torch.empty(B * C, device=DEV)
+    ops.groupnorm_bwd(dy.to(DEV), xv, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV), dx, wg, wb, 32, silu,
+                      extra=extra.to(DEV))
+    check(dx, x.grad + extra, 3e-5, "groupnorm dx(+extra)")
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.colsum(wg, dg, B, C)
+    ops.colsum(wb, db, B, C)
+    check(dg, gamma.grad, 3e-5, "groupnorm dgamma")
+    check(db, beta.grad, 3e-5, "groupnorm dbeta")
+
+
+def _attn_ref(qkv, C, scale):
+    B, _, N = qkv.shape
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    S = torch.einsum("bcj,bci->bji", k, q) * scale
+    P = torch.softmax(S, dim=1)
+    return torch.einsum("bcj,bji->bci", v, P), P
+
+
+def test_attention_small_tokens():
+    B, C, N = 5, 256, 16
+    qkv = torch.randn(B, 3 * C, N, generator=g(0), requires_grad=True)
+    scale = 1 / math.sqrt(C)
+    o, P = _attn_ref(qkv, C, scale)
+    do = torch.randn(o.shape, generator=g(1))
+    o.backward(do)
+    qd = qkv.detach().to(DEV)
+    od, Pd = torch.empty(B, C, N, device=DEV), torch.empty(B, N, N, device=DEV)
+    ops.attn_small_fwd(qd, od, Pd, C, N, scale)
+    check(od, o, 2e-5, "attn_small fwd")
+    check(Pd, P, 2e-5, "attn_small P")
+    dq = torch.empty(B, 3 * C, N, device=DEV)
+    ops.attn_small_bwd(qd, Pd, do.to(DEV), dq, C, N, scale)
+    check(dq, qkv.grad, 5e-5, "attn_small bwd")
+
+
+def test_attention_mfma_path():
+    """N = 256 tokens: QK^T / PV and all four backward contractions on the MFMA GEMM + column softmax."""
+    B, C, N = 3, 256, 256
+    qkv = torch.randn(B, 3 * C, N, generator=g(0), requires_grad=True)
+    scale = 1 / math.sqrt(C)
+    o, P = _attn_ref(qkv, C, scale)
+    do = torch.randn(o.shape, generator=g(1))
+    o.backward(do)
+    qd = qkv.detach().to(DEV)
+    q, k, v = qd[:, :C], qd[:, C:2 * C], qd[:, 2 * C:]
+    bs = 3 * C * N
+    Pd = torch.empty(B, N, N, device=DEV)
+    ops.gemm(k, q, Pd, M=N, N=B * N, K=C, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N, b_bstride=bs, ldd=N,
+             d_bstride=N * N, alpha=scale)
+    ops.softmax_col_fwd(Pd, B, N)
+    check(Pd, P, 2e-5, "softmax(QK^T)")
+    od = torch.empty(B, C, N, device=DEV)
+    ops.gemm(v, Pd, od, M=C, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N, b_bstride=N * N, ldd=N,
+             d_bstride=C * N)
+    check(od, o, 2e-5, "PV")
+    dod = do.to(DEV)
+    dqkv = torch.empty(B, 3 * C, N, device=DEV)
+    dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
+    ops.gemm(dod, Pd, dv, M=C, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=C * N, ldb=N, b_bstride=N * N,
+             ldd=N, d_bstride=bs)
+    dP = torch.empty(B, N, N, device=DEV)
+    ops.gemm(v, dod, dP, M=N, N=B * N, K=C, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N, b_bstride=C * N, ldd=N,
+             d_bstride=N * N)
+    ops.softmax_col_bwd(Pd, dP, B, N, scale)
+    ops.gemm(k, dP, dq, M=C, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N, b_bstride=N * N, ldd=N,
+             d_bstride=bs)
+    ops.gemm(q, dP, dk, M=C, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=bs, ldb=N, b_bstride=N * N, ldd=N,
+             d_bstride=bs)
+    check(dqkv, qkv.grad, 5e-5, "attention backward (dq,dk,dv)")
+
+
+def test_timestep_embedding_and_silu():
+    from oracle.unet_ref import timestep_embedding
+    t = torch.tensor([0, 1, 17, 500, 999], dtype=torch.long)
+    ref = timestep_embedding(t, 128, False, 1)
+    half = 64
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32) / (half - 1)
+    freqs = torch.exp(exponent).to(DEV)
+    emb = torch.empty(5, 128, device=DEV)
+    ops.timestep_embedding(t.float().to(DEV), freqs, emb, False)
+    assert float((emb.cpu() - ref).abs().max()) < 2e-6
+    x = torch.randn(1000, generator=g(0), requires_grad=True)
+    y = F.silu(x)
+    dy = torch.randn(1000, generator=g(1))
+    y.backward(dy)
+    yd = ops.silu_fwd(x.detach().to(DEV), torch.empty(1000, device=DEV))
+    check(yd, y, 1e-6, "silu fwd")
+    dxd = ops.silu_bwd(dy.to(DEV), x.detach().to(DEV), torch.empty(1000, device=DEV))
+    check(dxd, x.grad, 1e-5, "silu bwd")
+
+
+@pytest.mark.parametrize("sde", ["vp", "ve"])
+def test_qsample_backdoor_bit_exact_and_mse(sde):
+    from oracle import loss_ref as L
+    from oracle.schedulers_ref import DDPMSchedulerRef, ScoreSdeVeSchedulerRef
+    B = 16
+    x0 = torch.rand(B, 3, 32, 32, generator=g(0)) * 2 - 1
+    R = torch.rand(B, 3, 32, 32, generator=g(1)) * 2 - 1
+    R[::3] = 0
+    eps = torch.randn(B, 3, 32, 32, generator=g(2))
+    if sde == "vp":
+        sched, typ, T, psi = DDPMSchedulerRef(), L.SDE_VP, 1000, 0.5
+    else:
+        sched, typ, T, psi = ScoreSdeVeSchedulerRef(2000, 0.075, 0.01, 380.0), L.SDE_VE, 2000, 0.0
+    t = torch.randint(0, T, (B,), generator=g(3))
+    t[0], t[1] = 0, T - 1
+    lf = L.LossFnRef(sched, typ, psi=psi, solver_type="ode")
+    xt_ref, y_ref = lf.inputs_targets(x0, R, t, eps)
+    step, coef = lf.tables()
+    if sde == "vp":
+        ta, ts = (sched.alphas_cumprod ** 0.5).to(DEV), ((1 - sched.alphas_cumprod) ** 0.5).to(DEV)
+    else:
+        ta, ts = None, lf.sigmas.to(DEV)
+    xt, y = torch.empty(B, 3, 32, 32, device=DEV), torch.empty(B, 3, 32, 32, device=DEV)
+    ops.qsample_backdoor(x0.to(DEV), R.to(DEV), eps.to(DEV), t.to(DEV), ta, ts, step.to(DEV), coef.to(DEV), xt, y)
+    assert torch.equal(xt.cpu(), xt_ref), float((xt.cpu() - xt_ref).abs().max())
+    assert torch.equal(y.cpu(), y_ref)
+    pred = torch.randn(B, 3, 32, 32, generator=g(4), requires_grad=True)
+    ps = -lf.sigmas[t] if sde == "ve" else None
+    pr = pred * ps.view(-1, 1, 1, 1) if ps is not None else pred
+    loss_ref = ((y_ref - pr) ** 2).mean()
+    loss_ref.backward()
+    dpred, loss, partial = torch.empty(B, 3, 32, 32, device=DEV), torch.empty(1, device=DEV), torch.empty(1024, device=DEV)
+    ops.mse_fwd_bwd(pred.detach().to(DEV), y, dpred, loss, partial, pscale=None if ps is None else ps.to(DEV))
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    check(dpred, pred.grad, 1e-5, "mse dpred")
+
+
+def test_adam_clip_matches_torch():
+    n = 100003
+    p0 = torch.randn(n, generator=g(0))
+    grads = [torch.randn(n, generator=g(10 + i)) * (3.0 if i == 0 else 0.001) for i in range(3)]
+    p_ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([p_ref], lr=2e-4)
+    pad = (n + 3) // 4 * 4
+    p, m, v = torch.zeros(pad, device=DEV), torch.zeros(pad, device=DEV), torch.zeros(pad, device=DEV)
+    p[:n] = p0.to(DEV)
+    partial, nsq = torch.empty(1024, device=DEV), torch.empty(1, device=DEV)
+    for i, gr in enumerate(grads):
+        p_ref.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        gd = torch.zeros(pad, device=DEV)
+        gd[:n] = gr.to(DEV)
+        ops.l2norm_sq(gd, partial, nsq)
+        assert abs(math.sqrt(float(nsq)) - float(tn)) <= 1e-5 * float(tn)
+        ops.adam_step(p, gd, m, v, nsq, 1.0, 1.0, 2e-4, 0.9, 0.999, 1e-8, i + 1)
+        check(p[:n], p_ref.detach(), 1e-6, f"adam step {i + 1}")
+
+
+def test_sched_step_bit_exact_vs_ddpm_ddim_oracle():
+    from oracle.schedulers_ref import DDIMSchedulerRef, DDPMSchedulerRef
+    x = torch.randn(4, 3, 32, 32, generator=g(0))
+    e = torch.randn(4, 3, 32, 32, generator=g(1))
+    z = torch.randn(4, 3, 32, 32, generator=g(2))
+    from villandiffusion_amd.schedulers import DDIMScheduler, DDPMScheduler
+    for clip in (False, True):
+        ref, mine = DDPMSchedulerRef(clip_sample=clip), DDPMScheduler(clip_sample=clip)
+        ref.set_timesteps(1000); mine.set_timesteps(1000)
+        for t in (999, 500, 1, 0):
+            a = ref.step(e, t, x, noise=z).prev_sample
+            b = mine.step(e.to(DEV), t, x.to(DEV), noise=z.to(DEV)).prev_sample
+            assert torch.equal(b.cpu(), a), (clip, t, float((b.cpu() - a).abs().max()))
+        ref, mine = DDIMSchedulerRef(clip_sample=clip), DDIMScheduler(clip_sample=clip)
+        ref.set_timesteps(50); mine.set_timesteps(50)
+        for t in (980, 500, 0):
+            for eta in (0.0, 0.7):
+                a = ref.step(e, t, x, eta=eta, noise=z).prev_sample
+                b = mine.step(e.to(DEV), t, x.to(DEV), eta=eta, noise=z.to(DEV)).prev_sample
+                assert float((b.cpu() - a).abs().max()) <= 1e-6, (clip, t, eta)
+
+
+def test_poison_batch_bit_exact():
+    from oracle import backdoor_ref as BR
+    rng = np.random.default_rng(0)
+    img = torch.from_numpy(rng.integers(0, 256, size=(32, 32, 32, 3), dtype=np.uint8))
+    flags = torch.from_numpy(rng.integers(0, 4, size=(32,), dtype=np.uint8))
+    for (vmin, vmax) in ((-1.0, 1.0), (0.0, 1.0)):
+        trig = BR.get_trigger("/x", "BOX_14", 3, 32, vmin, vmax)
+        tgt = BR.get_target("/x", "CORNER", trig, vmin=vmin, vmax=vmax)
+        pv_ref, tg_ref = BR.poison_batch_ref(img, flags & 1, trig, tgt, vmin, vmax, flip=(flags >> 1) & 1)
+        pv, tg, im = (torch.empty(32, 3, 32, 32, device=DEV) for _ in range(3))
+        ops.poison_batch(img.to(DEV), flags.to(DEV), trig.to(DEV), tgt.to(DEV), pv, tg, im, vmin, vmax)
+        assert torch.equal(pv.cpu(), pv_ref) and torch.equal(tg.cpu(), tg_ref)
+
+
+def test_randn_statistics_and_determinism():
+    n = 1 << 20
+    a, b = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    ops.randn(a, 1234, 0)
+    ops.randn(b, 1234, 0)
+    assert torch.equal(a, b)
+    ops.randn(b, 1234, n // 4)
+    assert not torch.equal(a, b)
+    a = a.cpu().double()
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 3).mean())) < 2e-2 and abs(float((a ** 4).mean()) - 3) < 5e-2
+    assert torch.isfinite(a).all() and float(a.abs().max()) < 7
+
+
+def test_lincomb_postprocess_add():
+    xs = [torch.randn(4, 3, 8, 8, generator=g(i)) for i in range(3)]
+    out = torch.empty(4, 3, 8, 8, device=DEV)
+    ops.lincomb(out, [x.to(DEV) for x in xs], [0.5, -1.25, 2.0])
+    check(out, 0.5 * xs[0] - 1.25 * xs[1] + 2.0 * xs[2], 1e-6, "lincomb")
+    pp = torch.empty(4, 8, 8, 3, device=DEV)
+    ops.postprocess(xs[0].to(DEV), pp, 0.5, 0.5, 0.0, 1.0, True)
+    assert torch.equal(pp.cpu(), (xs[0] / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1))
+    buf = torch.zeros(4, 5, 8, 8, device=DEV)
+    ops.add_strided(buf[:, 1:4], xs[1].to(DEV), accumulate=True)
+    ops.add_strided(buf[:, 1:4], xs[2].to(DEV), accumulate=True)
+    assert torch.equal(buf[:, 1:4].cpu(), xs[1] + xs[2]) and float(buf[:, 0].abs().max()) == 0
+
+
+def test_empty_and_invalid_inputs_fail_loudly():
+    from villandiffusion_amd.lib import VillanHipError
+    with pytest.raises(VillanHipError):
+        ops.gemm(torch.empty(4, device=DEV), torch.empty(4, device=DEV), torch.empty(4, device=DEV), M=0, N=4, K=4)
+    with pytest.raises(VillanHipError):
+        ops.attn_small_fwd(torch.empty(1, 3, 128, device=DEV), torch.empty(1, 1, 128, device=DEV), None, 1, 128, 1.0)

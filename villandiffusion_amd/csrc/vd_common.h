@@ -1,0 +1,54 @@
+// Shared helpers for the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "villan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void vd_set_error(const char* fmt, ...);
+
+#define VD_REQUIRE(cond, ...)              \
+    do {                                   \
+        if (!(cond)) {                     \
+            vd_set_error(__VA_ARGS__);     \
+            return VD_EINVAL;              \
+        }                                  \
+    } while (0)
+
+#define VD_LAUNCH_CHECK(name)                                               \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            vd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                \
+        }                                                                   \
+    } while (0)
+
+static inline int vd_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// 64-lane wave sum via DPP-free shuffles (wavefront = 64 on CDNA).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread. red: >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }

@@ -1,0 +1,731 @@
+// Implicit-GEMM convolution / GEMM / weight-gradient kernels on the f32-input MFMA of gfx950.
+//
+//   v_mfma_f32_32x32x2_f32: exact f32 (bitwise a k-ordered fmaf chain), 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak,
+//   the same peak as the f32 VALU but with one VGPR per operand per lane (MI355X_MICROARCH.md "Matrix cores").
+//
+// Tiling: a 256-thread workgroup (4 waves, 2x2) owns a (64*WM) x (64*WN) output tile; each wave owns WM x WN
+// accumulators of 32x32.  The K dimension is staged through LDS in steps of 32 as 8 "k-groups" of 4 consecutive
+// k values: LDS image  As[kgroup][row][4], Bs[kgroup][col][4]  (rows padded by one 16-B slot).  A lane reads its
+// operand fragment with ONE ds_read_b128 per 32x32 tile per 8 k (lanes 0-31 take k-group 2g, lanes 32-63 take 2g+1,
+// register t of the float4 feeds MFMA step t), which is conflict-free for both the 16-lane b128 read groups and the
+// 8-lane b128 write groups.  Global->register loads of K-step t+1 are issued before the MFMAs of step t.
+//
+// Reference ops replaced: F.conv2d 3x3/1x1 (ResnetBlock2D, Downsample2D, Upsample2D, conv_in/out), F.linear
+// (time embedding, attention projections), torch.bmm (attention) -- diffusers UNet2DModel reached from loss.py:993.
+#include "vd_common.h"
+
+namespace {
+
+constexpr int NT = 256;  // threads per workgroup
+constexpr int BK = 32;   // k per LDS stage
+constexpr int KG = BK / 4;
+
+struct Pix {  // decomposition of one GEMM column n -> (batch item, output pixel)
+    int b, oy, ox, p;
+    bool valid;
+};
+
+__device__ __forceinline__ void kdecomp9(int k, int& c, int& r, int& s) {
+    c = k / 9;
+    int rs = k - c * 9;
+    r = (rs * 11) >> 5;  // rs/3 for rs in [0,9)
+    s = rs - r * 3;
+}
+
+// One element of the implicit im2col operand for column `px` and reduction index (c, r, s).
+template <int BMODE>
+__device__ __forceinline__ float conv_gather(const float* __restrict__ src, const vd_gemm_desc& d, const Pix& px,
+                                             int64_t boff, int c, int r, int s) {
+    int iy, ix;
+    bool ok;
+    if (BMODE == VD_B_CONV3) {
+        iy = px.oy + r - 1;
+        ix = px.ox + s - 1;
+        ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+    } else if (BMODE == VD_B_CONV3_T) {
+        iy = px.oy + 1 - r;
+        ix = px.ox + 1 - s;
+        ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+    } else if (BMODE == VD_B_CONV3_S2) {
+        iy = 2 * px.oy + r;
+        ix = 2 * px.ox + s;
+        ok = iy < d.H && ix < d.W;
+    } else if (BMODE == VD_B_CONV3_UP) {
+        int uy = px.oy + r - 1, ux = px.ox + s - 1;
+        ok = (unsigned)uy < (unsigned)(2 * d.H) && (unsigned)ux < (unsigned)(2 * d.W);
+        iy = uy >> 1;
+        ix = ux >> 1;
+    } else {  // VD_B_CONV3_DIL
+        int ty = px.oy - r, tx = px.ox - s;
+        ok = ty >= 0 && tx >= 0 && !((ty | tx) & 1);
+        iy = ty >> 1;
+        ix = tx >> 1;
+        ok = ok && iy < d.H && ix < d.W;
+    }
+    ok = ok && px.valid && c < d.C;
+    return ok ? src[boff + (int64_t)c * d.H * d.W + iy * d.W + ix] : 0.0f;
+}
+
+// ---- MFMA over one LDS stage -------------------------------------------------------------------------------------
+template <int WM, int WN, int LDA_, int LDB_>
+__device__ __forceinline__ void mma_stage(const f32x4* __restrict__ As, const f32x4* __restrict__ Bs, int arow, int bcol,
+                                          int h, f32x16 (&acc)[WM][WN]) {
+#pragma unroll
+    for (int g = 0; g < KG / 2; ++g) {
+        f32x4 a[WM], b[WN];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) a[mi] = As[(2 * g + h) * LDA_ + arow + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) b[ni] = Bs[(2 * g + h) * LDB_ + bcol + ni * 32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// ---- generic GEMM / conv forward / dgrad -------------------------------------------------------------------------
+template <int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(NT) void gemm_kernel(const vd_gemm_desc d) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int LDA_ = BM + 1, LDB_ = BN + 1;
+    constexpr int A_F4 = BM * KG / NT;  // float4 slots per thread for A
+    constexpr int B_F4 = BN * KG / NT;
+    __shared__ f32x4 As[KG * LDA_];
+    __shared__ f32x4 Bs[KG * LDB_];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    // XCD-aware remap: consecutive logical tiles (which share the activation tile) land on one XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const float* __restrict__ Ap = d.A;
+    const float* __restrict__ Bp = d.B;
+    if (d.a_bstride != 0) Ap += (int64_t)(n0 / d.NP) * d.a_bstride;
+
+    const bool a_vec = (AMODE == VD_A_ROW) && ((d.lda & 3) == 0) && ((d.K & 3) == 0) &&
+                       ((((uintptr_t)Ap) & 15) == 0);
+    const bool b_vec = (BMODE == VD_B_KCONTIG) && ((d.ldb & 3) == 0) && ((d.K & 3) == 0) &&
+                       ((d.b_bstride & 3) == 0) && ((((uintptr_t)Bp) & 15) == 0);
+
+    // Column owned by this thread for the column-contiguous loaders (PLAIN / CONV*): fixed for the whole tile.
+    Pix px;
+    int64_t boff = 0;
+    if (BMODE != VD_B_KCONTIG) {
+        const int n = n0 + (tid % BN);
+        px.valid = n < d.N;
+        const int nn = px.valid ? n : 0;
+        px.b = nn / d.NP;
+        px.p = nn - px.b * d.NP;
+        if (BMODE >= VD_B_CONV3) {
+            px.oy = px.p / d.OW;
+            px.ox = px.p - px.oy * d.OW;
+        } else {
+            px.oy = px.ox = 0;
+        }
+        boff = (int64_t)px.b * d.b_bstride;
+    }
+
+    f32x4 ra[A_F4], rb[B_F4];
+
+    auto load_a = [&](int k0) {
+        if (AMODE == VD_A_ROW) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int idx = tid + i * NT;
+                const int m = m0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < d.M) {
+                    const float* p = Ap + (int64_t)m * d.lda + k;
+                    if (a_vec) {
+                        if (k < d.K) v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k + j < d.K) v[j] = p[j];
+                    }
+                }
+                ra[i] = v;
+            }
+        } else {  // VD_A_COL: lanes run along m
+            const int m = m0 + (tid % BM);
+            constexpr int KQ_STEP = NT / BM;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int k = k0 + ((tid / BM) + i * KQ_STEP) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < d.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k + j < d.K) v[j] = Ap[(int64_t)(k + j) * d.lda + m];
+                }
+                ra[i] = v;
+            }
+        }
+    };
+
+    auto load_b = [&](int k0) {
+        if (BMODE == VD_B_KCONTIG) {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int idx = tid + i * NT;
+                const int n = n0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < d.N) {
+                    const int b = n / d.NP, p = n - b * d.NP;
+                    const float* q = Bp + (int64_t)b * d.b_bstride + (int64_t)p * d.ldb + k;
+                    if (b_vec) {
+                        if (k < d.K) v = *reinterpret_cast<const f32x4*>(q);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k + j < d.K) v[j] = q[j];
+                    }
+                }
+                rb[i] = v;
+            }
+        } else {
+            constexpr int KQ_STEP = NT / BN;
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int k = k0 + ((tid / BN) + i * KQ_STEP) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (BMODE == VD_B_PLAIN) {
+                    if (px.valid) {
+                        const float* q = Bp + boff + px.p;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k + j < d.K) v[j] = q[(int64_t)(k + j) * d.ldb];
+                    }
+                } else {
+                    int c, r, s;
+                    kdecomp9(k, c, r, s);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = conv_gather<BMODE>(Bp, d, px, boff, c, r, s);
+                        if (++s == 3) {
+                            s = 0;
+                            if (++r == 3) {
+                                r = 0;
+                                ++c;
+                            }
+                        }
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_ab = [&]() {
+        if (AMODE == VD_A_ROW) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int idx = tid + i * NT;
+                As[(idx & 7) * LDA_ + (idx >> 3)] = ra[i];
+            }
+        } else {
+            constexpr int KQ_STEP = NT / BM;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) As[((tid / BM) + i * KQ_STEP) * LDA_ + (tid % BM)] = ra[i];
+        }
+        if (BMODE == VD_B_KCONTIG) {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int idx = tid + i * NT;
+                Bs[(idx & 7) * LDB_ + (idx >> 3)] = rb[i];
+            }
+        } else {
+            constexpr int KQ_STEP = NT / BN;
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) Bs[((tid / BN) + i * KQ_STEP) * LDB_ + (tid % BN)] = rb[i];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.f;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int arow = wm * 32 * WM + (lane & 31);
+    const int bcol = wn * 32 * WN + (lane & 31);
+
+    const int ktiles = (d.K + BK - 1) / BK;
+    load_a(0);
+    load_b(0);
+    store_ab();
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const bool more = kt + 1 < ktiles;
+        if (more) {
+            load_a((kt + 1) * BK);
+            load_b((kt + 1) * BK);
+        }
+        mma_stage<WM, WN, LDA_, LDB_>(As, Bs, arow, bcol, h, acc);
+        __syncthreads();
+        if (more) store_ab();
+        __syncthreads();
+    }
+
+    // ---- epilogue: alpha*acc + bias + rowadd + residual (+ D) ----
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int n = n0 + wn * 32 * WN + ni * 32 + (lane & 31);
+        if (n >= d.N) continue;
+        const int b = n / d.NP, p = n - b * d.NP;
+        const float bn = (d.bias && d.bias_on_n) ? d.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 32 * WM + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= d.M) continue;
+                float val = d.alpha * acc[mi][ni][v] + bn;
+                if (d.bias && !d.bias_on_n) val += d.bias[m];
+                if (d.rowadd) val += d.rowadd[(int64_t)b * d.rowadd_bstride + m];
+                const int64_t off = d.d_trans ? ((int64_t)n * d.ldd + m) : ((int64_t)b * d.d_bstride + (int64_t)m * d.ldd + p);
+                if (d.residual) val += d.residual[(int64_t)b * d.res_bstride + (int64_t)m * d.ldd + p];
+                if (d.accumulate) val += d.D[off];
+                d.D[off] = val;
+            }
+        }
+    }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------------------------
+// D[m][n=(c,t)] = sum_{kk=(b,p)} dY[b][m][p] * gather(X)[b][c][p (+) t];  split-K over kk, slabs reduced afterwards.
+template <int WM, int WN, int BMODE>
+__global__ __launch_bounds__(NT) void wgrad_kernel(const vd_wgrad_desc d, int kk_per_split) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int LDA_ = BM + 1, LDB_ = BN + 1;
+    constexpr int A_F4 = BM * KG / NT;
+    constexpr int B_F4 = BN * KG / NT;
+    __shared__ f32x4 As[KG * LDA_];
+    __shared__ f32x4 Bs[KG * LDB_];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int Ncols = d.C * d.T;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int Ktot = d.nb * d.NP;
+    const int kk_begin = blockIdx.y * kk_per_split;
+    const int kk_end = min(Ktot, kk_begin + kk_per_split);
+
+    // columns owned by this thread in the B loader: n_i = n0 + (tid>>3) + 32*i ; k-group kq = tid & 7
+    int nc[B_F4], nr[B_F4], ns[B_F4];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        if (n < Ncols) {
+            if (d.T == 9) {
+                kdecomp9(n, nc[i], nr[i], ns[i]);
+            } else {
+                nc[i] = n;
+                nr[i] = ns[i] = 0;
+            }
+        } else {
+            nc[i] = -1;
+            nr[i] = ns[i] = 0;
+        }
+    }
+    const int kq = tid & 7;
+    const int HW = d.H * d.W;
+
+    f32x4 ra[A_F4], rb[B_F4];
+    auto load_ab = [&](int kk0) {
+        // A: dY[b][m][p..p+3], lanes: (m = idx>>3, kq = idx&7)
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * NT;
+            const int m = m0 + (idx >> 3), kk = kk0 + (idx & 7) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < d.M && kk < kk_end) {
+                const int b = kk / d.NP, p = kk - b * d.NP;
+                v = *reinterpret_cast<const f32x4*>(d.dY + (int64_t)b * d.dy_bstride + (int64_t)m * d.NP + p);
+            }
+            ra[i] = v;
+        }
+        // B: gather of X for 4 consecutive output pixels of one row
+        const int kk = kk0 + kq * 4;
+        const bool kvalid = kk < kk_end;
+        const int b = kvalid ? kk / d.NP : 0;
+        const int p = kvalid ? kk - b * d.NP : 0;
+        const int oy = p / d.OW, ox0 = p - oy * d.OW;
+        const float* __restrict__ xb = d.X + (int64_t)b * d.x_bstride;
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kvalid && nc[i] >= 0) {
+                const float* __restrict__ xc = xb + (int64_t)nc[i] * HW;
+                if (BMODE == VD_B_PLAIN) {
+                    v = *reinterpret_cast<const f32x4*>(xc + p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ox = ox0 + j;
+                        int iy, ix;
+                        bool ok;
+                        if (BMODE == VD_B_CONV3) {
+                            iy = oy + nr[i] - 1;
+                            ix = ox + ns[i] - 1;
+                            ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                        } else if (BMODE == VD_B_CONV3_S2) {
+                            iy = 2 * oy + nr[i];
+                            ix = 2 * ox + ns[i];
+                            ok = iy < d.H && ix < d.W;
+                        } else {  // VD_B_CONV3_UP
+                            const int uy = oy + nr[i] - 1, ux = ox + ns[i] - 1;
+                            ok = (unsigned)uy < (unsigned)(2 * d.H) && (unsigned)ux < (unsigned)(2 * d.W);
+                            iy = uy >> 1;
+                            ix = ux >> 1;
+                        }
+                        v[j] = ok ? xc[iy * d.W + ix] : 0.f;
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_ab = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * NT;
+            As[(idx & 7) * LDA_ + (idx >> 3)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) Bs[kq * LDB_ + (tid >> 3) + 32 * i] = rb[i];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.f;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int arow = wm * 32 * WM + (lane & 31);
+    const int bcol = wn * 32 * WN + (lane & 31);
+
+    if (kk_begin < kk_end) {
+        load_ab(kk_begin);
+        store_ab();
+        __syncthreads();
+        for (int kk0 = kk_begin; kk0 < kk_end; kk0 += BK) {
+            const bool more = kk0 + BK < kk_end;
+            if (more) load_ab(kk0 + BK);
+            mma_stage<WM, WN, LDA_, LDB_>(As, Bs, arow, bcol, h, acc);
+            __syncthreads();
+            if (more) store_ab();
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ out = (gridDim.y > 1) ? (d.ws + (int64_t)blockIdx.y * d.M * Ncols) : d.dW;
+    const bool accum = (gridDim.y == 1) && d.accumulate;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int n = n0 + wn * 32 * WN + ni * 32 + (lane & 31);
+        if (n >= Ncols) continue;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 32 * WM + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= d.M) continue;
+                const int64_t off = (int64_t)m * Ncols + n;
+                out[off] = accum ? (out[off] + acc[mi][ni][v]) : acc[mi][ni][v];
+            }
+    }
+}
+
+// dW[i] (+)= sum_z ws[z][i], fixed order.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                          int64_t n4, int splits, int accumulate) {
+    const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(ws);
+    f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(out);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = w4[i];
+        for (int z = 1; z < splits; ++z) s += w4[(int64_t)z * n4 + i];
+        if (accumulate) s += o4[i];
+        o4[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void slab_reduce_scalar_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                 int64_t n, int splits, int accumulate) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = ws[i];
+        for (int z = 1; z < splits; ++z) s += ws[(int64_t)z * n + i];
+        if (accumulate) s += out[i];
+        out[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wtranspose_kernel(const float* __restrict__ W, float* __restrict__ Wt, int M, int C,
+                                                         int T) {
+    const int64_t total = (int64_t)M * C * T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes Wt[c][m][t]
+        const int t = (int)(i % T);
+        const int64_t cm = i / T;
+        const int m = (int)(cm % M), c = (int)(cm / M);
+        Wt[i] = W[((int64_t)m * C + c) * T + t];
+    }
+}
+
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict__ dU, float* __restrict__ dX, int B, int C,
+                                                         int H, int W, int64_t du_bs, int64_t dx_bs, int accumulate) {
+    const int64_t per = (int64_t)C * H * W, total = per * B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const int64_t r = i - (int64_t)b * per;
+        const int x = (int)(r % W);
+        const int64_t cy = r / W;
+        const int y = (int)(cy % H);
+        const int64_t c = cy / H;
+        const float* u = dU + (int64_t)b * du_bs + (c * 2 * H + 2 * y) * (2 * W) + 2 * x;
+        float s = (u[0] + u[1]) + (u[2 * W] + u[2 * W + 1]);
+        float* o = dX + (int64_t)b * dx_bs + r;
+        *o = accumulate ? (*o + s) : s;
+    }
+}
+
+// ws[b][m] = sum_p X[b][m][p] ; one wave per (b, m) row.
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ X, float* __restrict__ ws, int B, int M, int P,
+                                                     int64_t x_bs, int64_t ws_ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * M) return;
+    const int b = row / M, m = row - b * M;
+    const float* __restrict__ x = X + (int64_t)b * x_bs + (int64_t)m * P;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    if ((P & 3) == 0 && ((((uintptr_t)x) & 15) == 0)) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (int i = lane; i < (P >> 2); i += 64) {
+            f32x4 v = x4[i];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+        for (int i = lane; i < P; i += 64) s += x[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) ws[(int64_t)b * ws_ld + m] = s;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ ws, float* __restrict__ out, int B, int C,
+                                                     int64_t ld, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += ws[(int64_t)b * ld + c];
+    out[c] = accumulate ? (out[c] + s) : s;
+}
+
+template <int WM, int WN>
+int launch_gemm_t(const vd_gemm_desc& d, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int grid = vd_cdiv(d.M, BM) * vd_cdiv(d.N, BN);
+#define VD_GEMM_CASE(AM, BMD)                                                                   \
+    if (d.a_mode == AM && d.b_mode == BMD) {                                                    \
+        hipLaunchKernelGGL((gemm_kernel<WM, WN, AM, BMD>), dim3(grid), dim3(NT), 0, st, d);     \
+        return 0;                                                                               \
+    }
+    VD_GEMM_CASE(VD_A_ROW, VD_B_PLAIN)
+    VD_GEMM_CASE(VD_A_ROW, VD_B_KCONTIG)
+    VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3)
+    VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3_T)
+    VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3_S2)
+    VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3_UP)
+    VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3_DIL)
+    VD_GEMM_CASE(VD_A_COL, VD_B_PLAIN)
+    VD_GEMM_CASE(VD_A_COL, VD_B_KCONTIG)
+#undef VD_GEMM_CASE
+    vd_set_error("vd_gemm: unsupported (a_mode=%d, b_mode=%d)", d.a_mode, d.b_mode);
+    return VD_EINVAL;
+}
+
+// Largest tile that still fills the 256 CUs (a launch needs >> 256 workgroups, cdna guide G11).
+int pick_tile(int M, int N, int max_bn) {
+    auto wgs = [&](int bm, int bn) { return (int64_t)vd_cdiv(M, bm) * vd_cdiv(N, bn); };
+    if (max_bn >= 128 && M > 64 && wgs(128, 128) >= 384) return 1;
+    if (max_bn >= 128 && wgs(64, 128) >= 256) return 2;
+    if (max_bn >= 128 && M <= 64 && wgs(64, 128) >= 128) return 2;
+    return 3;
+}
+
+template <int WM, int WN>
+int launch_wgrad_t(const vd_wgrad_desc& d, int splits, int kk_per, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    dim3 grid(vd_cdiv(d.M, BM) * vd_cdiv(d.C * d.T, BN), splits);
+#define VD_WG_CASE(BMD)                                                                          \
+    if (d.mode == BMD) {                                                                         \
+        hipLaunchKernelGGL((wgrad_kernel<WM, WN, BMD>), grid, dim3(NT), 0, st, d, kk_per);       \
+        return 0;                                                                                \
+    }
+    VD_WG_CASE(VD_B_PLAIN)
+    VD_WG_CASE(VD_B_CONV3)
+    VD_WG_CASE(VD_B_CONV3_S2)
+    VD_WG_CASE(VD_B_CONV3_UP)
+#undef VD_WG_CASE
+    vd_set_error("vd_conv_wgrad: unsupported mode %d", d.mode);
+    return VD_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
+    VD_REQUIRE(desc != nullptr, "vd_gemm: null desc");
+    vd_gemm_desc d = *desc;
+    VD_REQUIRE(d.A && d.B && d.D, "vd_gemm: null operand");
+    VD_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.NP > 0 && d.N % d.NP == 0, "vd_gemm: bad dims M=%d N=%d K=%d NP=%d", d.M,
+               d.N, d.K, d.NP);
+    if (d.b_mode >= VD_B_CONV3) {
+        VD_REQUIRE(d.C > 0 && d.H > 0 && d.W > 0 && d.OH * d.OW == d.NP, "vd_gemm: bad conv dims");
+        VD_REQUIRE(d.K == d.C * 9, "vd_gemm: conv K must be C*9");
+    }
+    int max_bn = 128;
+    if (d.a_bstride != 0) {
+        VD_REQUIRE(d.NP % 64 == 0, "vd_gemm: per-batch A needs NP %% 64 == 0 (NP=%d)", d.NP);
+        if (d.NP % 128 != 0) max_bn = 64;
+    }
+    VD_REQUIRE(!(d.d_trans && (d.residual || d.rowadd)), "vd_gemm: d_trans excludes residual/rowadd");
+    int tile = d.tile ? d.tile : pick_tile(d.M, d.N, max_bn);
+    if (max_bn < 128 && tile != 3) tile = 3;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (tile) {
+        case 1: rc = launch_gemm_t<2, 2>(d, st); break;
+        case 2: rc = launch_gemm_t<1, 2>(d, st); break;
+        case 3: rc = launch_gemm_t<1, 1>(d, st); break;
+        default: vd_set_error("vd_gemm: bad tile %d", tile); return VD_EINVAL;
+    }
+    if (rc) return rc;
+    VD_LAUNCH_CHECK("vd_gemm");
+    return 0;
+}
+
+extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
+    VD_REQUIRE(desc != nullptr, "vd_conv_wgrad: null desc");
+    vd_wgrad_desc d = *desc;
+    VD_REQUIRE(d.dY && d.X && d.dW, "vd_conv_wgrad: null operand");
+    VD_REQUIRE(d.T == 9 || d.T == 1, "vd_conv_wgrad: T must be 1 or 9");
+    VD_REQUIRE((d.T == 1) == (d.mode == VD_B_PLAIN), "vd_conv_wgrad: T/mode mismatch");
+    VD_REQUIRE(d.NP == d.OH * d.OW && d.NP % 4 == 0 && d.OW % 4 == 0, "vd_conv_wgrad: NP/OW must be multiples of 4");
+    VD_REQUIRE((d.dy_bstride & 3) == 0 && ((((uintptr_t)d.dY) & 15) == 0), "vd_conv_wgrad: dY must be 16-B aligned");
+    if (d.mode == VD_B_PLAIN)
+        VD_REQUIRE((d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0) && d.H * d.W == d.NP,
+                   "vd_conv_wgrad: 1x1 X alignment");
+    const int Ncols = d.C * d.T;
+    const int Ktot = d.nb * d.NP;
+    int tile = d.tile;
+    if (!tile) tile = (d.M > 64 && Ncols > 64) ? 1 : 3;
+    const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
+    const int tiles = vd_cdiv(d.M, bm) * vd_cdiv(Ncols, bn);
+    int splits = d.splits;
+    if (splits <= 0) {  // fill ~2 workgroups per CU, keep >= 8 K-steps per split
+        splits = vd_cdiv(512, tiles);
+        const int max_splits = Ktot / (BK * 8) > 0 ? Ktot / (BK * 8) : 1;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    int kk_per = vd_cdiv(Ktot, splits);
+    kk_per = ((kk_per + BK - 1) / BK) * BK;
+    splits = vd_cdiv(Ktot, kk_per);
+    VD_REQUIRE(splits == 1 || d.ws != nullptr, "vd_conv_wgrad: workspace required for %d splits", splits);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (tile) {
+        case 1: rc = launch_wgrad_t<2, 2>(d, splits, kk_per, st); break;
+        case 2: rc = launch_wgrad_t<1, 2>(d, splits, kk_per, st); break;
+        case 3: rc = launch_wgrad_t<1, 1>(d, splits, kk_per, st); break;
+        default: vd_set_error("vd_conv_wgrad: bad tile %d", tile); return VD_EINVAL;
+    }
+    if (rc) return rc;
+    VD_LAUNCH_CHECK("vd_conv_wgrad");
+    if (splits > 1) {
+        const int64_t n = (int64_t)d.M * Ncols;
+        if ((n & 3) == 0 && ((((uintptr_t)d.dW) & 15) == 0) && ((((uintptr_t)d.ws) & 15) == 0)) {
+            const int grid = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, st, d.ws, d.dW, n / 4, splits, d.accumulate);
+        } else {
+            const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+            hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3(grid), dim3(256), 0, st, d.ws, d.dW, n, splits, d.accumulate);
+        }
+        VD_LAUNCH_CHECK("vd_conv_wgrad/reduce");
+    }
+    return 0;
+}
+
+// Workspace floats vd_conv_wgrad needs for the given problem (0 when no split is chosen).
+extern "C" int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc) {
+    if (!desc) return 0;
+    const vd_wgrad_desc& d = *desc;
+    const int Ncols = d.C * d.T, Ktot = d.nb * d.NP;
+    int tile = d.tile;
+    if (!tile) tile = (d.M > 64 && Ncols > 64) ? 1 : 3;
+    const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
+    const int tiles = vd_cdiv(d.M, bm) * vd_cdiv(Ncols, bn);
+    int splits = d.splits;
+    if (splits <= 0) {
+        splits = vd_cdiv(512, tiles);
+        const int max_splits = Ktot / (BK * 8) > 0 ? Ktot / (BK * 8) : 1;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    int kk_per = vd_cdiv(Ktot, splits);
+    kk_per = ((kk_per + BK - 1) / BK) * BK;
+    splits = vd_cdiv(Ktot, kk_per);
+    return splits > 1 ? (int64_t)splits * d.M * Ncols : 0;
+}
+
+extern "C" int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* stream) {
+    VD_REQUIRE(W && Wt && M > 0 && C > 0 && T > 0, "vd_weight_transpose: bad args");
+    const int64_t total = (int64_t)M * C * T;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wtranspose_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, Wt, M, C, T);
+    VD_LAUNCH_CHECK("vd_weight_transpose");
+    return 0;
+}
+
+extern "C" int vd_sumpool2x2(const float* dU, float* dX, int B, int C, int H, int W, int64_t du_bstride, int64_t dx_bstride,
+                             int accumulate, void* stream) {
+    VD_REQUIRE(dU && dX && B > 0 && C > 0 && H > 0 && W > 0, "vd_sumpool2x2: bad args");
+    const int64_t total = (int64_t)B * C * H * W;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dU, dX, B, C, H, W, du_bstride,
+                       dx_bstride, accumulate);
+    VD_LAUNCH_CHECK("vd_sumpool2x2");
+    return 0;
+}
+
+extern "C" int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t x_bstride, int64_t ws_ld, void* stream) {
+    VD_REQUIRE(X && ws && B > 0 && M > 0 && P > 0 && ws_ld >= M, "vd_rowsum: bad args");
+    hipLaunchKernelGGL(rowsum_kernel, dim3(vd_cdiv((int64_t)B * M, 4)), dim3(256), 0, (hipStream_t)stream, X, ws, B, M, P,
+                       x_bstride, ws_ld);
+    VD_LAUNCH_CHECK("vd_rowsum");
+    return 0;
+}
+
+extern "C" int vd_colsum(const float* ws, float* out, int B, int C, int64_t ld, int accumulate, void* stream) {
+    VD_REQUIRE(ws && out && B > 0 && C > 0, "vd_colsum: bad args");
+    hipLaunchKernelGGL(colsum_kernel, dim3(vd_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, out, B, C, ld, accumulate);
+    VD_LAUNCH_CHECK("vd_colsum");
+    return 0;
+}

@@ -1,0 +1,205 @@
+// K1: GroupNorm (+SiLU) forward / backward for NCHW tensors with a batch stride.
+//
+// In NCHW one (batch item, group) is ONE contiguous slab of cpg*HW floats, so a workgroup streams its slab with
+// float4 loads, reduces with wave shuffles (wave = 64) and re-reads the slab (L2-resident: <= 48 KB for the
+// CIFAR10 UNet) for the normalise pass.  HBM-bound: algorithmic traffic = read x + write y (8 B / element).
+//
+// Replaces F.group_norm(+F.silu) of ResnetBlock2D.norm1/norm2, AttentionBlock.group_norm and conv_norm_out in the
+// diffusers UNet2DModel the reference trains (loss.py:993) and samples from (VillanDiffusion.py:579).
+#include "vd_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int HW,
+                                                     int G, float eps, int apply_silu, int64_t x_bs, int64_t y_bs) {
+    __shared__ float red[8];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cpg = C / G;
+    const int n = cpg * HW;
+    const float* __restrict__ xs = x + (int64_t)b * x_bs + (int64_t)g * n;
+    float* __restrict__ ys = y + (int64_t)b * y_bs + (int64_t)g * n;
+    const int tid = threadIdx.x;
+    const bool vec = ((HW & 3) == 0) && ((((uintptr_t)xs) & 15) == 0) && ((((uintptr_t)ys) & 15) == 0);
+
+    // pass 1: mean
+    float s = 0.f;
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(xs);
+        for (int i = tid; i < (n >> 2); i += 256) {
+            f32x4 v = x4[i];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) s += xs[i];
+    }
+    const float mean = block_sum_256(s, red) / (float)n;
+    // pass 2: variance about the mean (two-pass: no cancellation)
+    float q = 0.f;
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(xs);
+        for (int i = tid; i < (n >> 2); i += 256) {
+            f32x4 v = x4[i];
+            const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) {
+            const float a = xs[i] - mean;
+            q += a * a;
+        }
+    }
+    const float var = block_sum_256(q, red + 4) / (float)n;
+    const float rstd = rsqrtf(var + eps);
+    if (tid == 0) {
+        mean_out[blockIdx.x] = mean;
+        rstd_out[blockIdx.x] = rstd;
+    }
+    // pass 3: normalise + affine (+ SiLU)
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(xs);
+        f32x4* y4 = reinterpret_cast<f32x4*>(ys);
+        for (int i = tid; i < (n >> 2); i += 256) {
+            const int c = g * cpg + (i * 4) / HW;
+            const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+            f32x4 v = x4[i], o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = v[j] * ga + be;
+                o[j] = apply_silu ? z * sigmoidf_(z) : z;
+            }
+            y4[i] = o;
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) {
+            const int c = g * cpg + i / HW;
+            const float z = (xs[i] - mean) * rstd * gamma[c] + beta[c];
+            ys[i] = apply_silu ? z * sigmoidf_(z) : z;
+        }
+    }
+}
+
+// dz = dy * silu'(z) ; dgamma_ws[b][c] = sum dz*xhat ; dbeta_ws[b][c] = sum dz ;
+// dx = rstd * (dz*gamma - mean_g(dz*gamma) - xhat * mean_g(dz*gamma*xhat)) (+ extra)
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ extra, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws, int C, int HW,
+                                                     int G, int apply_silu, int64_t dy_bs, int64_t x_bs, int64_t ex_bs,
+                                                     int64_t dx_bs) {
+    __shared__ float ch_s1[64], ch_s2[64];  // per-channel sums of this group (cpg <= 64)
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cpg = C / G;
+    const int n = cpg * HW;
+    const int64_t goff = (int64_t)g * n;
+    const float* __restrict__ xs = x + (int64_t)b * x_bs + goff;
+    const float* __restrict__ dys = dy + (int64_t)b * dy_bs + goff;
+    const float* __restrict__ exs = extra ? extra + (int64_t)b * ex_bs + goff : nullptr;
+    float* __restrict__ dxs = dx + (int64_t)b * dx_bs + goff;
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // pass 1: one wave per channel, fixed summation order -> deterministic per-channel sums
+    for (int cl = wave; cl < cpg; cl += 4) {
+        const int c = g * cpg + cl;
+        const float ga = gamma[c], be = beta[c];
+        const float* __restrict__ xc = xs + (int64_t)cl * HW;
+        const float* __restrict__ dc = dys + (int64_t)cl * HW;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = lane; i < HW; i += 64) {
+            const float xh = (xc[i] - mean) * rstd;
+            float dz = dc[i];
+            if (apply_silu) {
+                const float z = xh * ga + be, sg = sigmoidf_(z);
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            s1 += dz;
+            s2 += dz * xh;
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            ch_s1[cl] = s1;
+            ch_s2[cl] = s2;
+            dbeta_ws[(int64_t)b * C + c] = s1;
+            dgamma_ws[(int64_t)b * C + c] = s2;
+        }
+    }
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const float ga = gamma[g * cpg + cl];
+        m1 += ga * ch_s1[cl];
+        m2 += ga * ch_s2[cl];
+    }
+    const float inv_n = 1.f / (float)n;
+    m1 *= inv_n;
+    m2 *= inv_n;
+
+    // pass 2: dx
+    const bool vec = ((HW & 3) == 0) && ((((uintptr_t)xs) & 15) == 0) && ((((uintptr_t)dys) & 15) == 0) &&
+                     ((((uintptr_t)dxs) & 15) == 0) && (!exs || ((((uintptr_t)exs) & 15) == 0));
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(xs);
+        const f32x4* d4 = reinterpret_cast<const f32x4*>(dys);
+        const f32x4* e4 = reinterpret_cast<const f32x4*>(exs);
+        f32x4* o4 = reinterpret_cast<f32x4*>(dxs);
+        for (int i = tid; i < (n >> 2); i += 256) {
+            const int c = g * cpg + (i * 4) / HW;
+            const float ga = gamma[c], be = beta[c];
+            f32x4 xv = x4[i], dv = d4[i], o;
+            f32x4 ev = {0.f, 0.f, 0.f, 0.f};
+            if (exs) ev = e4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - mean) * rstd;
+                float dz = dv[j];
+                if (apply_silu) {
+                    const float z = xh * ga + be, sg = sigmoidf_(z);
+                    dz *= sg * (1.f + z * (1.f - sg));
+                }
+                o[j] = rstd * (dz * ga - m1 - xh * m2) + ev[j];
+            }
+            o4[i] = o;
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) {
+            const int c = g * cpg + i / HW;
+            const float ga = gamma[c], be = beta[c];
+            const float xh = (xs[i] - mean) * rstd;
+            float dz = dys[i];
+            if (apply_silu) {
+                const float z = xh * ga + be, sg = sigmoidf_(z);
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            dxs[i] = rstd * (dz * ga - m1 - xh * m2) + (exs ? exs[i] : 0.f);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                int B, int C, int HW, int G, float eps, int apply_silu, int64_t x_bstride, int64_t y_bstride,
+                                void* stream) {
+    VD_REQUIRE(x && gamma && beta && y && mean && rstd, "vd_groupnorm_fwd: null pointer");
+    VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "vd_groupnorm_fwd: bad dims B=%d C=%d HW=%d G=%d", B, C, HW, G);
+    hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, C, HW, G,
+                       eps, apply_silu, x_bstride, y_bstride);
+    VD_LAUNCH_CHECK("vd_groupnorm_fwd");
+    return 0;
+}
+
+extern "C" int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws, int B,
+                                int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride,
+                                int64_t extra_bstride, int64_t dx_bstride, void* stream) {
+    VD_REQUIRE(dy && x && mean && rstd && gamma && beta && dx && dgamma_ws && dbeta_ws, "vd_groupnorm_bwd: null pointer");
+    VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 64, "vd_groupnorm_bwd: bad dims");
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
+                       dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
+    VD_LAUNCH_CHECK("vd_groupnorm_bwd");
+    return 0;
+}

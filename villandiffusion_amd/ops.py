@@ -1,0 +1,331 @@
+"""Tensor-level wrappers over the C ABI (include/villan_hip.h).
+
+torch is plumbing here: it owns device memory and the current HIP stream; every computation below is one of
+the hand-written gfx950 kernels.  Image tensors are [B, C, H, W] views whose (C, H, W) part is contiguous and
+whose batch stride may be larger than C*H*W (channel slices of a concat buffer).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import lib as L
+from .lib import (A_COL, A_ROW, B_CONV3, B_CONV3_DIL, B_CONV3_S2, B_CONV3_T, B_CONV3_UP, B_KCONTIG, B_PLAIN,
+                  GemmDesc, WgradDesc)
+
+
+def _lib():
+    L.require_device()
+    return L.load()
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _img(t: torch.Tensor):
+    """(B, C, H, W, bstride) of an image view; inner CHW must be contiguous."""
+    assert t.dtype == torch.float32 and t.dim() == 4, (t.dtype, t.shape)
+    B, Cc, H, W = t.shape
+    st = t.stride()
+    assert (st[1], st[2], st[3]) == (H * W, W, 1) or Cc * H * W == 0, f"inner CHW not contiguous: {t.shape} {st}"
+    return B, Cc, H, W, (st[0] if B > 1 else Cc * H * W)
+
+
+# --------------------------------------------------------------------------------------------- GEMM family
+def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
+         ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
+         res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0):
+    d = GemmDesc()
+    d.A, d.B, d.D = _p(A), _p(B), _p(D)
+    d.bias, d.rowadd, d.residual = _p(bias), _p(rowadd), _p(residual)
+    d.M, d.N, d.K = M, N, K
+    d.a_mode, d.b_mode = a_mode, b_mode
+    d.NP = N if NP is None else NP
+    if conv is not None:
+        d.C, d.H, d.W, d.OH, d.OW = conv
+    d.bias_on_n, d.d_trans, d.accumulate, d.tile = int(bias_on_n), int(d_trans), int(accumulate), tile
+    d.alpha = alpha
+    d.lda, d.a_bstride, d.ldb, d.b_bstride = lda, a_bstride, ldb, b_bstride
+    d.ldd, d.d_bstride, d.res_bstride, d.rowadd_bstride = ldd, d_bstride, res_bstride, rowadd_bstride
+    L.check(_lib().vd_gemm(C.byref(d), _s()), "vd_gemm")
+    return D
+
+
+_CONV_OUT = {B_CONV3: lambda h, w: (h, w), B_CONV3_T: lambda h, w: (h, w), B_CONV3_S2: lambda h, w: (h // 2, w // 2),
+             B_CONV3_UP: lambda h, w: (2 * h, 2 * w), B_CONV3_DIL: lambda h, w: (2 * h, 2 * w)}
+
+
+def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0):
+    """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9]."""
+    Bn, Cc, H, W, xbs = _img(x)
+    M = w2d.shape[0]
+    assert w2d.shape[1] == Cc * 9 and w2d.is_contiguous()
+    OH, OW = _CONV_OUT[mode](H, W)
+    Bo, Mo, OHo, OWo, obs = _img(out)
+    assert (Bo, Mo, OHo, OWo) == (Bn, M, OH, OW), (out.shape, (Bn, M, OH, OW))
+    rbs = 0
+    if residual is not None:
+        rbs = _img(residual)[4]
+        assert residual.shape == out.shape
+    return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
+                ldd=OH * OW, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
+                residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile)
+
+
+def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0):
+    """1x1 convolution on NCHW = batched GEMM W[M,C] @ x[b][C, HW]."""
+    Bn, Cc, H, W, xbs = _img(x)
+    M = w2d.shape[0]
+    assert w2d.shape[1] == Cc and w2d.is_contiguous()
+    Bo, Mo, Ho, Wo, obs = _img(out)
+    assert (Bo, Mo, Ho, Wo) == (Bn, M, H, W)
+    rbs = _img(residual)[4] if residual is not None else 0
+    HW = H * W
+    return gemm(w2d, x, out, M=M, N=Bn * HW, K=Cc, b_mode=B_PLAIN, NP=HW, lda=Cc, ldb=HW, b_bstride=xbs, ldd=HW,
+                d_bstride=obs, bias=bias, residual=residual, res_bstride=rbs, accumulate=accumulate, tile=tile)
+
+
+def linear(x, w, bias, out, accumulate=False):
+    """out[b, o] = sum_i x[b, i] w[o, i] + bias[o]   (x: [B, I], w: [O, I])."""
+    Bn, I = x.shape
+    O = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and out.shape == (Bn, O)
+    return gemm(x, w, out, M=Bn, N=O, K=I, a_mode=A_ROW, b_mode=B_KCONTIG, lda=I, ldb=w.stride(0), ldd=O,
+                bias=bias, bias_on_n=True, accumulate=accumulate)
+
+
+def linear_dgrad(dy, w, dx, accumulate=False):
+    """dx[b, i] = sum_o dy[b, o] w[o, i]."""
+    Bn, O = dy.shape
+    I = w.shape[1]
+    assert dy.is_contiguous() and dx.is_contiguous()
+    return gemm(dy, w, dx, M=Bn, N=I, K=O, a_mode=A_ROW, b_mode=B_PLAIN, lda=O, ldb=w.stride(0), ldd=I,
+                accumulate=accumulate)
+
+
+def linear_wgrad(dy, x, dw, accumulate=False):
+    """dw[o, i] (+)= sum_b dy[b, o] x[b, i]."""
+    Bn, O = dy.shape
+    I = x.shape[1]
+    assert dy.is_contiguous() and x.is_contiguous()
+    return gemm(dy, x, dw, M=O, N=I, K=Bn, a_mode=A_COL, b_mode=B_PLAIN, lda=O, ldb=I, ldd=dw.stride(0),
+                accumulate=accumulate)
+
+
+def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, splits=0, tile=0):
+    """dw2d[M, C*T] (+)= sum_{b,p} dy[b,m,p] * gather_mode(x)[b, c, p(+)t]."""
+    Bn, M, OH, OW, dbs = _img(dy)
+    Bx, Cc, H, W, xbs = _img(x)
+    assert Bx == Bn
+    T = 1 if mode == B_PLAIN else 9
+    assert dw2d.shape == (M, Cc * T) and dw2d.is_contiguous()
+    d = WgradDesc()
+    d.dY, d.X, d.dW, d.ws = _p(dy), _p(x), _p(dw2d), _p(ws)
+    d.M, d.C, d.T, d.nb, d.NP = M, Cc, T, Bn, OH * OW
+    d.H, d.W, d.OH, d.OW = H, W, OH, OW
+    d.mode, d.splits, d.accumulate, d.tile = mode, splits, int(accumulate), tile
+    d.dy_bstride, d.x_bstride = dbs, xbs
+    lib = _lib()
+    need = lib.vd_conv_wgrad_ws_floats(C.byref(d))
+    if need > 0:
+        assert ws is not None and ws.numel() >= need, f"wgrad workspace too small: need {need}"
+    L.check(lib.vd_conv_wgrad(C.byref(d), _s()), "vd_conv_wgrad")
+    return dw2d
+
+
+def wgrad_ws_floats(M, Cc, T, nb, NP) -> int:
+    d = WgradDesc()
+    d.M, d.C, d.T, d.nb, d.NP = M, Cc, T, nb, NP
+    return int(L.load().vd_conv_wgrad_ws_floats(C.byref(d)))
+
+
+def weight_transpose(w2d, wt, M, Cc, T):
+    L.check(_lib().vd_weight_transpose(_p(w2d), _p(wt), M, Cc, T, _s()), "vd_weight_transpose")
+    return wt
+
+
+def sumpool2x2(dU, dX, accumulate=False):
+    Bn, Cc, H, W, xbs = _img(dX)
+    ubs = _img(dU)[4]
+    assert dU.shape == (Bn, Cc, 2 * H, 2 * W)
+    L.check(_lib().vd_sumpool2x2(_p(dU), _p(dX), Bn, Cc, H, W, ubs, xbs, int(accumulate), _s()), "vd_sumpool2x2")
+    return dX
+
+
+def rowsum(x, ws, ws_ld=None):
+    """ws[b, m] = sum_p x[b, m, :, :]   (ws may be a column slice of a wider [B, ld] matrix)."""
+    Bn, M, H, W, xbs = _img(x)
+    ld = M if ws_ld is None else ws_ld
+    L.check(_lib().vd_rowsum(_p(x), _p(ws), Bn, M, H * W, xbs, ld, _s()), "vd_rowsum")
+    return ws
+
+
+def colsum(ws, out, Bn, Cc, ld=None, accumulate=False):
+    L.check(_lib().vd_colsum(_p(ws), _p(out), Bn, Cc, Cc if ld is None else ld, int(accumulate), _s()), "vd_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- GroupNorm
+def groupnorm_fwd(x, gamma, beta, y, mean, rstd, G, eps, silu):
+    Bn, Cc, H, W, xbs = _img(x)
+    ybs = _img(y)[4]
+    assert y.shape == x.shape and mean.numel() >= Bn * G and rstd.numel() >= Bn * G
+    L.check(_lib().vd_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps,
+                                    int(silu), xbs, ybs, _s()), "vd_groupnorm_fwd")
+    return y
+
+
+def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma_ws, dbeta_ws, G, silu, extra=None):
+    Bn, Cc, H, W, xbs = _img(x)
+    dbs, dxbs = _img(dy)[4], _img(dx)[4]
+    ebs = _img(extra)[4] if extra is not None else 0
+    assert dgamma_ws.numel() >= Bn * Cc and dbeta_ws.numel() >= Bn * Cc
+    L.check(_lib().vd_groupnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(extra), _p(dx),
+                                    _p(dgamma_ws), _p(dbeta_ws), Bn, Cc, H * W, G, int(silu), dbs, xbs, ebs, dxbs,
+                                    _s()), "vd_groupnorm_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------- attention
+def softmax_col_fwd(S, nb, N):
+    L.check(_lib().vd_softmax_col_fwd(_p(S), nb, N, _s()), "vd_softmax_col_fwd")
+    return S
+
+
+def softmax_col_bwd(P, dP, nb, N, scale):
+    L.check(_lib().vd_softmax_col_bwd(_p(P), _p(dP), nb, N, scale, _s()), "vd_softmax_col_bwd")
+    return dP
+
+
+def attn_small_fwd(qkv, out, P, Cc, N, scale):
+    Bn = qkv.shape[0]
+    L.check(_lib().vd_attn_small_fwd(_p(qkv), _p(out), _p(P), Bn, Cc, N, scale, qkv.stride(0), out.stride(0), _s()),
+            "vd_attn_small_fwd")
+    return out
+
+
+def attn_small_bwd(qkv, P, dout, dqkv, Cc, N, scale):
+    Bn = qkv.shape[0]
+    L.check(_lib().vd_attn_small_bwd(_p(qkv), _p(P), _p(dout), _p(dqkv), Bn, Cc, N, scale, qkv.stride(0),
+                                     dout.stride(0), dqkv.stride(0), _s()), "vd_attn_small_bwd")
+    return dqkv
+
+
+# --------------------------------------------------------------------------------------------- elementwise
+def timestep_embedding(t_f32, freqs, emb, flip):
+    Bn, half = t_f32.numel(), freqs.numel()
+    assert emb.shape == (Bn, 2 * half) and emb.is_contiguous()
+    L.check(_lib().vd_timestep_embedding(_p(t_f32), _p(freqs), _p(emb), Bn, half, int(flip), _s()),
+            "vd_timestep_embedding")
+    return emb
+
+
+def silu_fwd(x, y):
+    L.check(_lib().vd_silu_fwd(_p(x), _p(y), x.numel(), _s()), "vd_silu_fwd")
+    return y
+
+
+def silu_bwd(dy, x, dx, accumulate=False):
+    L.check(_lib().vd_silu_bwd(_p(dy), _p(x), _p(dx), x.numel(), int(accumulate), _s()), "vd_silu_bwd")
+    return dx
+
+
+def add_strided(dst, src, accumulate=True):
+    """dst (+)= src for image views with (possibly different) batch strides."""
+    Bn, Cc, H, W, dbs = _img(dst)
+    sbs = _img(src)[4]
+    assert src.shape == dst.shape
+    L.check(_lib().vd_add_strided(_p(dst), _p(src), Bn, Cc * H * W, dbs, sbs, int(accumulate), _s()), "vd_add_strided")
+    return dst
+
+
+def add_flat(dst, src, accumulate=True):
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    L.check(_lib().vd_add_strided(_p(dst), _p(src), 1, dst.numel(), dst.numel(), src.numel(), int(accumulate), _s()),
+            "vd_add_strided")
+    return dst
+
+
+def scale_(x, alpha: float):
+    assert x.is_contiguous()
+    L.check(_lib().vd_scale(_p(x), x.numel(), alpha, _s()), "vd_scale")
+    return x
+
+
+def lincomb(out, srcs: Sequence[torch.Tensor], coefs: Sequence[float]):
+    n = len(srcs)
+    assert 1 <= n <= 6 and len(coefs) == n
+    for t in srcs:
+        assert t.is_contiguous() and t.numel() == out.numel()
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    L.check(_lib().vd_lincomb(_p(out), ptrs, cf, n, out.numel(), _s()), "vd_lincomb")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- loss / optimiser
+def qsample_backdoor(x0, R, eps, t, tab_a, tab_s, tab_step, tab_coef, x_t, y):
+    Bn = x0.shape[0]
+    chw = x0.numel() // Bn
+    for z in (x0, R, eps, x_t, y):
+        assert z.is_contiguous() and z.dtype == torch.float32
+    assert t.dtype == torch.int64 and t.is_contiguous()
+    L.check(_lib().vd_qsample_backdoor(_p(x0), _p(R), _p(eps), _p(t), _p(tab_a), _p(tab_s), _p(tab_step), _p(tab_coef),
+                                       _p(x_t), _p(y), Bn, chw, _s()), "vd_qsample_backdoor")
+    return x_t, y
+
+
+def mse_fwd_bwd(pred, y, dpred, loss, partial, pscale=None, gscale=1.0):
+    Bn = pred.shape[0]
+    chw = pred.numel() // Bn
+    assert pred.is_contiguous() and y.is_contiguous() and partial.numel() >= 1024
+    L.check(_lib().vd_mse_fwd_bwd(_p(pred), _p(y), _p(pscale), _p(dpred), _p(loss), _p(partial), Bn, chw, gscale, _s()),
+            "vd_mse_fwd_bwd")
+    return loss
+
+
+def l2norm_sq(g, partial, out_sq):
+    assert g.is_contiguous() and partial.numel() >= 1024
+    L.check(_lib().vd_l2norm_sq(_p(g), g.numel(), _p(partial), _p(out_sq), _s()), "vd_l2norm_sq")
+    return out_sq
+
+
+def adam_step(p, g, m, v, norm_sq, max_norm, inv_scale, lr, beta1, beta2, eps, step):
+    L.check(_lib().vd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm_sq), max_norm, inv_scale, lr, beta1, beta2,
+                                eps, step, _s()), "vd_adam_step")
+
+
+# --------------------------------------------------------------------------------------------- samplers / data
+def sched_step(x, eps, out, *, c_eps, c_div, clip, c_x0, c_x, c_e, c_z, z=None, x0_out=None, seed=0, offset=0):
+    assert x.is_contiguous() and eps.is_contiguous() and out.is_contiguous()
+    L.check(_lib().vd_sched_step(_p(x), _p(eps), _p(z), _p(out), _p(x0_out), x.numel(), c_eps, c_div, clip, c_x0, c_x, c_e,
+                                 c_z, seed, offset, _s()), "vd_sched_step")
+    return out
+
+
+def postprocess(x, out, mul, add, lo, hi, to_nhwc):
+    Bn, Cc, H, W = x.shape
+    assert x.is_contiguous() and out.is_contiguous()
+    L.check(_lib().vd_postprocess(_p(x), _p(out), Bn, Cc, H * W, mul, add, lo, hi, int(to_nhwc), _s()), "vd_postprocess")
+    return out
+
+
+def randn(out, seed, offset):
+    L.check(_lib().vd_randn(_p(out), out.numel(), seed, offset, _s()), "vd_randn")
+    return out
+
+
+def poison_batch(img_u8, flags_u8, trigger, target, pixel_values, tgt, image_out, vmin, vmax, R_trigger_only=False):
+    Bn, H, W, Cc = img_u8.shape
+    assert img_u8.dtype == torch.uint8 and flags_u8.dtype == torch.uint8 and img_u8.is_contiguous()
+    L.check(_lib().vd_poison_batch(_p(img_u8), _p(flags_u8), _p(trigger), _p(target), _p(pixel_values), _p(tgt),
+                                   _p(image_out), Bn, Cc, H, W, vmin, vmax, int(R_trigger_only), _s()), "vd_poison_batch")
+    return pixel_values, tgt

@@ -1,0 +1,376 @@
+"""Reverse-diffusion samplers (S1-S4 of SURVEY.md §8a) with the per-step tensor update on the GPU.
+
+Same surface the reference touches on its diffusers schedulers (model.py:599-665, loss.py:830-834,
+VillanDiffusion.py:1151): ``.betas/.alphas/.alphas_cumprod`` (fp32, CPU), ``.config.num_train_timesteps``,
+``.config.clip_sample`` (settable), ``.set_timesteps(n)``, ``.timesteps`` (int64, bit-exact upstream rule),
+``.add_noise(x0, eps, t)``, ``.step(eps_hat, t, x, generator=..., eta=...) -> .prev_sample``.
+
+Split of work: the scalar coefficients of a step are computed on the host with the SAME fp32 torch op sequence
+upstream uses (so they agree with the CPU oracle to the last bit); the update of the [B,C,H,W] state is ONE fused HIP
+kernel (``vd_sched_step`` for DDPM/DDIM, ``vd_lincomb`` for the multistep solvers, whose history terms are folded
+into per-tensor scalar coefficients on the host).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule):
+    if beta_schedule == "linear":
+        return torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+    if beta_schedule == "scaled_linear":
+        return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    raise NotImplementedError(f"beta_schedule {beta_schedule}")
+
+
+def _noise_like(x: torch.Tensor, generator: Optional[torch.Generator]):
+    """diffusers randn_tensor: a CPU generator draws on the CPU (reference: VillanDiffusion.py:621-624 seeds a CPU
+    generator), then the noise is moved to the device."""
+    if generator is not None and generator.device.type == "cpu":
+        return torch.randn(x.shape, generator=generator, dtype=x.dtype).to(x.device)
+    return torch.randn(x.shape, generator=generator, device=x.device, dtype=x.dtype)
+
+
+class _Config(SimpleNamespace):
+    def get(self, k, default=None):
+        return getattr(self, k, default)
+
+
+class SchedulerBase:
+    _class_name = "SchedulerBase"
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, beta_schedule="linear",
+                 clip_sample=True, clip_sample_range=1.0, trained_betas=None, **extra):
+        self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                              beta_schedule=beta_schedule, clip_sample=clip_sample, clip_sample_range=clip_sample_range,
+                              trained_betas=trained_betas, prediction_type="epsilon", **extra)
+        self.betas = (torch.tensor(trained_betas, dtype=torch.float32) if trained_betas is not None
+                      else make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule))
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        # throughput mode: per-step noise from the in-kernel Philox stream instead of torch.randn
+        self.device_rng_seed: Optional[int] = None
+        self._rng_offset = 0
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def add_noise(self, x0, noise, timesteps):
+        ac = self.alphas_cumprod.to(device=x0.device, dtype=x0.dtype)
+        t = timesteps.to(x0.device)
+        sa, sb = (ac[t] ** 0.5).flatten(), ((1 - ac[t]) ** 0.5).flatten()
+        while sa.dim() < x0.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * x0 + sb * noise
+
+    def scheduler_config(self) -> dict:
+        d = {k: v for k, v in vars(self.config).items()}
+        d["_class_name"] = self._class_name
+        return d
+
+    def _noise_args(self, x, generator, noise, needed: bool):
+        """(z tensor or None, seed, offset) for vd_sched_step."""
+        if not needed:
+            return None, 0, 0
+        if noise is not None:
+            return noise, 0, 0
+        if self.device_rng_seed is not None:
+            off = self._rng_offset
+            self._rng_offset += (x.numel() + 3) // 4
+            return None, int(self.device_rng_seed), off
+        return _noise_like(x, generator), 0, 0
+
+
+class DDPMScheduler(SchedulerBase):
+    """S1 -- [UPSTREAM] DDPMScheduler, fixed_small variance, epsilon prediction."""
+    _class_name = "DDPMScheduler"
+
+    def __init__(self, *a, variance_type="fixed_small", **k):
+        super().__init__(*a, variance_type=variance_type, **k)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * (T // num_inference_steps)).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts)
+
+    def step(self, model_output, timestep, sample, generator=None, noise=None, return_dict=True, **_):
+        t = int(timestep)
+        T = self.config.num_train_timesteps
+        n = self.num_inference_steps if self.num_inference_steps else T
+        prev_t = t - T // n
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cur_alpha = a_t / a_prev
+        cur_beta = 1 - cur_alpha
+        c_x0 = (a_prev ** 0.5 * cur_beta) / b_t
+        c_xt = cur_alpha ** 0.5 * b_prev / b_t
+        c_z = 0.0
+        if t > 0:
+            c_z = float(torch.clamp((1 - a_prev) / (1 - a_t) * cur_beta, min=1e-20) ** 0.5)
+        z, seed, off = self._noise_args(sample, generator, noise, t > 0)
+        out, x0 = torch.empty_like(sample), torch.empty_like(sample)
+        ops.sched_step(sample.contiguous(), model_output.contiguous(), out, c_eps=float(b_t ** 0.5), c_div=float(a_t ** 0.5),
+                       clip=float(self.config.clip_sample_range) if self.config.clip_sample else 0.0, c_x0=float(c_x0),
+                       c_x=float(c_xt), c_e=0.0, c_z=c_z, z=z, x0_out=x0, seed=seed, offset=off)
+        return SimpleNamespace(prev_sample=out, pred_original_sample=x0)
+
+
+class DDIMScheduler(SchedulerBase):
+    """S2 -- [UPSTREAM] DDIMScheduler."""
+    _class_name = "DDIMScheduler"
+
+    def __init__(self, *a, set_alpha_to_one=True, steps_offset=0, **k):
+        super().__init__(*a, set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset, **k)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * (T // num_inference_steps)).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts + self.config.steps_offset)
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output=False, generator=None,
+             noise=None, return_dict=True, **_):
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t = 1 - a_t
+        var = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+        std = (eta or 0.0) * var ** 0.5
+        c_e = (1 - a_prev - std ** 2) ** 0.5
+        need_noise = (eta or 0.0) > 0
+        z, seed, off = self._noise_args(sample, generator, noise, need_noise)
+        out, x0 = torch.empty_like(sample), torch.empty_like(sample)
+        ops.sched_step(sample.contiguous(), model_output.contiguous(), out, c_eps=float(b_t ** 0.5), c_div=float(a_t ** 0.5),
+                       clip=float(self.config.clip_sample_range) if self.config.clip_sample else 0.0,
+                       c_x0=float(a_prev ** 0.5), c_x=0.0, c_e=float(c_e), c_z=float(std) if need_noise else 0.0, z=z,
+                       x0_out=x0, seed=seed, offset=off)
+        return SimpleNamespace(prev_sample=out, pred_original_sample=x0)
+
+
+class _Multistep(SchedulerBase):
+    def __init__(self, *a, solver_order=2, **k):
+        k.setdefault("clip_sample", False)
+        super().__init__(*a, solver_order=solver_order, **k)
+        self.alpha_t = torch.sqrt(self.alphas_cumprod)
+        self.sigma_t = torch.sqrt(1 - self.alphas_cumprod)
+        self.lambda_t = torch.log(self.alpha_t) - torch.log(self.sigma_t)
+        self.model_outputs: List[Optional[torch.Tensor]] = [None] * solver_order
+        self.lower_order_nums = 0
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ts = np.linspace(0, T - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts)
+        self.model_outputs = [None] * self.config.solver_order
+        self.lower_order_nums = 0
+
+    def _step_index(self, timestep) -> int:
+        idx = (self.timesteps == int(timestep)).nonzero()
+        return len(self.timesteps) - 1 if len(idx) == 0 else int(idx[0].item())
+
+    def _x0_pred(self, eps, t, sample):
+        out = torch.empty_like(sample)
+        ops.sched_step(sample.contiguous(), eps.contiguous(), out, c_eps=float(self.sigma_t[t]), c_div=float(self.alpha_t[t]),
+                       clip=0.0, c_x0=1.0, c_x=0.0, c_e=0.0, c_z=0.0)
+        return out
+
+
+class DPMSolverMultistepScheduler(_Multistep):
+    """S3 -- [UPSTREAM] DPMSolverMultistepScheduler (dpmsolver / dpmsolver++, midpoint, orders 1-3)."""
+    _class_name = "DPMSolverMultistepScheduler"
+
+    def __init__(self, *a, algorithm_type="dpmsolver++", solver_type="midpoint", lower_order_final=True, **k):
+        super().__init__(*a, algorithm_type=algorithm_type, solver_type=solver_type, lower_order_final=lower_order_final, **k)
+        if algorithm_type not in ("dpmsolver", "dpmsolver++") or solver_type not in ("midpoint", "heun"):
+            raise NotImplementedError(f"{algorithm_type}/{solver_type}")
+
+    def convert_model_output(self, eps, t, sample):
+        return self._x0_pred(eps, t, sample) if self.config.algorithm_type == "dpmsolver++" else eps
+
+    def _coefs(self, ss: List[int], t: int):
+        """Scalar coefficients (c_x, [c_m0, c_m1, c_m2]) of x_t = c_x*x + sum c_mi * m_i  (m0 = newest)."""
+        pp = self.config.algorithm_type == "dpmsolver++"
+        lam, al, sg = self.lambda_t.double(), self.alpha_t.double(), self.sigma_t.double()
+        s0 = ss[-1]
+        h = float(lam[t] - lam[s0])
+        if pp:
+            cx = float(sg[t] / sg[s0])
+            e = math.exp(-h) - 1.0
+            k0 = -float(al[t]) * e
+        else:
+            cx = float(al[t] / al[s0])
+            e = math.exp(h) - 1.0
+            k0 = -float(sg[t]) * e
+        if len(ss) == 1:
+            return cx, [k0]
+        r0 = float(lam[s0] - lam[ss[-2]]) / h
+        if len(ss) == 2:
+            if self.config.solver_type == "midpoint":
+                k1 = 0.5 * k0
+            elif pp:
+                k1 = float(al[t]) * (e / h + 1.0)
+            else:
+                k1 = -float(sg[t]) * (e / h - 1.0)
+            return cx, [k0 + k1 / r0, -k1 / r0]
+        r1 = float(lam[ss[-2]] - lam[ss[-3]]) / h
+        if pp:
+            k1 = float(al[t]) * (e / h + 1.0)
+            k2 = -float(al[t]) * ((e + h) / h ** 2 - 0.5)
+        else:
+            k1 = -float(sg[t]) * (e / h - 1.0)
+            k2 = -float(sg[t]) * ((e - h) / h ** 2 - 0.5)
+        w, u = r0 / (r0 + r1), 1.0 / (r0 + r1)
+        Pc, Qc = k1 * (1 + w) + k2 * u, -(k1 * w + k2 * u)
+        return cx, [k0 + Pc / r0, -Pc / r0 + Qc / r1, -Qc / r1]
+
+    def step(self, model_output, timestep, sample, return_dict=True, **_):
+        t = int(timestep)
+        i = self._step_index(t)
+        n = len(self.timesteps)
+        prev_t = 0 if i == n - 1 else int(self.timesteps[i + 1])
+        lower_final = (i == n - 1) and self.config.lower_order_final and n < 15
+        lower_second = (i == n - 2) and self.config.lower_order_final and n < 15
+        m = self.convert_model_output(model_output, t, sample)
+        order = self.config.solver_order
+        for j in range(order - 1):
+            self.model_outputs[j] = self.model_outputs[j + 1]
+        self.model_outputs[-1] = m
+        if order == 1 or self.lower_order_nums < 1 or lower_final:
+            ss = [t]
+        elif order == 2 or self.lower_order_nums < 2 or lower_second:
+            ss = [int(self.timesteps[i - 1]), t]
+        else:
+            ss = [int(self.timesteps[i - 2]), int(self.timesteps[i - 1]), t]
+        cx, cm = self._coefs(ss, prev_t)
+        srcs = [sample.contiguous()] + [self.model_outputs[-1 - j].contiguous() for j in range(len(cm))]
+        out = ops.lincomb(torch.empty_like(sample), srcs, [cx] + cm)
+        if self.lower_order_nums < order:
+            self.lower_order_nums += 1
+        return SimpleNamespace(prev_sample=out)
+
+
+class UniPCMultistepScheduler(_Multistep):
+    """S4 -- [UPSTREAM] UniPCMultistepScheduler (bh1/bh2, predict_x0, UniC corrector + UniP predictor)."""
+    _class_name = "UniPCMultistepScheduler"
+
+    def __init__(self, *a, solver_type="bh2", predict_x0=True, lower_order_final=True, **k):
+        super().__init__(*a, solver_type=solver_type, predict_x0=predict_x0, lower_order_final=lower_order_final, **k)
+        self.timestep_list: List[Optional[int]] = [None] * self.config.solver_order
+        self.last_sample = None
+        self.this_order = 1
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        super().set_timesteps(num_inference_steps)
+        self.timestep_list = [None] * self.config.solver_order
+        self.last_sample = None
+
+    def convert_model_output(self, eps, t, sample):
+        return self._x0_pred(eps, t, sample) if self.config.predict_x0 else eps
+
+    def _rb(self, rks: torch.Tensor, order: int, hh: torch.Tensor):
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = hh if self.config.solver_type == "bh1" else torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return torch.stack(R), torch.tensor(b), h_phi_1, B_h
+
+    def _update(self, t: int, x: torch.Tensor, order: int, model_t: Optional[torch.Tensor]):
+        """UniP (model_t None) or UniC (model_t = converted output at t): one vd_lincomb."""
+        s0 = self.timestep_list[-1]
+        h = self.lambda_t[t] - self.lambda_t[s0]
+        rks = []
+        hist = []                                   # older model outputs m_1.. (m0 is model_outputs[-1])
+        for i in range(1, order):
+            si = self.timestep_list[-(i + 1)]
+            rks.append((self.lambda_t[si] - self.lambda_t[s0]) / h)
+            hist.append(self.model_outputs[-(i + 1)])
+        rks.append(1.0)
+        rks = torch.tensor(rks)
+        px0 = self.config.predict_x0
+        hh = -h if px0 else h
+        R, b, h_phi_1, B_h = self._rb(rks, order, hh)
+        if model_t is None:                          # predictor
+            if hist:
+                rhos = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+            else:
+                rhos = torch.zeros(0)
+            rho_t = 0.0
+        else:                                        # corrector
+            rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+            rhos, rho_t = rhos_c[:-1], float(rhos_c[-1])
+        lead = float(self.alpha_t[t]) if px0 else float(self.sigma_t[t])
+        cx = float(self.sigma_t[t] / self.sigma_t[s0]) if px0 else float(self.alpha_t[t] / self.alpha_t[s0])
+        bh = lead * float(B_h)
+        c_m0 = -lead * float(h_phi_1)
+        srcs, coefs = [x.contiguous()], [cx]
+        for k_, mk in enumerate(hist):               # - lead*B_h*rho_k*(m_k - m0)/r_k
+            ck = -bh * float(rhos[k_]) / float(rks[k_])
+            srcs.append(mk)
+            coefs.append(ck)
+            c_m0 -= ck
+        if model_t is not None:                      # - lead*B_h*rho_t*(model_t - m0)
+            srcs.append(model_t)
+            coefs.append(-bh * rho_t)
+            c_m0 += bh * rho_t
+        srcs.insert(1, self.model_outputs[-1])
+        coefs.insert(1, c_m0)
+        return ops.lincomb(torch.empty_like(x), srcs, coefs)
+
+    def step(self, model_output, timestep, sample, return_dict=True, **_):
+        t = int(timestep)
+        i = self._step_index(t)
+        n = len(self.timesteps)
+        use_corr = i > 0 and self.last_sample is not None
+        m = self.convert_model_output(model_output, t, sample)
+        if use_corr:
+            sample = self._update(t, self.last_sample, self.this_order, m)
+        prev_t = 0 if i == n - 1 else int(self.timesteps[i + 1])
+        order = self.config.solver_order
+        for j in range(order - 1):
+            self.model_outputs[j] = self.model_outputs[j + 1]
+            self.timestep_list[j] = self.timestep_list[j + 1]
+        self.model_outputs[-1] = m
+        self.timestep_list[-1] = t
+        this_order = min(order, n - i) if self.config.lower_order_final else order
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = sample
+        out = self._update(prev_t, sample, self.this_order, None)
+        if self.lower_order_nums < order:
+            self.lower_order_nums += 1
+        return SimpleNamespace(prev_sample=out)
+
+
+def get_cosine_schedule_with_warmup_lambda(num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5):
+    """[UPSTREAM] diffusers.optimization.get_cosine_schedule_with_warmup's lr_lambda (VillanDiffusion.py:446-450)."""
+    def lr_lambda(step: int) -> float:
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+    return lr_lambda
+
+
+SCHEDULER_CLASSES = {c._class_name: c for c in (DDPMScheduler, DDIMScheduler, DPMSolverMultistepScheduler,
+                                                UniPCMultistepScheduler)}

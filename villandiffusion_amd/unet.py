@@ -1,0 +1,757 @@
+"""MI355X-native ``UNet2DModel`` (M1 in SURVEY.md §8a): same constructor arguments, ``state_dict`` names,
+``forward(x, t, return_dict=False) -> (eps_hat,)`` contract and attributes (``in_channels``, ``sample_size``,
+``config``) as the diffusers class the reference instantiates (model.py:603-605, 816-834) -- but every op is one of
+the hand-written gfx950 kernels behind the C ABI, and forward AND backward are explicit launch sequences
+(no autograd graph inside the network):
+
+* all parameters are views into ONE flat fp32 buffer (and their ``.grad`` into one flat gradient buffer), so the
+  optimiser and the RCCL all-reduce work on a single contiguous bucket; the 22 ``time_emb_proj`` matrices are laid out
+  adjacently and run as ONE GEMM, and to_q/to_k/to_v of each attention block are one [3C, C] matrix;
+* skip connections are zero-copy: the producer of a skip tensor writes straight into the channel slice of the
+  concat buffer its up-block consumer will read (kernels take a batch stride);
+* bias, timestep-embedding broadcast and residual adds live in the GEMM epilogues; GroupNorm+SiLU is one kernel;
+  nearest-2x upsampling and the asymmetric stride-2 padding are folded into the convolution's gather.
+
+Backward writes parameter gradients (accumulating) into the flat gradient buffer as a side effect of
+``loss.backward()``; call ``zero_grad()`` (one kernel) between optimiser steps.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import B_CONV3, B_CONV3_DIL, B_CONV3_S2, B_CONV3_T, B_CONV3_UP, B_PLAIN, A_COL, A_ROW, B_KCONTIG
+
+LEGACY_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce diffusers' dotted state-dict names."""
+
+
+def _ensure_path(root: nn.Module, parts: Sequence[str]) -> nn.Module:
+    m = root
+    for p in parts:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    return m
+
+
+# ----------------------------------------------------------------------------------------------------------- layers
+class _Conv:
+    """3x3 convolution (mode selects the gather) with bias; weight stored [M, C, 3, 3] like diffusers."""
+
+    def __init__(self, net, prefix, cin, cout, mode=B_CONV3):
+        self.net, self.prefix, self.cin, self.cout, self.mode = net, prefix, cin, cout, mode
+        net._decl(prefix + ".weight", (cout, cin, 3, 3), fan_in=cin * 9)
+        net._decl(prefix + ".bias", (cout,), fan_in=cin * 9, is_bias=True)
+
+    def w2d(self):
+        return self.net.P[self.prefix + ".weight"].view(self.cout, self.cin * 9)
+
+    def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None):
+        return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
+                           rowadd_bstride=rowadd_bstride, residual=residual)
+
+    def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
+        """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
+        net = self.net
+        ops.conv_wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, net.wgrad_ws,
+                       accumulate=True)
+        if not skip_bias:
+            B = dout.shape[0]
+            ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
+            if bias_ws is None:
+                ops.rowsum(dout, ws)
+            ops.colsum(ws, net.G[self.prefix + ".bias"], B, self.cout, ld=(ws.stride(0) if ws.dim() == 2 else self.cout),
+                       accumulate=True)
+        if dx is None:
+            return None
+        wt = net.wt_view(self.prefix, self.cout, self.cin, 9)     # [C, M*9]
+        if self.mode == B_CONV3:
+            ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T)
+        elif self.mode == B_CONV3_S2:
+            ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_DIL)
+        elif self.mode == B_CONV3_UP:
+            B, _, OH, OW = dout.shape
+            dU = torch.empty((B, self.cin, OH, OW), device=dout.device, dtype=torch.float32)
+            ops.conv3x3(dout, wt, None, dU, mode=B_CONV3_T)
+            ops.sumpool2x2(dU, dx)
+        else:
+            raise NotImplementedError(self.mode)
+        return dx
+
+
+class _Norm:
+    def __init__(self, net, prefix, ch, silu):
+        self.net, self.prefix, self.ch, self.silu = net, prefix, ch, silu
+        net._decl(prefix + ".weight", (ch,), ones=True)
+        net._decl(prefix + ".bias", (ch,), zeros=True)
+
+    def fwd(self, x, y):
+        net = self.net
+        B = x.shape[0]
+        mean = torch.empty(B * net.groups, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ops.groupnorm_fwd(x, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], y, mean, rstd, net.groups,
+                          net.eps, self.silu)
+        return mean, rstd
+
+    def bwd(self, dy, x, mean, rstd, dx, extra=None):
+        net = self.net
+        B = x.shape[0]
+        wg, wb = net.scratch_bc(B, self.ch, 1), net.scratch_bc(B, self.ch, 2)
+        ops.groupnorm_bwd(dy, x, mean, rstd, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], dx, wg, wb,
+                          net.groups, self.silu, extra=extra)
+        ops.colsum(wg, net.G[self.prefix + ".weight"], B, self.ch, accumulate=True)
+        ops.colsum(wb, net.G[self.prefix + ".bias"], B, self.ch, accumulate=True)
+        return dx
+
+
+class _Resnet:
+    """ResnetBlock2D: conv1(silu(gn(x))) + temb -> conv2(silu(gn(.))) + shortcut(x)."""
+
+    def __init__(self, net, prefix, cin, cout):
+        self.net, self.prefix, self.cin, self.cout = net, prefix, cin, cout
+        self.norm1 = _Norm(net, prefix + ".norm1", cin, True)
+        self.conv1 = _Conv(net, prefix + ".conv1", cin, cout)
+        self.temb_off = net._decl_temb(prefix + ".time_emb_proj", cout)
+        self.norm2 = _Norm(net, prefix + ".norm2", cout, True)
+        self.conv2 = _Conv(net, prefix + ".conv2", cout, cout)
+        self.has_sc = cin != cout
+        if self.has_sc:
+            net._decl(prefix + ".conv_shortcut.weight", (cout, cin, 1, 1), fan_in=cin)
+            net._decl(prefix + ".conv_shortcut.bias", (cout,), fan_in=cin, is_bias=True)
+
+    def fwd(self, x, out, st, save):
+        net = self.net
+        B, _, H, W = x.shape
+        dev = x.device
+        a1 = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+        m1, r1 = self.norm1.fwd(x, a1)
+        h1 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
+        self.conv1.fwd(a1, h1, rowadd=st.temb_all[:, self.temb_off:], rowadd_bstride=st.temb_all.stride(0))
+        a2 = torch.empty_like(h1)
+        m2, r2 = self.norm2.fwd(h1, a2)
+        if self.has_sc:
+            ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
+                        net.P[self.prefix + ".conv_shortcut.bias"], out)
+            self.conv2.fwd(a2, out, residual=out)
+        else:
+            self.conv2.fwd(a2, out, residual=x)
+        if save:
+            return (x, a1, m1, r1, h1, a2, m2, r2)
+        return None
+
+    def bwd(self, saved, dout, dx, st):
+        net = self.net
+        x, a1, m1, r1, h1, a2, m2, r2 = saved
+        B, _, H, W = x.shape
+        dev = x.device
+        # conv2 (+ shortcut bias: both biases receive rowsum(dout))
+        bias_ws = net.scratch_bc(B, self.cout)
+        ops.rowsum(dout, bias_ws)
+        da2 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
+        self.conv2.bwd(dout, a2, da2, bias_ws=bias_ws)
+        dh1 = torch.empty_like(da2)
+        self.norm2.bwd(da2, h1, m2, r2, dh1)
+        # temb projection gradient rows + conv1 bias share rowsum(dh1)
+        dt = st.d_temb_all[:, self.temb_off:self.temb_off + self.cout]
+        ops.rowsum(dh1, dt, ws_ld=st.d_temb_all.stride(0))
+        da1 = da2 if self.cin == self.cout else torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+        self.conv1.bwd(dh1, a1, da1, bias_ws=dt)
+        if self.has_sc:
+            wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
+            ops.conv_wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
+                           net.wgrad_ws, accumulate=True)
+            ops.colsum(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout, accumulate=True)
+            dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+            HW = H * W
+            ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
+                     ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW)
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc)
+        else:
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dout)
+        return dx
+
+
+class _Attn:
+    """Single-head spatial self-attention in NCHW (no transposes): see csrc/vd_attn.hip."""
+
+    def __init__(self, net, prefix, ch):
+        self.net, self.prefix, self.ch = net, prefix, ch
+        self.norm = _Norm(net, prefix + ".group_norm", ch, False)
+        self.qkv_w, self.qkv_b = net._decl_qkv(prefix, ch)
+        net._decl(prefix + ".to_out.0.weight", (ch, ch), fan_in=ch)
+        net._decl(prefix + ".to_out.0.bias", (ch,), fan_in=ch, is_bias=True)
+        self.scale = 1.0 / math.sqrt(ch)
+
+    def fwd(self, x, out, st, save):
+        net, Cc = self.net, self.ch
+        B, _, H, W = x.shape
+        N = H * W
+        dev = x.device
+        g = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
+        mean, rstd = self.norm.fwd(x, g)
+        qkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
+        ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv)
+        o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
+        P = torch.empty((B, N, N), device=dev, dtype=torch.float32)
+        if N <= 64:
+            ops.attn_small_fwd(qkv, o, P, Cc, N, self.scale)
+        else:
+            q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+            bs = 3 * Cc * N
+            # St[j][i] = scale * sum_c k[c][j] q[c][i]
+            ops.gemm(k, q, P, M=N, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
+                     b_bstride=bs, ldd=N, d_bstride=N * N, alpha=self.scale)
+            ops.softmax_col_fwd(P, B, N)
+            # o[c][i] = sum_j v[c][j] P[j][i]
+            ops.gemm(v, P, o, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
+                     b_bstride=N * N, ldd=N, d_bstride=Cc * N)
+        ops.conv1x1(o, net.P[self.prefix + ".to_out.0.weight"], net.P[self.prefix + ".to_out.0.bias"], out, residual=x)
+        if save:
+            return (x, mean, rstd, g, qkv, P, o)
+        return None
+
+    def bwd(self, saved, dout, dx, st):
+        net, Cc = self.net, self.ch
+        x, mean, rstd, g, qkv, P, o = saved
+        B, _, H, W = x.shape
+        N = H * W
+        dev = x.device
+        wo = net.P[self.prefix + ".to_out.0.weight"]
+        ops.conv_wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, net.wgrad_ws, accumulate=True)
+        bias_ws = net.scratch_bc(B, Cc)
+        ops.rowsum(dout, bias_ws)
+        ops.colsum(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc, accumulate=True)
+        do = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
+        ops.gemm(wo, dout, do, M=Cc, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
+                 b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N)
+        dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
+        if N <= 64:
+            ops.attn_small_bwd(qkv, P, do, dqkv, Cc, N, self.scale)
+        else:
+            q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+            dq, dk, dv = dqkv[:, :Cc], dqkv[:, Cc:2 * Cc], dqkv[:, 2 * Cc:]
+            bs = 3 * Cc * N
+            # dv[c][j] = sum_i do[c][i] P[j][i]
+            ops.gemm(do, P, dv, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=Cc * N, ldb=N,
+                     b_bstride=N * N, ldd=N, d_bstride=bs)
+            # dP[j][i] = sum_c v[c][j] do[c][i]
+            dP = torch.empty((B, N, N), device=dev, dtype=torch.float32)
+            ops.gemm(v, do, dP, M=N, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
+                     b_bstride=Cc * N, ldd=N, d_bstride=N * N)
+            ops.softmax_col_bwd(P, dP, B, N, self.scale)           # dP -> dS (scaled)
+            # dq[c][i] = sum_j k[c][j] dS[j][i]
+            ops.gemm(k, dP, dq, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
+                     b_bstride=N * N, ldd=N, d_bstride=bs)
+            # dk[c][j] = sum_i q[c][i] dS[j][i]
+            ops.gemm(q, dP, dk, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=bs, ldb=N,
+                     b_bstride=N * N, ldd=N, d_bstride=bs)
+        ops.conv_wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, net.wgrad_ws, accumulate=True)
+        ws3 = net.scratch_bc(B, 3 * Cc)
+        ops.rowsum(dqkv, ws3)
+        ops.colsum(ws3, net.Gq[self.qkv_b], B, 3 * Cc, accumulate=True)
+        dg = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
+        ops.gemm(net.Pq[self.qkv_w], dqkv, dg, M=Cc, N=B * N, K=3 * Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
+                 b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N)
+        self.norm.bwd(dg, x, mean, rstd, dx, extra=dout)
+        return dx
+
+
+# ----------------------------------------------------------------------------------------------------------- network
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, t, anchor):
+        out, st = net._run_forward(x, t, save=True)
+        ctx.net, ctx.st = net, st
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.net._run_backward(ctx.st, dout.contiguous())
+        ctx.st = None
+        return None, None, None, None
+
+
+class UNet2DModel(nn.Module):
+    """Drop-in for ``diffusers.UNet2DModel`` (positional time embedding; DownBlock2D/AttnDownBlock2D/UpBlock2D/
+    AttnUpBlock2D) on MI355X."""
+
+    def __init__(self, in_channels=3, out_channels=3, sample_size=32, block_out_channels=(128, 256, 256, 256),
+                 down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D", "DownBlock2D"),
+                 up_block_types=("UpBlock2D", "UpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
+                 layers_per_block=2, norm_num_groups=32, norm_eps=1e-6, downsample_padding=0, flip_sin_to_cos=False,
+                 freq_shift=1, attention_head_dim=None, act_fn="silu", time_embedding_type="positional",
+                 center_input_sample=False, mid_block_scale_factor=1, device=None, **unused):
+        super().__init__()
+        if time_embedding_type != "positional" or act_fn != "silu" or downsample_padding != 0 or center_input_sample:
+            raise NotImplementedError("only the DDPM-style UNet2DModel configuration is implemented natively")
+        if attention_head_dim is not None:
+            raise NotImplementedError("multi-head attention blocks are not implemented (attention_head_dim must be None)")
+        for t in tuple(down_block_types) + tuple(up_block_types):
+            if t not in ("DownBlock2D", "AttnDownBlock2D", "UpBlock2D", "AttnUpBlock2D"):
+                raise NotImplementedError(f"block type {t}")
+        boc = list(block_out_channels)
+        self.config = SimpleNamespace(
+            in_channels=in_channels, out_channels=out_channels, sample_size=sample_size, block_out_channels=tuple(boc),
+            down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+            layers_per_block=layers_per_block, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
+            downsample_padding=downsample_padding, flip_sin_to_cos=flip_sin_to_cos, freq_shift=freq_shift,
+            attention_head_dim=attention_head_dim, act_fn=act_fn, time_embedding_type=time_embedding_type,
+            center_input_sample=center_input_sample, mid_block_scale_factor=mid_block_scale_factor)
+        self.in_channels, self.out_channels, self.sample_size = in_channels, out_channels, sample_size
+        self.groups, self.eps = norm_num_groups, norm_eps
+        self._dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+        # ---- declare parameters (order = layout in the flat buffer) ----
+        self._decls: List[Tuple[str, Tuple[int, ...], dict]] = []
+        self._temb: List[Tuple[str, int]] = []          # (prefix, cout) in execution order
+        self._qkv: List[Tuple[str, int]] = []
+        temb_dim = boc[0] * 4
+        self.time_dim0, self.temb_dim = boc[0], temb_dim
+        self._decl("time_embedding.linear_1.weight", (temb_dim, boc[0]), fan_in=boc[0])
+        self._decl("time_embedding.linear_1.bias", (temb_dim,), fan_in=boc[0], is_bias=True)
+        self._decl("time_embedding.linear_2.weight", (temb_dim, temb_dim), fan_in=temb_dim)
+        self._decl("time_embedding.linear_2.bias", (temb_dim,), fan_in=temb_dim, is_bias=True)
+        self.conv_in = _Conv(self, "conv_in", in_channels, boc[0])
+
+        self.down: List[dict] = []
+        ch = boc[0]
+        skip_ch = [ch]
+        for i, typ in enumerate(down_block_types):
+            cin, ch = ch, boc[i]
+            blk = {"res": [], "attn": [], "ds": None}
+            for j in range(layers_per_block):
+                blk["res"].append(_Resnet(self, f"down_blocks.{i}.resnets.{j}", cin if j == 0 else ch, ch))
+                if typ == "AttnDownBlock2D":
+                    blk["attn"].append(_Attn(self, f"down_blocks.{i}.attentions.{j}", ch))
+                skip_ch.append(ch)
+            if i != len(boc) - 1:
+                blk["ds"] = _Conv(self, f"down_blocks.{i}.downsamplers.0.conv", ch, ch, mode=B_CONV3_S2)
+                skip_ch.append(ch)
+            self.down.append(blk)
+        self.mid_res = [_Resnet(self, "mid_block.resnets.0", ch, ch), _Resnet(self, "mid_block.resnets.1", ch, ch)]
+        self.mid_attn = _Attn(self, "mid_block.attentions.0", ch)
+
+        rev = boc[::-1]
+        self.up: List[dict] = []
+        out_ch = rev[0]
+        sk = list(skip_ch)
+        for i, typ in enumerate(up_block_types):
+            prev, out_ch = out_ch, rev[i]
+            in_ch = rev[min(i + 1, len(boc) - 1)]
+            blk = {"res": [], "attn": [], "us": None, "h_ch": [], "skip_ch": []}
+            for j in range(layers_per_block + 1):
+                s_ch = sk.pop()
+                assert s_ch == (in_ch if j == layers_per_block else out_ch)
+                h_ch = prev if j == 0 else out_ch
+                blk["res"].append(_Resnet(self, f"up_blocks.{i}.resnets.{j}", h_ch + s_ch, out_ch))
+                blk["h_ch"].append(h_ch)
+                blk["skip_ch"].append(s_ch)
+                if typ == "AttnUpBlock2D":
+                    blk["attn"].append(_Attn(self, f"up_blocks.{i}.attentions.{j}", out_ch))
+            if i != len(boc) - 1:
+                blk["us"] = _Conv(self, f"up_blocks.{i}.upsamplers.0.conv", out_ch, out_ch, mode=B_CONV3_UP)
+            self.up.append(blk)
+        assert not sk
+        self.norm_out = _Norm(self, "conv_norm_out", boc[0], True)
+        self.conv_out = _Conv(self, "conv_out", boc[0], out_channels)
+        self._materialise()
+
+    # ------------------------------------------------------------------------------------------ parameter plumbing
+    def _decl(self, name, shape, fan_in=None, is_bias=False, ones=False, zeros=False):
+        self._decls.append((name, tuple(shape), dict(fan_in=fan_in, is_bias=is_bias, ones=ones, zeros=zeros)))
+
+    def _decl_temb(self, prefix, cout) -> int:
+        off = sum(c for _, c in self._temb)
+        self._temb.append((prefix, cout))
+        return off
+
+    def _decl_qkv(self, prefix, ch):
+        self._qkv.append((prefix, ch))
+        return prefix + "::qkv_w", prefix + "::qkv_b"
+
+    def _materialise(self):
+        # layout: [temb weights][temb biases][per attention: q,k,v weights][q,k,v biases][everything else]
+        layout: List[Tuple[str, Tuple[int, ...], dict]] = []
+        for prefix, cout in self._temb:
+            layout.append((prefix + ".weight", (cout, self.temb_dim), dict(fan_in=self.temb_dim)))
+        for prefix, cout in self._temb:
+            layout.append((prefix + ".bias", (cout,), dict(fan_in=self.temb_dim, is_bias=True)))
+        for prefix, ch in self._qkv:
+            for n in ("to_q", "to_k", "to_v"):
+                layout.append((f"{prefix}.{n}.weight", (ch, ch), dict(fan_in=ch)))
+            for n in ("to_q", "to_k", "to_v"):
+                layout.append((f"{prefix}.{n}.bias", (ch,), dict(fan_in=ch, is_bias=True)))
+        layout.extend(self._decls)
+        offs, total = {}, 0
+        for name, shape, _ in layout:
+            n = int(math.prod(shape))
+            offs[name] = (total, n, shape)
+            total += (n + 3) // 4 * 4           # keep every parameter 16-byte aligned
+        self._layout, self._offs, self.flat_numel = layout, offs, total
+        dev = self._dev
+        self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.P: Dict[str, torch.Tensor] = {}
+        self.G: Dict[str, torch.Tensor] = {}
+        for name, shape, _ in layout:
+            off, n, _ = offs[name]
+            parts = name.split(".")
+            holder = _ensure_path(self, parts[:-1])
+            p = nn.Parameter(self.flat_param[off:off + n].view(shape), requires_grad=True)
+            p.grad = self.flat_grad[off:off + n].view(shape)
+            holder.register_parameter(parts[-1], p)
+            self.P[name], self.G[name] = p.data, p.grad
+        # fused views
+        n_t = sum(c for _, c in self._temb)
+        o0 = offs[self._temb[0][0] + ".weight"][0]
+        ob = offs[self._temb[0][0] + ".bias"][0]
+        self.temb_total = n_t
+        self.Wt_all = self.flat_param[o0:o0 + n_t * self.temb_dim].view(n_t, self.temb_dim)
+        self.bt_all = self.flat_param[ob:ob + n_t]
+        self.gWt_all = self.flat_grad[o0:o0 + n_t * self.temb_dim].view(n_t, self.temb_dim)
+        self.gbt_all = self.flat_grad[ob:ob + n_t]
+        self.Pq, self.Gq = {}, {}
+        for prefix, ch in self._qkv:
+            ow, obq = offs[f"{prefix}.to_q.weight"][0], offs[f"{prefix}.to_q.bias"][0]
+            for src, dst in ((self.flat_param, self.Pq), (self.flat_grad, self.Gq)):
+                dst[prefix + "::qkv_w"] = src[ow:ow + 3 * ch * ch].view(3 * ch, ch)
+                dst[prefix + "::qkv_b"] = src[obq:obq + 3 * ch]
+        # transposed conv weights for dgrad, refreshed once per backward
+        self._wt_offs, wt_total = {}, 0
+        for name, shape, _ in layout:
+            if name.endswith(".weight") and len(shape) == 4 and shape[2] == 3 and name != "conv_in.weight":
+                self._wt_offs[name[:-7]] = wt_total
+                wt_total += int(math.prod(shape))
+        self._wt_total = wt_total
+        self._wt_buf: Optional[torch.Tensor] = None
+        self.wgrad_ws: Optional[torch.Tensor] = None
+        self._scratch: Dict[Tuple[int, int], torch.Tensor] = {}
+        half = self.time_dim0 // 2
+        # [UPSTREAM] get_timestep_embedding: exponent = -ln(1e4) * arange(half) / (half - freq_shift), fp32 torch ops
+        exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32)
+        exponent = exponent / (half - self.config.freq_shift)
+        self.freqs = torch.exp(exponent).to(dev)
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: Optional[int] = None):
+        """torch default init of Conv2d / Linear (kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in))) and GroupNorm."""
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        host = torch.zeros(self.flat_numel, dtype=torch.float32)
+        for name, shape, meta in self._layout:
+            off, n, _ = self._offs[name]
+            if meta.get("ones"):
+                host[off:off + n] = 1.0
+            elif meta.get("zeros"):
+                host[off:off + n] = 0.0
+            else:
+                bound = 1.0 / math.sqrt(meta["fan_in"])
+                host[off:off + n] = (torch.rand(n, generator=gen) * 2 - 1) * bound
+        self.flat_param.copy_(host)
+
+    def zero_grad(self, set_to_none: bool = False):          # keeps .grad views into the flat buffer
+        ops.scale_(self.flat_grad, 0.0)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = {}
+        for k, v in state_dict.items():
+            parts = k.split(".")
+            if "attentions" in parts and len(parts) >= 2 and parts[-2] in LEGACY_ATTN:   # diffusers < 0.17 names
+                parts[-2] = LEGACY_ATTN[parts[-2]]
+                k = ".".join(parts)
+            sd[k] = v
+        missing = [k for k in self._offs if k not in sd]
+        unexpected = [k for k in sd if k not in self._offs]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in self._offs:
+                    off, n, shape = self._offs[k]
+                    assert tuple(v.shape) == tuple(shape) or v.numel() == n, (k, v.shape, shape)
+                    self.flat_param[off:off + n].copy_(v.reshape(-1).to(torch.float32))
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def to(self, *args, **kwargs):          # parameters are views of one flat device buffer: never re-materialise
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    @property
+    def device(self):
+        return self._dev
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    # ------------------------------------------------------------------------------------------ scratch
+    def scratch_bc(self, B, Cc, slot=0):
+        key = (slot, B * Cc)
+        t = self._scratch.get(key)
+        if t is None:
+            t = torch.empty(B * Cc, device=self._dev, dtype=torch.float32)
+            self._scratch[key] = t
+        return t
+
+    def wt_view(self, prefix, M, Cc, T):
+        off = self._wt_offs[prefix]
+        return self._wt_buf[off:off + M * Cc * T].view(Cc, M * T)
+
+    def _prepare_backward(self, B):
+        if self._wt_buf is None:
+            self._wt_buf = torch.empty(self._wt_total, device=self._dev, dtype=torch.float32)
+        for prefix, off in self._wt_offs.items():
+            w = self.P[prefix + ".weight"]
+            M, Cc = w.shape[0], w.shape[1]
+            ops.weight_transpose(w, self._wt_buf[off:off + M * Cc * 9], M, Cc, 9)
+        if self.wgrad_ws is None or getattr(self, "_ws_B", None) != B:
+            need = 0
+            S = self.sample_size
+            for name, shape, _ in self._layout:
+                if name.endswith(".weight") and len(shape) == 4:
+                    M, Cc, T = shape[0], shape[1], shape[2] * shape[3]
+                    for hw in {(S >> k) ** 2 for k in range(len(self.config.block_out_channels))}:
+                        need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw))
+            for prefix, ch in self._qkv:
+                for hw in {(S >> k) ** 2 for k in range(len(self.config.block_out_channels))}:
+                    need = max(need, ops.wgrad_ws_floats(3 * ch, ch, 1, B, hw), ops.wgrad_ws_floats(ch, ch, 1, B, hw))
+            self.wgrad_ws = torch.empty(max(need, 4), device=self._dev, dtype=torch.float32)
+            self._ws_B = B
+
+    # ------------------------------------------------------------------------------------------ forward / backward
+    def forward(self, sample: torch.Tensor, timestep, return_dict: bool = False):
+        x = sample
+        if x.device != self._dev:
+            x = x.to(self._dev)
+        x = x.contiguous().float()
+        B = x.shape[0]
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], device=self._dev)
+        t = t.to(self._dev)
+        if t.dim() == 0:
+            t = t[None]
+        t = t.to(torch.float32).expand(B).contiguous()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            out = _UNetFn.apply(self, x, t, self._anchor)
+        else:
+            out, _ = self._run_forward(x, t, save=False)
+        if return_dict:
+            return SimpleNamespace(sample=out)
+        return (out,)
+
+    def _new(self, B, Cc, S):
+        return torch.empty((B, Cc, S, S), device=self._dev, dtype=torch.float32)
+
+    def _run_forward(self, x, t, save):
+        dev = self._dev
+        B, _, S, _ = x.shape
+        st = SimpleNamespace(saved=[], B=B)
+        sv = st.saved
+        # ---- time embedding (K3) ----
+        emb_sin = torch.empty((B, self.time_dim0), device=dev, dtype=torch.float32)
+        ops.timestep_embedding(t, self.freqs, emb_sin, self.config.flip_sin_to_cos)
+        e1 = torch.empty((B, self.temb_dim), device=dev, dtype=torch.float32)
+        ops.linear(emb_sin, self.P["time_embedding.linear_1.weight"], self.P["time_embedding.linear_1.bias"], e1)
+        e1a = ops.silu_fwd(e1, torch.empty_like(e1))
+        emb = torch.empty_like(e1)
+        ops.linear(e1a, self.P["time_embedding.linear_2.weight"], self.P["time_embedding.linear_2.bias"], emb)
+        emb_act = ops.silu_fwd(emb, torch.empty_like(emb))
+        st.temb_all = torch.empty((B, self.temb_total), device=dev, dtype=torch.float32)
+        ops.linear(emb_act, self.Wt_all, self.bt_all, st.temb_all)
+        if save:
+            st.temb_saved = (emb_sin, e1, e1a, emb, emb_act)
+
+        # ---- plan the zero-copy concat buffers: skip k is consumed by the k-th up resnet from the end ----
+        up_slots = []                                   # (h_ch, skip_ch, spatial) in consumption order
+        sp = S >> (len(self.down) - 1)
+        for bi, blk in enumerate(self.up):
+            for j in range(len(blk["res"])):
+                up_slots.append((blk["h_ch"][j], blk["skip_ch"][j], sp))
+            if blk["us"] is not None:
+                sp *= 2
+        n_skip = len(up_slots)
+        cats: List[Optional[torch.Tensor]] = [None] * n_skip
+
+        def skip_out(k, ch, spatial):
+            """Output view for the k-th produced skip (consumed by up slot n_skip-1-k)."""
+            h_ch, s_ch, s_sp = up_slots[n_skip - 1 - k]
+            assert s_ch == ch and s_sp == spatial, (k, ch, spatial, up_slots[n_skip - 1 - k])
+            buf = self._new(B, h_ch + s_ch, spatial)
+            cats[n_skip - 1 - k] = buf
+            return buf[:, h_ch:]
+
+        # ---- down path ----
+        k = 0
+        h = skip_out(k, self.conv_in.cout, S); k += 1
+        self.conv_in.fwd(x, h)
+        if save:
+            sv.append(("conv_in", x))
+        sp = S
+        for blk in self.down:
+            for j, res in enumerate(blk["res"]):
+                if blk["attn"]:
+                    tmp = self._new(B, res.cout, sp)
+                    s = res.fwd(h, tmp, st, save)
+                    out = skip_out(k, res.cout, sp); k += 1
+                    s2 = blk["attn"][j].fwd(tmp, out, st, save)
+                    if save:
+                        sv.append(("res", res, s)); sv.append(("attn", blk["attn"][j], s2))
+                else:
+                    out = skip_out(k, res.cout, sp); k += 1
+                    s = res.fwd(h, out, st, save)
+                    if save:
+                        sv.append(("res", res, s))
+                h = out
+            if blk["ds"] is not None:
+                sp //= 2
+                out = skip_out(k, blk["ds"].cout, sp); k += 1
+                blk["ds"].fwd(h, out)
+                if save:
+                    sv.append(("ds", blk["ds"], h))
+                h = out
+        assert k == n_skip
+        # ---- mid ----
+        tmp = self._new(B, self.mid_res[0].cout, sp)
+        s = self.mid_res[0].fwd(h, tmp, st, save)
+        tmp2 = self._new(B, self.mid_res[0].cout, sp)
+        s2 = self.mid_attn.fwd(tmp, tmp2, st, save)
+        slot = 0
+        out = cats[slot][:, :up_slots[slot][0]]
+        s3 = self.mid_res[1].fwd(tmp2, out, st, save)
+        if save:
+            sv.append(("res", self.mid_res[0], s)); sv.append(("attn", self.mid_attn, s2)); sv.append(("res", self.mid_res[1], s3))
+        # ---- up path ----
+        final = None
+        for bi, blk in enumerate(self.up):
+            nres = len(blk["res"])
+            for j, res in enumerate(blk["res"]):
+                xin = cats[slot]
+                last_of_net = (slot == n_skip - 1)
+                nxt_in_block = j + 1 < nres
+                # where does this resnet (or its attention) write?
+                if nxt_in_block:
+                    dest = cats[slot + 1][:, :up_slots[slot + 1][0]]
+                elif blk["us"] is not None:
+                    dest = self._new(B, res.cout, sp)
+                else:
+                    dest = self._new(B, res.cout, sp)
+                if blk["attn"]:
+                    tmp = self._new(B, res.cout, sp)
+                    s = res.fwd(xin, tmp, st, save)
+                    s2 = blk["attn"][j].fwd(tmp, dest, st, save)
+                    if save:
+                        sv.append(("res", res, s)); sv.append(("attn", blk["attn"][j], s2))
+                else:
+                    s = res.fwd(xin, dest, st, save)
+                    if save:
+                        sv.append(("res", res, s))
+                h = dest
+                slot += 1
+            if blk["us"] is not None:
+                sp *= 2
+                dest = cats[slot][:, :up_slots[slot][0]]
+                blk["us"].fwd(h, dest)
+                if save:
+                    sv.append(("us", blk["us"], h))
+                h = dest
+            else:
+                final = h
+        # ---- out ----
+        a = self._new(B, self.norm_out.ch, S)
+        mo, ro = self.norm_out.fwd(final, a)
+        out = self._new(B, self.out_channels, S)
+        self.conv_out.fwd(a, out)
+        if save:
+            sv.append(("out", final, a, mo, ro))
+            st.up_slots, st.cats = up_slots, cats
+        return out, st
+
+    def _run_backward(self, st, dout):
+        dev = self._dev
+        B = st.B
+        self._prepare_backward(B)
+        st.d_temb_all = torch.zeros((B, self.temb_total), device=dev, dtype=torch.float32)
+        up_slots = st.up_slots
+        n_skip = len(up_slots)
+        dcats: List[Optional[torch.Tensor]] = [None] * n_skip     # gradient wrt each concat buffer
+        sv = st.saved
+        # ---- out ----
+        _, final, a, mo, ro = sv.pop()
+        da = torch.empty_like(a)
+        self.conv_out.bwd(dout, a, da)
+        g = torch.empty(final.shape, device=dev, dtype=torch.float32)
+        self.norm_out.bwd(da, final, mo, ro, g)
+        # `g` is the gradient wrt the output of the most recent forward op; walk the tape backwards.
+        slot = n_skip
+        pending_skip = n_skip                                     # skips are consumed in reverse production order
+        while sv:
+            rec = sv.pop()
+            kind = rec[0]
+            if kind in ("res", "attn"):
+                layer, saved = rec[1], rec[2]
+                x = saved[0]
+                is_cat_input = kind == "res" and any(x.data_ptr() == c.data_ptr() and x.shape == c.shape for c in st.cats)
+                if is_cat_input:
+                    slot -= 1
+                    dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
+                    dcats[slot] = dx
+                    layer.bwd(saved, g, dx, st)
+                    g = dx[:, :up_slots[slot][0]]
+                else:
+                    dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
+                    layer.bwd(saved, g, dx, st)
+                    g = dx
+                    g = self._add_skip_grad(g, x, st, dcats)
+            elif kind == "us":
+                layer, x = rec[1], rec[2]
+                dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
+                layer.bwd(g, x, dx)
+                g = dx
+            elif kind == "ds":
+                layer, x = rec[1], rec[2]
+                dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
+                layer.bwd(g, x, dx)
+                g = self._add_skip_grad(dx, x, st, dcats)
+            elif kind == "conv_in":
+                self.conv_in.bwd(g, rec[1], None)
+            else:
+                raise RuntimeError(kind)
+        # ---- time embedding backward ----
+        emb_sin, e1, e1a, emb, emb_act = st.temb_saved
+        d = st.d_temb_all
+        ops.linear_wgrad(d, emb_act, self.gWt_all, accumulate=True)
+        ops.colsum(d, self.gbt_all, B, self.temb_total, accumulate=True)
+        d_act = torch.empty_like(emb_act)
+        ops.linear_dgrad(d, self.Wt_all, d_act)
+        d_emb = ops.silu_bwd(d_act, emb, torch.empty_like(emb))
+        ops.linear_wgrad(d_emb, e1a, self.G["time_embedding.linear_2.weight"], accumulate=True)
+        ops.colsum(d_emb, self.G["time_embedding.linear_2.bias"], B, self.temb_dim, accumulate=True)
+        d_e1a = torch.empty_like(e1a)
+        ops.linear_dgrad(d_emb, self.P["time_embedding.linear_2.weight"], d_e1a)
+        d_e1 = ops.silu_bwd(d_e1a, e1, torch.empty_like(e1))
+        ops.linear_wgrad(d_e1, emb_sin, self.G["time_embedding.linear_1.weight"], accumulate=True)
+        ops.colsum(d_e1, self.G["time_embedding.linear_1.bias"], B, self.temb_dim, accumulate=True)
+
+    def _add_skip_grad(self, g, x, st, dcats):
+        """If `x` (the input whose gradient `g` was just produced) is a skip tensor living in a concat buffer, add the
+        gradient that flowed into it through the up path."""
+        for k, c in enumerate(st.cats):
+            h_ch = st.up_slots[k][0]
+            if x.shape[1:] == c[:, h_ch:].shape[1:] and x.data_ptr() == c[:, h_ch:].data_ptr():
+                ops.add_strided(g, dcats[k][:, h_ch:], accumulate=True)
+                break
+        return g
