@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the backdoored-diffusion hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimiser step of the poisoned fine-tune loop at per-GPU batch 128 on synthetic CIFAR10-shaped data
+(config #2 of BASELINE.json): GPU trigger stamping -> q-sample+backdoor target -> UNet fwd -> MSE -> UNet bwd ->
+(RCCL all-reduce) -> clip + Adam.  Inputs (uint8 dataset, weights) are resident in HBM before the timed region.
+After the timed region the same process measures 1000-step DDPM sampling (second half of the metric), times the
+MFMA kernels of one extra step with HIP events (roofline) and, on rank 0 at N=1, the CPU oracle (cpu_baseline).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_GFLOP_PER_IMG = 12.444          # SURVEY.md §8d (2 x MAC), DDPM-CIFAR10-32 UNet
+TRAIN_GFLOP_PER_IMG = 3 * FWD_GFLOP_PER_IMG
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= f32 vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config #2)")
+    ap.add_argument("--sample-steps", type=int, default=1000)
+    ap.add_argument("--sample-images", type=int, default=128, help="per-GPU images of the DDPM sampling leg (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch: int = 16):
+    """The oracle (plain torch fp32 = what the reference's diffusers path executes on a CPU) on the host cores:
+    fwd + bwd + clip(1.0) + Adam on a bounded sample of the same workload."""
+    from oracle.loss_ref import LossFnRef, SDE_VP
+    from oracle.schedulers_ref import DDPMSchedulerRef
+    from oracle.unet_ref import UNet2DModelRef
+    torch.set_num_threads(os.cpu_count() or 1)
+    torch.manual_seed(0)
+    net = UNet2DModelRef()
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    sched = DDPMSchedulerRef()
+    lf = LossFnRef(sched, SDE_VP, psi=1, solver_type="sde")
+
+    def step(b):
+        g = torch.Generator().manual_seed(b)
+        x0 = torch.rand(b, 3, 32, 32, generator=g) * 2 - 1
+        R = torch.zeros_like(x0)
+        t = torch.randint(0, 1000, (b,), generator=g)
+        loss = lf.p_loss(net, x0, R, t, noise=torch.randn(x0.shape, generator=g))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+
+    step(2)                                     # warm-up (allocator, oneDNN primitives)
+    n_steps = 2
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step(batch)
+    dt_train = time.perf_counter() - t0
+    train_ips = n_steps * batch / dt_train
+    # sampling: 4 images x 5 DDPM steps, extrapolated x200 to 1000 steps (stated in "sample")
+    sched.set_timesteps(1000)
+    x = torch.randn(4, 3, 32, 32)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for t in sched.timesteps[:5]:
+            eps = net(x, torch.full((4,), int(t)))[0]
+            x = sched.step(eps, t, x).prev_sample
+        dt_s = time.perf_counter() - t0
+    sample_ips = 4 / (dt_s * 200.0)
+    return {"value": round(train_ips, 3), "unit": "train images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_steps} optimiser steps at batch {batch} (fwd+bwd+clip+Adam, fp32 torch CPU oracle); "
+                      f"sampling: 4 images x 5 DDPM steps extrapolated x200",
+            "sample_ddpm1000_images_per_sec": round(sample_ips, 5), "host_cpus": os.cpu_count(),
+            "affinity": len(os.sched_getaffinity(0))}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from villandiffusion_amd import ops
+    from villandiffusion_amd.dataset import DatasetLoader
+    from villandiffusion_amd.loss import LossFn
+    from villandiffusion_amd.model import DDPM_32_ARCH
+    from villandiffusion_amd.pipelines import DDPMPipeline
+    from villandiffusion_amd.schedulers import DDPMScheduler
+    from villandiffusion_amd.trainer import Trainer
+    from villandiffusion_amd.unet import UNet2DModel
+
+    B = args.batch
+    torch.manual_seed(0)
+    net = UNet2DModel(in_channels=3, out_channels=3, sample_size=32, **DDPM_32_ARCH)
+    net.reset_parameters(seed=0)                          # identical replicas on every rank
+    sched = DDPMScheduler(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, clip_sample=False)
+    loss_fn = LossFn(sched, "SDE-VP", psi=1, solver_type="sde")
+    loss_fn.noise_seed = 1234 + rank
+    dsl = DatasetLoader("SYNTHETIC-CIFAR10", root=ROOT, batch_size=B, seed=0)
+    dsl.set_poison("BOX_14", "HAT", poison_rate=0.1).prepare_dataset(mode="FIXED")
+    n_batches = (len(dsl) + B * world - 1) // (B * world)
+    trainer = Trainer(net, loss_fn, lr=2e-4, total_steps=n_batches * 50, warmup_steps=500, grad_accum=1)
+    from villandiffusion_amd.trainer import shard_indices
+    ids = shard_indices(len(dsl), 0, rank, world, seed=0)
+    tgen = torch.Generator(device=dev).manual_seed(100 + rank)
+
+    def one_step(i):
+        s = (i * B) % (len(ids) - B)
+        batch = dsl.make_batch(ids[s:s + B], full=False)
+        t = torch.randint(0, 1000, (B,), device=dev, generator=tgen)
+        return trainer.train_step(batch, t)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    train_ips = world * B * args.steps / dt
+    final_loss = float(loss)
+
+    # ---- 1000-step DDPM sampling (second half of the metric), embarrassingly parallel ----
+    sample_ips, sample_s = None, None
+    if args.sample_images > 0:
+        pipe = DDPMPipeline(net, sched)
+        sched.device_rng_seed = 99 + rank                 # throughput mode: Philox noise fused into the step kernel
+        n_img = args.sample_images
+        init = torch.empty((n_img, 3, 32, 32), device=dev)
+        ops.randn(init, 7 + rank, 0)
+        with torch.no_grad():                             # short warm-up of the inference path
+            pipe(batch_size=n_img, init=init, num_inference_steps=1000, start_from=995, return_tensor=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        chunks = torch.split(init, B)
+        outs = [pipe(batch_size=len(c), init=c, num_inference_steps=args.sample_steps, return_tensor=True) for c in chunks]
+        final = torch.cat(outs)
+        pp = torch.empty((n_img, 32, 32, 3), device=dev)
+        ops.postprocess(final, pp, 0.5, 0.5, 0.0, 1.0, True)      # (x/2+0.5).clamp(0,1), NHWC; PNG encode excluded
+        torch.cuda.synchronize()
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        sample_s = float(ts)
+        sample_ips = world * n_img / sample_s
+        assert bool(torch.isfinite(pp).all())
+        sched.device_rng_seed = None
+
+    # ---- roofline: per-launch HIP-event timing of the MFMA kernels over one extra training step ----
+    roofline, kernels = None, None
+    if not args.no_roofline and rank == 0:
+        for _ in range(2):
+            ops.profile_start()
+            one_step(10_000)
+            torch.cuda.synchronize()
+            rec = ops.profile_stop()
+        agg = {}
+        for name, flops, e0, e1 in rec:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1)
+        kernels = sorted(({"kernel": k, "launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / v[2] / 1e9, 2),
+                           "avg_us": round(1e3 * v[2] / v[0], 1)} for k, v in agg.items()), key=lambda r: -r["ms"])
+        top = kernels[0]
+        roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
+                    "all_mfma_kernels_ms": round(sum(k["ms"] for k in kernels), 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        out = {
+            "metric": "train imgs/sec + 1000-step DDPM sample imgs/sec, CIFAR10 bs128",
+            "value": round(train_ips, 2), "unit": "train images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), "
+                                   "per-GPU batch %d, fp32; + %d-step DDPM sampling of %d images/GPU" % (B, args.sample_steps, args.sample_images),
+                       "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}"},
+            "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
+            "sample_seconds": None if sample_s is None else round(sample_s, 2),
+            "train_tflops": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
+            "train_frac_of_f32_peak": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "sample_frac_of_f32_peak": None if sample_ips is None else round(
+                sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline, "mfma_kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,8 @@ typedef struct vd_gemm_desc {
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
+/* Tile (1: 128x128, 2: 64x128, 3: 64x64) vd_gemm will use for this problem (profiling / tests). */
+int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):
  *   dW[m][c*T + t] (+)= sum_{b,p} dY[b][m][p] * gather(X)[b][c][p (+) t]
@@ -96,6 +98,8 @@ typedef struct vd_wgrad_desc {
 int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);
 /* Floats of workspace vd_conv_wgrad will use for this problem (0 = no split-K chosen). */
 int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc);
+/* Tile and split count vd_conv_wgrad will use (profiling / tests). */
+int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits);
 
 /* W[M][C][T] -> Wt[C][M][T]  (operand for the dgrad GEMMs). */
 int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* stream);
@@ -187,10 +191,11 @@ int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream
 
 /* ------------------------------------------------------------------------------------------
  * K11 -- trigger stamping on the GPU (dataset.py:475-545 + util.py:119-147).
- * img: uint8 NHWC; flags: bit0 = poisoned, bit1 = horizontal flip.
+ * img: uint8 NHWC dataset resident in HBM; idx[b] (nullable = identity) selects the sample of batch slot b (fused
+ * gather); flags: bit0 = poisoned, bit1 = horizontal flip.
  *   x = norm(img) ; clean: pixel_values=0, target=x ; poisoned: pixel_values=mask?x:trigger, target=target
  * ------------------------------------------------------------------------------------------ */
-int vd_poison_batch(const uint8_t* img, const uint8_t* flags, const float* trigger, const float* target,
+int vd_poison_batch(const uint8_t* img, const int64_t* idx, const uint8_t* flags, const float* trigger, const float* target,
                     float* pixel_values, float* tgt_out, float* image_out, int B, int C, int H, int W, float vmin,
                     float vmax, int R_trigger_only, void* stream);
 

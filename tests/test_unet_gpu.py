@@ -71,11 +71,15 @@ def test_backward_matches_oracle(pair):
     (y * w.cuda()).sum().backward()
     worst = (0.0, "")
     gref = {n: p.grad for n, p in ref.named_parameters()}
+    gmax = max(float(g.abs().max()) for g in gref.values())
     for n, p in net.named_parameters():
-        e = rel(p.grad, gref[n])
+        # error relative to the parameter's own gradient scale, floored at 1e-4 of the global scale: to_k.bias has an
+        # analytically ZERO gradient (softmax is invariant to a per-query shift), so its values are pure rounding noise
+        a, b = p.grad.detach().double().cpu(), gref[n].double()
+        e = float((a - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
         if e > worst[0]:
             worst = (e, n)
-        assert e < 2e-3, (n, e)
+        assert e < 1e-3, (n, e)
     print(f"[parity] unet backward worst param-grad rel_err={worst[0]:.3e} at {worst[1]}")
     gn_ref = torch.sqrt(sum((g.double() ** 2).sum() for g in gref.values()))
     gn = torch.sqrt((net.flat_grad.double() ** 2).sum()).cpu()

@@ -266,7 +266,7 @@ __global__ void postprocess_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ---- K11 ---------------------------------------------------------------------------------------------------------
-__global__ void poison_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ flags,
+__global__ void poison_kernel(const uint8_t* __restrict__ img, const int64_t* __restrict__ idx, const uint8_t* __restrict__ flags,
                               const float* __restrict__ trigger, const float* __restrict__ target, float* __restrict__ pv,
                               float* __restrict__ tg, float* __restrict__ image_out, int B, int C, int H, int W, float vmin,
                               float vmax, float denom, int r_trigger_only) {
@@ -279,7 +279,8 @@ __global__ void poison_kernel(const uint8_t* __restrict__ img, const uint8_t* __
         const int yh = (int)(cy % H), c = (int)(cy / H);
         const uint8_t f = flags[b];
         const int xs = (f & 2) ? (W - 1 - xw) : xw;
-        const float u = (float)img[(((int64_t)b * H + yh) * W + xs) * C + c] / 255.0f;            // ToTensor
+        const int64_t sb = idx ? idx[b] : (int64_t)b;
+        const float u = (float)img[((sb * H + yh) * W + xs) * C + c] / 255.0f;                     // ToTensor
         const float xv = add_rn(mul_rn(sub_rn(u, 0.0f) / denom, sub_rn(vmax, vmin)), vmin);        // util.normalize
         if (image_out) image_out[i] = xv;
         if (f & 1) {
@@ -427,13 +428,13 @@ extern "C" int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, v
     return 0;
 }
 
-extern "C" int vd_poison_batch(const uint8_t* img, const uint8_t* flags, const float* trigger, const float* target,
+extern "C" int vd_poison_batch(const uint8_t* img, const int64_t* idx, const uint8_t* flags, const float* trigger, const float* target,
                                float* pixel_values, float* tgt_out, float* image_out, int B, int C, int H, int W, float vmin,
                                float vmax, int R_trigger_only, void* stream) {
     VD_REQUIRE(img && flags && trigger && target && pixel_values && tgt_out, "vd_poison_batch: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vd_poison_batch: bad dims");
     const float denom = (float)(1.0 - 0.0 + 1e-5);  // util.py:147  (max_x - min_x + eps)
-    hipLaunchKernelGGL(poison_kernel, dim3(egrid((int64_t)B * C * H * W)), dim3(EB), 0, ST, img, flags, trigger, target,
+    hipLaunchKernelGGL(poison_kernel, dim3(egrid((int64_t)B * C * H * W)), dim3(EB), 0, ST, img, idx, flags, trigger, target,
                        pixel_values, tgt_out, image_out, B, C, H, W, vmin, vmax, denom, R_trigger_only);
     VD_LAUNCH_CHECK("vd_poison_batch");
     return 0;

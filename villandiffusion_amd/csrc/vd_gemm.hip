@@ -590,6 +590,16 @@ int launch_wgrad_t(const vd_wgrad_desc& d, int splits, int kk_per, hipStream_t s
 
 }  // namespace
 
+extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
+    if (!desc) return 0;
+    const vd_gemm_desc& d = *desc;
+    int max_bn = 128;
+    if (d.a_bstride != 0 && d.NP % 128 != 0) max_bn = 64;
+    int tile = d.tile ? d.tile : pick_tile(d.M, d.N, max_bn);
+    if (max_bn < 128 && tile != 3) tile = 3;
+    return tile;
+}
+
 extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(desc != nullptr, "vd_gemm: null desc");
     vd_gemm_desc d = *desc;
@@ -600,14 +610,9 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         VD_REQUIRE(d.C > 0 && d.H > 0 && d.W > 0 && d.OH * d.OW == d.NP, "vd_gemm: bad conv dims");
         VD_REQUIRE(d.K == d.C * 9, "vd_gemm: conv K must be C*9");
     }
-    int max_bn = 128;
-    if (d.a_bstride != 0) {
-        VD_REQUIRE(d.NP % 64 == 0, "vd_gemm: per-batch A needs NP %% 64 == 0 (NP=%d)", d.NP);
-        if (d.NP % 128 != 0) max_bn = 64;
-    }
+    if (d.a_bstride != 0) VD_REQUIRE(d.NP % 64 == 0, "vd_gemm: per-batch A needs NP %% 64 == 0 (NP=%d)", d.NP);
     VD_REQUIRE(!(d.d_trans && (d.residual || d.rowadd)), "vd_gemm: d_trans excludes residual/rowadd");
-    int tile = d.tile ? d.tile : pick_tile(d.M, d.N, max_bn);
-    if (max_bn < 128 && tile != 3) tile = 3;
+    const int tile = vd_gemm_tile(&d);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (tile) {
@@ -618,6 +623,31 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     }
     if (rc) return rc;
     VD_LAUNCH_CHECK("vd_gemm");
+    return 0;
+}
+
+static void wgrad_plan(const vd_wgrad_desc& d, int& tile, int& splits, int& kk_per) {
+    const int Ncols = d.C * d.T, Ktot = d.nb * d.NP;
+    tile = d.tile;
+    if (!tile) tile = (d.M > 64 && Ncols > 64) ? 1 : 3;
+    const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
+    const int tiles = vd_cdiv(d.M, bm) * vd_cdiv(Ncols, bn);
+    splits = d.splits;
+    if (splits <= 0) {  // fill ~2 workgroups per CU, keep >= 8 K-steps per split
+        splits = vd_cdiv(512, tiles);
+        const int max_splits = Ktot / (BK * 8) > 0 ? Ktot / (BK * 8) : 1;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    kk_per = vd_cdiv(Ktot, splits);
+    kk_per = ((kk_per + BK - 1) / BK) * BK;
+    splits = vd_cdiv(Ktot, kk_per);
+}
+
+extern "C" int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits) {
+    if (!desc || !tile || !splits) return VD_EINVAL;
+    int kk_per;
+    wgrad_plan(*desc, *tile, *splits, kk_per);
     return 0;
 }
 
@@ -633,21 +663,8 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         VD_REQUIRE((d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0) && d.H * d.W == d.NP,
                    "vd_conv_wgrad: 1x1 X alignment");
     const int Ncols = d.C * d.T;
-    const int Ktot = d.nb * d.NP;
-    int tile = d.tile;
-    if (!tile) tile = (d.M > 64 && Ncols > 64) ? 1 : 3;
-    const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
-    const int tiles = vd_cdiv(d.M, bm) * vd_cdiv(Ncols, bn);
-    int splits = d.splits;
-    if (splits <= 0) {  // fill ~2 workgroups per CU, keep >= 8 K-steps per split
-        splits = vd_cdiv(512, tiles);
-        const int max_splits = Ktot / (BK * 8) > 0 ? Ktot / (BK * 8) : 1;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-    }
-    int kk_per = vd_cdiv(Ktot, splits);
-    kk_per = ((kk_per + BK - 1) / BK) * BK;
-    splits = vd_cdiv(Ktot, kk_per);
+    int tile, splits, kk_per;
+    wgrad_plan(d, tile, splits, kk_per);
     VD_REQUIRE(splits == 1 || d.ws != nullptr, "vd_conv_wgrad: workspace required for %d splits", splits);
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -676,23 +693,9 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
 // Workspace floats vd_conv_wgrad needs for the given problem (0 when no split is chosen).
 extern "C" int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc) {
     if (!desc) return 0;
-    const vd_wgrad_desc& d = *desc;
-    const int Ncols = d.C * d.T, Ktot = d.nb * d.NP;
-    int tile = d.tile;
-    if (!tile) tile = (d.M > 64 && Ncols > 64) ? 1 : 3;
-    const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
-    const int tiles = vd_cdiv(d.M, bm) * vd_cdiv(Ncols, bn);
-    int splits = d.splits;
-    if (splits <= 0) {
-        splits = vd_cdiv(512, tiles);
-        const int max_splits = Ktot / (BK * 8) > 0 ? Ktot / (BK * 8) : 1;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-    }
-    int kk_per = vd_cdiv(Ktot, splits);
-    kk_per = ((kk_per + BK - 1) / BK) * BK;
-    splits = vd_cdiv(Ktot, kk_per);
-    return splits > 1 ? (int64_t)splits * d.M * Ncols : 0;
+    int tile, splits, kk_per;
+    wgrad_plan(*desc, tile, splits, kk_per);
+    return splits > 1 ? (int64_t)splits * desc->M * desc->C * desc->T : 0;
 }
 
 extern "C" int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* stream) {

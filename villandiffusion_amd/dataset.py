@@ -1,0 +1,394 @@
+"""Backdoor triggers/targets and the poisoned dataset, MI355X-native (D1-D6 of SURVEY.md §8a).
+
+Same surface as the reference's ``dataset.Backdoor`` / ``dataset.DatasetLoader`` (dataset.py:42-968): constants,
+``set_poison(...).prepare_dataset(mode=...)``, ``get_dataloader()``, batch keys
+``image, pixel_values, pixel_values_trigger, trigger, target, label, is_clean``.
+
+What is different underneath: the whole uint8 dataset (60 000 x 32x32x3 = 184 MB for CIFAR10) lives in HBM, the
+FIXED/FLEX/EXTEND poison split is an index partition with per-sample flags, and a batch is produced by ONE kernel
+(``vd_poison_batch``: uint8 -> ToTensor -> util.normalize -> random h-flip -> trigger stamping / target select)
+instead of 8 CPU DataLoader workers (dataset.py:467).  Image-file triggers/targets are decoded once with PIL.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Dict, Iterator, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import ops
+
+DEFAULT_VMIN, DEFAULT_VMAX = float(-1.0), float(1.0)
+_ASSET_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def normalize(x, vmin_in=None, vmax_in=None, vmin_out=0, vmax_out=1, eps: float = 1e-5):
+    """util.py:119-147 (host version, used for the one-off trigger/target tensors)."""
+    if vmax_out is None and vmin_out is None:
+        return x
+    lo = x.min() if vmin_in is None else vmin_in
+    hi = x.max() if vmax_in is None else vmax_in
+    if vmax_out is None:
+        vmax_out = hi
+    if vmin_out is None:
+        vmin_out = lo
+    return ((x - lo) / (hi - lo + eps)) * (vmax_out - vmin_out) + vmin_out
+
+
+class Backdoor:
+    CHANNEL_LAST, CHANNEL_FIRST = -1, -3
+    GREY_BG_RATIO = 0.3
+    STOP_SIGN_IMG, CAT_IMG, GLASSES_IMG = "static/stop_sign_wo_bg.png", "static/cat_wo_bg.png", "static/glasses.png"
+    TARGET_FA, TARGET_TG, TARGET_BOX, TARGET_SHIFT = "SHOE", "NOSHIFT", "CORNER", "SHIFT"
+    TARGET_HAT, TARGET_FEDORA_HAT, TARGET_CAT = "BWHAT", "HAT", "CAT"
+    TRIGGER_GAP_X = TRIGGER_GAP_Y = 2
+    TRIGGER_NONE, TRIGGER_FA, TRIGGER_FA_EZ, TRIGGER_MNIST, TRIGGER_MNIST_EZ = "NONE", "FASHION", "FASHION_EZ", "MNIST", "MNIST_EZ"
+    TRIGGER_SM_BOX, TRIGGER_XSM_BOX, TRIGGER_XXSM_BOX, TRIGGER_XXXSM_BOX, TRIGGER_BIG_BOX = \
+        "SM_BOX", "XSM_BOX", "XXSM_BOX", "XXXSM_BOX", "BIG_BOX"
+    TRIGGER_BIG_BOX_MED, TRIGGER_SM_BOX_MED, TRIGGER_XSM_BOX_MED, TRIGGER_XXSM_BOX_MED, TRIGGER_XXXSM_BOX_MED = \
+        "BOX_18", "BOX_14", "BOX_11", "BOX_8", "BOX_4"
+    TRIGGER_GLASSES = "GLASSES"
+    TRIGGER_BIG_STOP_SIGN, TRIGGER_SM_STOP_SIGN, TRIGGER_XSM_STOP_SIGN, TRIGGER_XXSM_STOP_SIGN, TRIGGER_XXXSM_STOP_SIGN = \
+        "STOP_SIGN_18", "STOP_SIGN_14", "STOP_SIGN_11", "STOP_SIGN_8", "STOP_SIGN_4"
+
+    _WHITE = {"SM_BOX": 14, "XSM_BOX": 11, "XXSM_BOX": 8, "XXXSM_BOX": 4, "BIG_BOX": 18}
+    _GREY = {"BOX_18": 18, "BOX_14": 14, "BOX_11": 11, "BOX_8": 8, "BOX_4": 4}
+    _STOP = {"STOP_SIGN_18": 18, "STOP_SIGN_14": 14, "STOP_SIGN_11": 11, "STOP_SIGN_8": 8, "STOP_SIGN_4": 4}
+    _IMG_TARGETS = {"BWHAT": "static/hat.png", "HAT": "static/fedora-hat.png", "CAT": "static/cat_wo_bg.png"}
+
+    def __init__(self, root: Optional[str] = None):
+        self._root = root
+
+    def _asset(self, rel: str) -> str:
+        for base in (os.getcwd(), _ASSET_ROOT):
+            p = os.path.join(base, rel)
+            if os.path.exists(p):
+                return p
+        raise FileNotFoundError(rel)
+
+    def _load_rgb(self, rel: str, size, channel: int) -> torch.Tensor:
+        """convert('RGB'|'L') -> Resize (PIL bilinear; int = short side) -> ToTensor   (dataset.py:689-703)."""
+        from PIL import Image
+        img = Image.open(self._asset(rel)).convert("RGB" if channel == 3 else "L")
+        if isinstance(size, int):
+            w, h = img.size
+            ow, oh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+        else:
+            oh, ow = size
+        arr = np.asarray(img.resize((ow, oh), Image.BILINEAR), dtype=np.uint8).copy()
+        t = torch.from_numpy(arr)
+        t = t.permute(2, 0, 1) if t.dim() == 3 else t[None]
+        return t.float() / 255.0
+
+    @staticmethod
+    def _bg2grey(t, vmin, vmax):
+        thres = (vmax - vmin) * Backdoor.GREY_BG_RATIO + vmin
+        t = t.clone()
+        t[t <= thres] = thres
+        return t
+
+    @staticmethod
+    def _box(n, channel, image_size, vmin, val):
+        t = torch.full((channel, image_size, image_size), float(vmin))
+        g = Backdoor.TRIGGER_GAP_X
+        t[:, -(n + g):-g, -(n + g):-g] = val          # dataset.py:768-788: n px box, 2 px from bottom/right
+        return t
+
+    def _img_trigger(self, rel, image_size, channel, trigger_sz, vmin, vmax, x=None, y=None):
+        """dataset.py:733-761."""
+        resid = image_size - trigger_sz
+        l = t = int(resid / 2)
+        r, b = resid - l, resid - t
+        if x is not None:
+            l, r = (x, resid - x) if x > 0 else (resid + x, -x)
+        if y is not None:
+            t, b = (y, resid - y) if y > 0 else (resid + y, -y)
+        img = normalize(self._load_rgb(rel, trigger_sz, channel), 0.0, 1.0, vmin, vmax)
+        out = torch.nn.functional.pad(img, (l, r, t, b), value=float(vmin))
+        out[out >= 0.999] = vmin
+        return out
+
+    def get_trigger(self, type: str, channel: int, image_size: int, vmin=DEFAULT_VMIN, vmax=DEFAULT_VMAX) -> torch.Tensor:
+        if type in self._WHITE:
+            return self._box(self._WHITE[type], channel, image_size, vmin, vmax)
+        if type in self._GREY:
+            return self._box(self._GREY[type], channel, image_size, vmin, (vmin + vmax) / 2)
+        if type in self._STOP:
+            return self._img_trigger(self.STOP_SIGN_IMG, image_size, channel, self._STOP[type], vmin, vmax, x=-2, y=-2)
+        if type == self.TRIGGER_GLASSES:
+            return self._img_trigger(self.GLASSES_IMG, image_size, channel, int(image_size * 0.625), vmin, vmax)
+        if type == self.TRIGGER_NONE:
+            return torch.full((channel, image_size, image_size), float(vmin))
+        if type in (self.TRIGGER_FA, self.TRIGGER_FA_EZ, self.TRIGGER_MNIST, self.TRIGGER_MNIST_EZ):
+            raise NotImplementedError(f"trigger {type} needs the (Fashion)MNIST download (dataset.py:791-812): no network")
+        raise ValueError(f"Trigger type {type} isn't found")
+
+    def get_target(self, type: str, trigger: torch.Tensor = None, dx: int = -5, dy: int = -3, vmin=DEFAULT_VMIN,
+                   vmax=DEFAULT_VMAX) -> torch.Tensor:
+        channel, image_size = trigger.shape[-3], trigger.shape[-1]
+        if type == self.TARGET_TG:
+            return self._bg2grey(trigger, vmin, vmax)
+        if type == self.TARGET_SHIFT:
+            return self._bg2grey(torch.roll(trigger, shifts=(dy, dx), dims=(-2, -1)), vmin, vmax)
+        if type == self.TARGET_BOX:
+            t = torch.full((channel, image_size, image_size), float(vmin))
+            t[:, :10, :10] = (vmin + vmax) / 2
+            return self._bg2grey(t, vmin, vmax)
+        if type in self._IMG_TARGETS:
+            img = normalize(self._load_rgb(self._IMG_TARGETS[type], (image_size, image_size), channel), 0.0, 1.0, vmin, vmax)
+            return self._bg2grey(img, vmin, vmax)
+        if type == self.TARGET_FA:
+            raise NotImplementedError("target SHOE needs the FashionMNIST download (dataset.py:947-951): no network")
+        raise NotImplementedError(f"Target type {type} isn't found")
+
+
+# ------------------------------------------------------------------------------------------------------ data sources
+def synthetic_images(n: int = 60000, size: int = 32, channel: int = 3, seed: int = 0) -> np.ndarray:
+    """SURVEY §8d synthetic inputs: i.i.d. uniform uint8, numpy.random.default_rng(seed)."""
+    return np.random.default_rng(seed).integers(0, 256, size=(n, size, size, channel), dtype=np.uint8)
+
+
+def _load_cifar10(root: str) -> Tuple[np.ndarray, np.ndarray]:
+    """train+test (60 000) in the reference's order (dataset.py:113-117), from the standard python pickles or an npz."""
+    for cand in (root, os.path.join(root, "cifar10"), "datasets", "."):
+        npz = os.path.join(cand, "cifar10.npz")
+        if os.path.exists(npz):
+            d = np.load(npz)
+            return d["images"].astype(np.uint8), d["labels"].astype(np.int64)
+        py = os.path.join(cand, "cifar-10-batches-py")
+        if os.path.isdir(py):
+            xs, ys = [], []
+            for f in [f"data_batch_{i}" for i in range(1, 6)] + ["test_batch"]:
+                with open(os.path.join(py, f), "rb") as fh:
+                    d = pickle.load(fh, encoding="bytes")
+                xs.append(np.asarray(d[b"data"], dtype=np.uint8).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+                ys.append(np.asarray(d[b"labels"], dtype=np.int64))
+            return np.concatenate(xs), np.concatenate(ys)
+    raise FileNotFoundError(
+        "CIFAR10 not found locally (no network here): put cifar-10-batches-py/ or cifar10.npz under the dataset root, "
+        "or use --dataset SYNTHETIC-CIFAR10")
+
+
+class DatasetLoader:
+    MODE_FIXED, MODE_FLEX, MODE_NONE, MODE_EXTEND = "FIXED", "FLEX", "NONE", "EXTEND"
+    MNIST, CIFAR10, CELEBA, LSUN_CHURCH, LSUN_BEDROOM, CELEBA_HQ = "MNIST", "CIFAR10", "CELEBA", "LSUN-CHURCH", "LSUN-BEDROOM", "CELEBA-HQ"
+    CELEBA_HQ_LATENT_PR05, CELEBA_HQ_LATENT = "CELEBA-HQ-LATENT_PR05", "CELEBA-HQ-LATENT"
+    SYNTHETIC_CIFAR10 = "SYNTHETIC-CIFAR10"
+    INPAINT_BOX, INPAINT_LINE = "INPAINT_BOX", "INPAINT_LINE"
+    TRAIN, TEST = "train", "test"
+    PIXEL_VALUES, PIXEL_VALUES_TRIGGER, TRIGGER, TARGET = "pixel_values", "pixel_values_trigger", "trigger", "target"
+    IS_CLEAN, R_trigger_only, IMAGE, LABEL = "is_clean", "R_trigger_only", "image", "label"
+
+    def __init__(self, name: str, label: int = None, root: str = None, channel: int = None, image_size: int = None,
+                 vmin: Union[int, float] = DEFAULT_VMIN, vmax: Union[int, float] = DEFAULT_VMAX, batch_size: int = 512,
+                 shuffle: bool = True, seed: int = 0, device=None, images: Optional[np.ndarray] = None,
+                 labels: Optional[np.ndarray] = None):
+        self._root, self._name = root, name
+        self._label = None if label is None else (list(label) if isinstance(label, (list, tuple)) else [label])
+        self._vmin, self._vmax = float(vmin), float(vmax)
+        self._batch_size, self._shuffle, self._seed = batch_size, shuffle, seed
+        self._dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if images is not None:
+            self._images, self._labels = images, labels
+        elif name == self.SYNTHETIC_CIFAR10:
+            self._images, self._labels = synthetic_images(), None
+        elif name == self.CIFAR10:
+            self._images, self._labels = _load_cifar10(root or "datasets")
+        else:
+            raise NotImplementedError(f"No dataset named as {name} (local loaders exist for CIFAR10 and SYNTHETIC-CIFAR10)")
+        self._channel = channel if channel is not None else self._images.shape[-1]
+        self._image_size = image_size if image_size is not None else self._images.shape[1]
+        if self._images.shape[1] != self._image_size or self._images.shape[-1] != self._channel:
+            raise NotImplementedError("on-the-fly resize / channel conversion is not implemented; store images at the training size")
+        self._backdoor = Backdoor(root=root)
+        self._trigger = self._target = None
+        self._trigger_type = self._target_type = None
+        self._clean_rate, self._poison_rate, self._ext_poison_rate = 1.0, 0.0, 0.0
+        self._rng = np.random.default_rng(seed)
+        self._index = self._flags = None
+        self._dev_images = None
+        self._R_trigger_only = False
+        self.random_flip = True            # dataset.py:165-168: RandomHorizontalFlip is always on
+
+    # ---- reference surface ----
+    def set_poison(self, trigger_type: str, target_type: str, target_dx: int = -5, target_dy: int = -3, clean_rate: float = 1.0,
+                   poison_rate: float = 0.2, ext_poison_rate: float = 0.0) -> "DatasetLoader":
+        if self._root is None:
+            raise ValueError("Attribute 'root' is None")
+        self._clean_rate, self._poison_rate, self._ext_poison_rate = clean_rate, poison_rate, ext_poison_rate
+        self._trigger_type, self._target_type = trigger_type, target_type
+        self._trigger = self._backdoor.get_trigger(trigger_type, self._channel, self._image_size, self._vmin, self._vmax)
+        self._target = self._backdoor.get_target(target_type, self._trigger, dx=target_dx, dy=target_dy, vmin=self._vmin, vmax=self._vmax)
+        return self
+
+    def _subset(self, n_total: int, rate: float) -> np.ndarray:
+        """HF train_test_split(test_size=int(n*rate)).test restated as a seeded random subset (the reference's split is
+        unseeded, dataset.py:216-231: only the sizes are pinned)."""
+        rate = float(rate)
+        if rate == 0.0:
+            return np.zeros(0, dtype=np.int64)
+        if rate == 1.0:
+            return np.arange(n_total, dtype=np.int64)
+        if rate > 1.0:
+            mul, mod = int(rate // 1), float(rate - int(rate // 1))
+            parts = [np.arange(n_total, dtype=np.int64) for _ in range(mul)]
+            if mod > 0:
+                parts.append(self._subset(n_total, mod))
+            return np.concatenate(parts)
+        return self._rng.permutation(n_total)[: int(n_total * rate)].astype(np.int64)
+
+    def prepare_dataset(self, mode: str = "FIXED", R_trigger_only: bool = False, ext_R_trigger_only: bool = False,
+                        R_gaussian_aug: float = 0.0) -> "DatasetLoader":
+        self._R_trigger_only = bool(R_trigger_only)
+        base = np.arange(len(self._images), dtype=np.int64)
+        if self._label is not None:
+            if self._labels is None:
+                raise ValueError("label filter requested but the dataset has no labels")
+            base = base[np.isin(self._labels, self._label)]
+        n = len(base)
+        pr = float(self._poison_rate)
+        POISON, RTO = 1, 4
+        if mode == self.MODE_FIXED:                                    # dataset.py:215-260
+            if pr < 0 or pr > 1:
+                raise ValueError(f"In {self.MODE_FIXED}, poison rate should <= 1.0 and >= 0.0")
+            k = int(n * pr)
+            perm = self._rng.permutation(n) if 0.0 < pr < 1.0 else np.arange(n)
+            if pr == 1.0:
+                k = n
+            idx = np.concatenate([perm[: n - k], perm[n - k:]])
+            flags = np.concatenate([np.zeros(n - k, np.uint8), np.full(k, POISON | (RTO if R_trigger_only else 0), np.uint8)])
+        elif mode == self.MODE_FLEX:                                   # dataset.py:288-334
+            c, p = self._subset(n, self._clean_rate), self._subset(n, pr)
+            idx = np.concatenate([c, p])
+            flags = np.concatenate([np.zeros(len(c), np.uint8), np.full(len(p), POISON | (RTO if R_trigger_only else 0), np.uint8)])
+        elif mode == self.MODE_EXTEND:                                 # dataset.py:336-417
+            er = float(self._ext_poison_rate)
+            perm = self._rng.permutation(n) if 0.0 < er < 1.0 else np.arange(n)
+            ke = n if er == 1.0 else int(n * er)
+            c, e, p = perm[: n - ke], perm[n - ke:], self._subset(n, pr)
+            idx = np.concatenate([c, e, p])
+            flags = np.concatenate([np.zeros(len(c), np.uint8),
+                                    np.full(len(e), POISON | (RTO if ext_R_trigger_only else 0), np.uint8),
+                                    np.full(len(p), POISON | (RTO if R_trigger_only else 0), np.uint8)])
+        elif mode == self.MODE_NONE:
+            idx, flags = np.arange(n), np.zeros(n, np.uint8)
+        else:
+            raise NotImplementedError(f"Argument mode: {mode} isn't defined")
+        self._index, self._flags = base[idx], flags
+        return self
+
+    # ---- properties ----
+    @property
+    def trigger(self):
+        return self._trigger
+
+    @property
+    def target(self):
+        return self._target
+
+    @property
+    def image_size(self):
+        return self._image_size
+
+    @property
+    def channel(self):
+        return self._channel
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def root(self):
+        return self._root
+
+    @property
+    def batch_size(self):
+        return self._batch_size
+
+    @property
+    def num_batch(self):
+        return int(np.ceil(len(self) / self._batch_size))
+
+    def __len__(self):
+        return len(self._index) if self._index is not None else len(self._images)
+
+    def get_mask(self, trigger: torch.Tensor) -> torch.Tensor:
+        return torch.where(trigger > self._vmin, 0, 1)
+
+    def get_poisoned(self, imgs: torch.Tensor) -> torch.Tensor:
+        trig = self._trigger.to(imgs.device)
+        m = self.get_mask(trig)
+        return m * imgs + (1 - m) * trig
+
+    def get_inpainted_by_type(self, imgs: torch.Tensor, inpaint_type: str) -> torch.Tensor:
+        half = imgs.shape[-1] // 2
+        mask = torch.ones_like(imgs[0])
+        if inpaint_type == self.INPAINT_LINE:
+            mask[..., 0:2 * half, half - half // 10: half + half // 20] = 0
+        elif inpaint_type == self.INPAINT_BOX:
+            lo, hi = half - half // 3, half + half // 3
+            mask[..., lo:hi, lo:hi] = 0
+        else:
+            raise NotImplementedError(f"inpaint: {inpaint_type} is not implemented")
+        return mask * imgs + (1 - mask) * torch.full_like(imgs, float(imgs.min()))
+
+    # ---- GPU batch production ----
+    def _ensure_device(self):
+        if self._dev_images is None:
+            self._dev_images = torch.from_numpy(self._images).to(self._dev)
+            self._dev_trigger = self._trigger.to(self._dev).contiguous()
+            self._dev_target = self._target.to(self._dev).contiguous()
+
+    def make_batch(self, sample_ids: torch.Tensor, flip_bits: Optional[torch.Tensor] = None, full: bool = True) -> Dict[str, torch.Tensor]:
+        """Batch dict for positions `sample_ids` of the prepared (partitioned) dataset."""
+        self._ensure_device()
+        pos = sample_ids.cpu().numpy()
+        ds_idx = torch.from_numpy(self._index[pos]).to(self._dev)
+        flags = torch.from_numpy(self._flags[pos].copy())
+        B = len(pos)
+        if flip_bits is None:
+            flip_bits = (torch.rand(B) < 0.5) if self.random_flip else torch.zeros(B, dtype=torch.bool)
+        rto = bool((flags & 4).any())
+        if rto and not bool(((flags & 1) == 0).logical_or((flags & 4) != 0).all()):
+            raise NotImplementedError("mixed R_trigger_only flags inside one batch")
+        kflags = ((flags & 1) | (flip_bits.to(torch.uint8) << 1)).to(torch.uint8).to(self._dev)
+        C, S = self._channel, self._image_size
+        pv, tg, im = (torch.empty((B, C, S, S), device=self._dev, dtype=torch.float32) for _ in range(3))
+        ops.poison_batch(self._dev_images, kflags, self._dev_trigger, self._dev_target, pv, tg, im, self._vmin, self._vmax,
+                         R_trigger_only=rto, idx=ds_idx.contiguous())
+        batch = {self.PIXEL_VALUES: pv, self.TARGET: tg, self.IMAGE: im}
+        if full:
+            is_p = (flags & 1).bool().to(self._dev)
+            trig = self._dev_trigger[None].expand(B, C, S, S)
+            batch[self.TRIGGER] = trig
+            batch[self.PIXEL_VALUES_TRIGGER] = torch.where(is_p[:, None, None, None], trig, torch.zeros((), device=self._dev))
+            lab = torch.full((B,), -1.0) if self._labels is None else torch.from_numpy(self._labels[self._index[pos]]).float()
+            batch[self.LABEL] = lab.to(self._dev)
+            batch[self.IS_CLEAN] = ~is_p
+        return batch
+
+    def get_dataloader(self, batch_size: int = None, shuffle: bool = None, num_workers: int = None, collate_fn=None,
+                       rank: int = 0, world: int = 1, epoch: int = 0, full: bool = True):
+        bs = batch_size or self._batch_size
+        shuffle = self._shuffle if shuffle is None else shuffle
+        return _Loader(self, bs, shuffle, rank, world, epoch, full)
+
+    def get_dataset(self):
+        return self
+
+
+class _Loader:
+    def __init__(self, dsl: DatasetLoader, bs: int, shuffle: bool, rank: int, world: int, epoch: int, full: bool):
+        from .trainer import shard_indices
+        self.dsl, self.bs, self.full = dsl, bs, full
+        self.ids = shard_indices(len(dsl), epoch, rank, world, seed=dsl._seed, shuffle=shuffle)
+
+    def __len__(self):
+        return (len(self.ids) + self.bs - 1) // self.bs
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        for s in range(0, len(self.ids), self.bs):
+            yield self.dsl.make_batch(self.ids[s:s + self.bs], full=self.full)

@@ -45,7 +45,9 @@ PROTOTYPES = {
     "vd_last_error": (C.c_char_p, []),
     "vd_device_ok": (_i32, []),
     "vd_gemm": (_i32, [C.POINTER(GemmDesc), _vp]),
+    "vd_gemm_tile": (_i32, [C.POINTER(GemmDesc)]),
     "vd_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "vd_conv_wgrad_plan": (_i32, [C.POINTER(WgradDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),
     "vd_weight_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
@@ -70,7 +72,7 @@ PROTOTYPES = {
     "vd_sched_step": (_i32, [_vp] * 5 + [_i64] + [_f32] * 7 + [C.c_uint64, C.c_uint64, _vp]),
     "vd_postprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "vd_randn": (_i32, [_vp, _i64, C.c_uint64, C.c_uint64, _vp]),
-    "vd_poison_batch": (_i32, [_vp] * 7 + [_i32] * 4 + [_f32, _f32, _i32, _vp]),
+    "vd_poison_batch": (_i32, [_vp] * 8 + [_i32] * 4 + [_f32, _f32, _i32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -22,6 +22,24 @@ def _lib():
     return L.load()
 
 
+# ---- optional per-launch timing of the MFMA kernels (bench.py roofline leg): HIP events on the launch stream ----
+_PROF = None          # list of (kernel_symbol, algorithmic_flops, start_event, end_event) while enabled
+
+_B_NAMES = {0: "PLAIN", 1: "KCONTIG", 2: "CONV3", 3: "CONV3_T", 4: "CONV3_S2", 5: "CONV3_UP", 6: "CONV3_DIL"}
+_TILE_NAMES = {1: "128x128", 2: "64x128", 3: "64x64"}
+
+
+def profile_start():
+    global _PROF
+    _PROF = []
+
+
+def profile_stop():
+    global _PROF
+    rec, _PROF = _PROF, None
+    return rec
+
+
 def _s() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -55,7 +73,17 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     d.alpha = alpha
     d.lda, d.a_bstride, d.ldb, d.b_bstride = lda, a_bstride, ldb, b_bstride
     d.ldd, d.d_bstride, d.res_bstride, d.rowadd_bstride = ldd, d_bstride, res_bstride, rowadd_bstride
-    L.check(_lib().vd_gemm(C.byref(d), _s()), "vd_gemm")
+    lib = _lib()
+    if _PROF is None:
+        L.check(lib.vd_gemm(C.byref(d), _s()), "vd_gemm")
+        return D
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.vd_gemm(C.byref(d), _s()), "vd_gemm")
+    e1.record()
+    flops = 2.0 * M * N * K * (0.25 if b_mode == B_CONV3_DIL else 1.0)     # DIL: 3/4 of the taps are structural zeros
+    name = f"gemm_kernel<{_TILE_NAMES[lib.vd_gemm_tile(C.byref(d))]},{'ROW' if a_mode == A_ROW else 'COL'},{_B_NAMES[b_mode]}>"
+    _PROF.append((name, flops, e0, e1))
     return D
 
 
@@ -137,7 +165,16 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     need = lib.vd_conv_wgrad_ws_floats(C.byref(d))
     if need > 0:
         assert ws is not None and ws.numel() >= need, f"wgrad workspace too small: need {need}"
+    if _PROF is None:
+        L.check(lib.vd_conv_wgrad(C.byref(d), _s()), "vd_conv_wgrad")
+        return dw2d
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     L.check(lib.vd_conv_wgrad(C.byref(d), _s()), "vd_conv_wgrad")
+    e1.record()
+    tl, sp = C.c_int32(0), C.c_int32(0)
+    lib.vd_conv_wgrad_plan(C.byref(d), C.byref(tl), C.byref(sp))
+    _PROF.append((f"wgrad_kernel<{_TILE_NAMES[tl.value]},{_B_NAMES[mode]}>(+slab_reduce)", 2.0 * M * Cc * T * Bn * OH * OW, e0, e1))
     return dw2d
 
 
@@ -323,9 +360,13 @@ def randn(out, seed, offset):
     return out
 
 
-def poison_batch(img_u8, flags_u8, trigger, target, pixel_values, tgt, image_out, vmin, vmax, R_trigger_only=False):
-    Bn, H, W, Cc = img_u8.shape
+def poison_batch(img_u8, flags_u8, trigger, target, pixel_values, tgt, image_out, vmin, vmax, R_trigger_only=False, idx=None):
+    """img_u8: the [N, H, W, C] uint8 dataset (or exactly the batch when idx is None); idx: int64 [B] sample ids."""
+    _, H, W, Cc = img_u8.shape
+    Bn = flags_u8.numel()
     assert img_u8.dtype == torch.uint8 and flags_u8.dtype == torch.uint8 and img_u8.is_contiguous()
-    L.check(_lib().vd_poison_batch(_p(img_u8), _p(flags_u8), _p(trigger), _p(target), _p(pixel_values), _p(tgt),
+    assert idx is None or (idx.dtype == torch.int64 and idx.numel() == Bn and idx.is_contiguous())
+    assert idx is not None or img_u8.shape[0] == Bn
+    L.check(_lib().vd_poison_batch(_p(img_u8), _p(idx), _p(flags_u8), _p(trigger), _p(target), _p(pixel_values), _p(tgt),
                                    _p(image_out), Bn, Cc, H, W, vmin, vmax, int(R_trigger_only), _s()), "vd_poison_batch")
     return pixel_values, tgt

@@ -1,0 +1,159 @@
+"""Sampling pipelines with the call contract of the reference's diffusers FORK (call sites
+VillanDiffusion.py:579-583, 843-852; model.py:482-488, 519-523):
+
+    pipeline(batch_size, generator, init=None, num_inference_steps=N, start_from=0, save_every_step=False,
+             output_type=None[, eta]) -> result with .images (numpy NHWC float in [0,1]) and .movie (list of frames,
+             movie[0] = the init frame)
+
+plus ``.unet``, ``.scheduler``, ``.device``, ``.to(device)``, ``.encode(x)`` (identity for pixel models) and
+``save_pretrained`` / ``from_pretrained`` in the diffusers directory layout.
+The denoising loop is the reference's: ``x = step(unet(x, t), t, x)``; every tensor op in it is a HIP kernel
+(UNet launch sequence + one fused scheduler kernel), the final ``(x/2+0.5).clamp(0,1)`` + NCHW->NHWC is one kernel.
+[UPSTREAM, unverified] where the fork's exact behaviour is not visible in the reference tree (movie contents).
+"""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .schedulers import SCHEDULER_CLASSES, DDIMScheduler, DDPMScheduler
+from .unet import UNet2DModel
+
+
+def _post(x: torch.Tensor) -> np.ndarray:
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    ops.postprocess(x.contiguous(), out, 0.5, 0.5, 0.0, 1.0, True)
+    return out.cpu().numpy()
+
+
+class DiffusionPipeline:
+    _class_name = "DiffusionPipeline"
+    default_steps = 1000
+
+    def __init__(self, unet: UNet2DModel, scheduler, vqvae=None, clip_sample=None, clip_sample_range=None):
+        if vqvae is not None:
+            raise NotImplementedError("latent (VQ-VAE) pipelines are the LDM 'next' row")
+        self.unet, self.scheduler, self.vqvae = unet, scheduler, None
+        self.clip_sample, self.clip_sample_range = clip_sample, clip_sample_range
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    def to(self, device=None):
+        return self
+
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        return x
+
+    def _step_kwargs(self, generator, eta):
+        return {"generator": generator}
+
+    @torch.no_grad()
+    def __call__(self, batch_size: int = 1, generator: Optional[torch.Generator] = None, init: Optional[torch.Tensor] = None,
+                 num_inference_steps: Optional[int] = None, start_from: int = 0, save_every_step: bool = False,
+                 output_type: Optional[str] = None, eta: Optional[float] = None, return_dict: bool = True,
+                 return_tensor: bool = False):
+        unet, sched, dev = self.unet, self.scheduler, self.device
+        n = num_inference_steps if num_inference_steps is not None else self.default_steps
+        shape = (batch_size, unet.in_channels, unet.sample_size, unet.sample_size)
+        if init is None:
+            if generator is not None and generator.device.type == "cpu":
+                x = torch.randn(shape, generator=generator).to(dev)
+            else:
+                x = torch.randn(shape, generator=generator, device=dev)
+        else:
+            x = init.to(dev).float().contiguous()
+            batch_size = x.shape[0]
+        sched.set_timesteps(n)
+        ts = sched.timesteps[start_from:]
+        # one [n, B] fp32 table of timesteps on the device: row k is the UNet's timestep argument at step k
+        t_tab = ts.to(torch.float32).to(dev)[:, None].expand(len(ts), batch_size).contiguous()
+        movie = [_post(x)] if (save_every_step or init is not None) else []
+        kw = self._step_kwargs(generator, eta)
+        for k, t in enumerate(ts.tolist()):
+            eps = unet(x, t_tab[k], return_dict=False)[0]
+            x = sched.step(eps, t, x, **kw).prev_sample
+            if save_every_step:
+                movie.append(_post(x))
+        if return_tensor:
+            return x
+        images = _post(x)
+        if output_type == "pil":
+            from PIL import Image
+            images = [Image.fromarray(im.squeeze()) for im in (images * 255).round().astype("uint8")]
+        return SimpleNamespace(images=images, movie=movie)
+
+    # ---- diffusers on-disk layout ----
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True):
+        os.makedirs(os.path.join(save_directory, "unet"), exist_ok=True)
+        os.makedirs(os.path.join(save_directory, "scheduler"), exist_ok=True)
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump({"_class_name": self._class_name, "_diffusers_version": "0.16.1",
+                       "unet": ["diffusers", "UNet2DModel"], "scheduler": ["diffusers", self.scheduler._class_name]}, f, indent=2)
+        cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.unet.config).items()}
+        cfg["_class_name"] = "UNet2DModel"
+        with open(os.path.join(save_directory, "unet", "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2)
+        sd = {k: v.detach().cpu().contiguous().clone() for k, v in self.unet.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "unet", "diffusion_pytorch_model.safetensors"))
+        else:
+            torch.save(sd, os.path.join(save_directory, "unet", "diffusion_pytorch_model.bin"))
+        with open(os.path.join(save_directory, "scheduler", "scheduler_config.json"), "w") as f:
+            json.dump({k: v for k, v in self.scheduler.scheduler_config().items() if v is None or isinstance(v, (int, float, str, bool, list))},
+                      f, indent=2)
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs):
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"{path}: not a local diffusers checkpoint directory (hub ids such as 'google/ddpm-cifar10-32' need a "
+                f"network/HF cache; download the repo and pass its directory)")
+        with open(os.path.join(path, "unet", "config.json")) as f:
+            cfg = json.load(f)
+        cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+        unet = UNet2DModel(**cfg)
+        st = os.path.join(path, "unet", "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "unet", "diffusion_pytorch_model.bin"), map_location="cpu")
+        unet.load_state_dict(sd)
+        with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
+            scfg = json.load(f)
+        name = scfg.pop("_class_name", "DDPMScheduler")
+        scfg = {k: v for k, v in scfg.items() if not k.startswith("_") and k != "prediction_type"}
+        sched = SCHEDULER_CLASSES.get(name, DDPMScheduler)(**scfg)
+        return cls(unet, sched)
+
+
+class DDPMPipeline(DiffusionPipeline):
+    _class_name = "DDPMPipeline"
+    default_steps = 1000
+
+
+class DDIMPipeline(DiffusionPipeline):
+    _class_name = "DDIMPipeline"
+    default_steps = 50
+
+    def _step_kwargs(self, generator, eta):
+        return {"generator": generator, "eta": 0.0 if eta is None else eta}
+
+
+class PNDMPipeline(DiffusionPipeline):
+    """The fork's generic loop used for DPM-Solver / UniPC / ... (model.py:620-652): step(eps, t, x) only."""
+    _class_name = "PNDMPipeline"
+    default_steps = 50
+
+    def _step_kwargs(self, generator, eta):
+        return {}

@@ -1,0 +1,131 @@
+"""One optimiser step of the poisoned fine-tune loop (T1/T2 in SURVEY.md §8a; reference VillanDiffusion.py:1141-1176
+plus the accelerate semantics of SURVEY Appendix B), one process per GPU.
+
+* backward of micro-step k accumulates into the model's flat gradient buffer; the loss gradient is pre-divided by the
+  gradient-accumulation count G inside the MSE kernel (``accelerator.backward``);
+* on a sync step: ONE RCCL all-reduce (SUM) of the flat fp32 gradient bucket over xGMI (replaces nn.DataParallel's
+  per-step parameter broadcast + gradient reduce, VillanDiffusion.py:440), then ONE l2-norm kernel and ONE fused
+  clip + Adam kernel over the flat param/grad/m/v buffers (``clip_grad_norm_(…, 1.0)`` + ``torch.optim.Adam``);
+  the 1/world averaging and the clip coefficient are folded into the Adam kernel's gradient scale;
+* LR = base_lr * cosine-with-warmup(sync_step_count), advanced only on sync steps (accelerate's scheduler wrapper).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .schedulers import get_cosine_schedule_with_warmup_lambda
+
+
+class FusedAdam:
+    """torch.optim.Adam(betas=(0.9, 0.999), eps=1e-8, weight_decay=0) on one flat buffer, with the global-norm clip
+    fused in.  ``state_dict`` is flat too (exp_avg / exp_avg_sq / step)."""
+
+    def __init__(self, model, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: Optional[float] = 1.0):
+        self.model = model
+        self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        self.exp_avg = torch.zeros_like(model.flat_param)
+        self.exp_avg_sq = torch.zeros_like(model.flat_param)
+        self.step_count = 0
+        self._partial = torch.empty(1024, device=model.flat_param.device, dtype=torch.float32)
+        self.grad_norm_sq = torch.zeros(1, device=model.flat_param.device, dtype=torch.float32)
+
+    def step(self, lr: Optional[float] = None, grad_inv_scale: float = 1.0):
+        m = self.model
+        self.step_count += 1
+        nsq = None
+        if self.max_grad_norm is not None:
+            ops.l2norm_sq(m.flat_grad, self._partial, self.grad_norm_sq)
+            nsq = self.grad_norm_sq
+        ops.adam_step(m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, nsq,
+                      float(self.max_grad_norm or 0.0), grad_inv_scale, self.lr if lr is None else lr, self.betas[0],
+                      self.betas[1], self.eps, self.step_count)
+
+    def grad_norm(self, grad_inv_scale: float = 1.0) -> float:
+        """Global L2 norm of the (averaged) gradient of the last step -- synchronises; for logging/tests only."""
+        return math.sqrt(float(self.grad_norm_sq)) * grad_inv_scale
+
+    def state_dict(self) -> Dict:
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "lr": self.lr}
+
+    def load_state_dict(self, sd: Dict):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+        self.lr = float(sd.get("lr", self.lr))
+
+
+def allreduce_flat_grad(flat_grad: torch.Tensor, n_buckets: int = 4):
+    """SUM all-reduce of the flat gradient in a few large buckets (RCCL over xGMI: ring all-reduce is per-link bound,
+    so few large messages; backend "nccl" IS RCCL on ROCm, "gloo" in the CPU tests)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    n = flat_grad.numel()
+    per = (n + n_buckets - 1) // n_buckets
+    per = (per + 1023) // 1024 * 1024
+    works = []
+    for s in range(0, n, per):
+        works.append(dist.all_reduce(flat_grad[s:min(n, s + per)], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+
+
+def shard_indices(n_items: int, epoch: int, rank: int, world: int, seed: int = 0, shuffle: bool = True) -> torch.Tensor:
+    """DistributedSampler-style deterministic sharding: a seeded epoch permutation, padded to a multiple of `world`,
+    rank r takes the contiguous slice r.  Poison flags travel with the sample index."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed + epoch)
+        perm = torch.randperm(n_items, generator=g)
+    else:
+        perm = torch.arange(n_items)
+    total = (n_items + world - 1) // world * world
+    if total > n_items:
+        perm = torch.cat([perm, perm[: total - n_items]])
+    per = total // world
+    return perm[rank * per:(rank + 1) * per]
+
+
+class Trainer:
+    def __init__(self, model, loss_fn, lr: float, total_steps: int, warmup_steps: int = 500, grad_accum: int = 1,
+                 max_grad_norm: Optional[float] = 1.0, n_allreduce_buckets: int = 4):
+        self.model, self.loss_fn = model, loss_fn
+        self.base_lr = lr
+        self.opt = FusedAdam(model, lr, max_grad_norm=max_grad_norm)
+        self.lr_lambda: Callable[[int], float] = get_cosine_schedule_with_warmup_lambda(warmup_steps, total_steps)
+        self.grad_accum = max(1, int(grad_accum))
+        self.micro = 0
+        self.sched_step = 0                       # LambdaLR.last_epoch
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.n_buckets = n_allreduce_buckets
+        self.loss_fn.grad_scale = 1.0 / self.grad_accum
+        model.zero_grad()
+
+    @property
+    def lr(self) -> float:
+        return self.base_lr * self.lr_lambda(self.sched_step)
+
+    def train_step(self, batch, timesteps: torch.Tensor, noise: Optional[torch.Tensor] = None, last_batch: bool = False,
+                   target_key: str = "target", poison_key: str = "pixel_values"):
+        """One micro-step; returns the (un-divided) loss tensor of this micro-batch."""
+        loss = self.loss_fn.p_loss_by_keys(batch, self.model, target_latent_key=target_key, poison_latent_key=poison_key,
+                                           timesteps=timesteps, noise=noise)
+        if torch.is_tensor(loss):
+            loss.backward()
+        self.micro += 1
+        if self.micro % self.grad_accum == 0 or last_batch:       # accelerate: sync on every G-th and on the last batch
+            allreduce_flat_grad(self.model.flat_grad, self.n_buckets)
+            self.opt.step(lr=self.lr, grad_inv_scale=1.0 / self.world)
+            self.sched_step += 1
+            self.model.zero_grad()
+        return loss
+
+    def state_dict(self) -> Dict:
+        return {"optimizer": self.opt.state_dict(), "micro": self.micro, "sched_step": self.sched_step}
+
+    def load_state_dict(self, sd: Dict):
+        self.opt.load_state_dict(sd["optimizer"])
+        self.micro, self.sched_step = int(sd["micro"]), int(sd["sched_step"])

@@ -321,7 +321,7 @@ class UNet2DModel(nn.Module):
         self._decl("time_embedding.linear_1.bias", (temb_dim,), fan_in=boc[0], is_bias=True)
         self._decl("time_embedding.linear_2.weight", (temb_dim, temb_dim), fan_in=temb_dim)
         self._decl("time_embedding.linear_2.bias", (temb_dim,), fan_in=temb_dim, is_bias=True)
-        self.conv_in = _Conv(self, "conv_in", in_channels, boc[0])
+        self._conv_in = _Conv(self, "conv_in", in_channels, boc[0])
 
         self.down: List[dict] = []
         ch = boc[0]
@@ -363,7 +363,7 @@ class UNet2DModel(nn.Module):
             self.up.append(blk)
         assert not sk
         self.norm_out = _Norm(self, "conv_norm_out", boc[0], True)
-        self.conv_out = _Conv(self, "conv_out", boc[0], out_channels)
+        self._conv_out = _Conv(self, "conv_out", boc[0], out_channels)
         self._materialise()
 
     # ------------------------------------------------------------------------------------------ parameter plumbing
@@ -596,8 +596,8 @@ class UNet2DModel(nn.Module):
 
         # ---- down path ----
         k = 0
-        h = skip_out(k, self.conv_in.cout, S); k += 1
-        self.conv_in.fwd(x, h)
+        h = skip_out(k, self._conv_in.cout, S); k += 1
+        self._conv_in.fwd(x, h)
         if save:
             sv.append(("conv_in", x))
         sp = S
@@ -674,7 +674,7 @@ class UNet2DModel(nn.Module):
         a = self._new(B, self.norm_out.ch, S)
         mo, ro = self.norm_out.fwd(final, a)
         out = self._new(B, self.out_channels, S)
-        self.conv_out.fwd(a, out)
+        self._conv_out.fwd(a, out)
         if save:
             sv.append(("out", final, a, mo, ro))
             st.up_slots, st.cats = up_slots, cats
@@ -692,7 +692,7 @@ class UNet2DModel(nn.Module):
         # ---- out ----
         _, final, a, mo, ro = sv.pop()
         da = torch.empty_like(a)
-        self.conv_out.bwd(dout, a, da)
+        self._conv_out.bwd(dout, a, da)
         g = torch.empty(final.shape, device=dev, dtype=torch.float32)
         self.norm_out.bwd(da, final, mo, ro, g)
         # `g` is the gradient wrt the output of the most recent forward op; walk the tape backwards.
@@ -727,7 +727,7 @@ class UNet2DModel(nn.Module):
                 layer.bwd(g, x, dx)
                 g = self._add_skip_grad(dx, x, st, dcats)
             elif kind == "conv_in":
-                self.conv_in.bwd(g, rec[1], None)
+                self._conv_in.bwd(g, rec[1], None)
             else:
                 raise RuntimeError(kind)
         # ---- time embedding backward ----
