@@ -50,7 +50,8 @@ def cpu_baseline(batch: int = 16):
     from oracle.loss_ref import LossFnRef, SDE_VP
     from oracle.schedulers_ref import DDPMSchedulerRef
     from oracle.unet_ref import UNet2DModelRef
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0))          # cores this process may run on (cgroup/affinity), not the host total
+    torch.set_num_threads(max(1, ncpu))
     torch.manual_seed(0)
     net = UNet2DModelRef()
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
@@ -90,6 +91,11 @@ def cpu_baseline(batch: int = 16):
                       f"sampling: 4 images x 5 DDPM steps extrapolated x200",
             "sample_ddpm1000_images_per_sec": round(sample_ips, 5), "host_cpus": os.cpu_count(),
             "affinity": len(os.sched_getaffinity(0))}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -136,8 +142,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    log(f"setup done (world={world}, B={B}); warm-up {args.warmup} steps")
     for i in range(args.warmup):
         one_step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -152,6 +162,7 @@ def main():
     dt = float(tt)
     train_ips = world * B * args.steps / dt
     final_loss = float(loss)
+    log(f"train: {train_ips:.1f} img/s ({1e3 * dt / args.steps:.2f} ms/step), loss {final_loss:.4f}")
 
     # ---- 1000-step DDPM sampling (second half of the metric), embarrassingly parallel ----
     sample_ips, sample_s = None, None
@@ -180,6 +191,7 @@ def main():
         sample_ips = world * n_img / sample_s
         assert bool(torch.isfinite(pp).all())
         sched.device_rng_seed = None
+        log(f"sample: {sample_ips:.4f} img/s ({sample_s:.2f} s for {n_img} images x {args.sample_steps} steps)")
 
     # ---- roofline: per-launch HIP-event timing of the MFMA kernels over one extra training step ----
     roofline, kernels = None, None
@@ -203,9 +215,11 @@ def main():
                     "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
                     "all_mfma_kernels_ms": round(sum(k["ms"] for k in kernels), 2)}
 
+    log("roofline leg done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline()
+        log(f"cpu baseline: {cpu}")
 
     if rank == 0:
         ms = 1e3 * dt / args.steps

@@ -97,6 +97,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: it ships its own HIP runtime (libamdhip64) and this library has to bind to that
+    # SAME runtime instance -- device pointers and streams cross the boundary.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise VillanHipError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback exists). "
