@@ -68,6 +68,8 @@ typedef struct vd_gemm_desc {
     int32_t d_trans;         /* 1: D[n*ldd + m] (n-major store)                                 */
     int32_t accumulate;      /* 1: D += result                                                  */
     int32_t tile;            /* 0 auto, 1: 128x128, 2: 64x128, 3: 64x64                         */
+    int32_t debug;           /* 0 in production. Timing-only ablations (results invalid): 1 = no global loads
+                                after the first K-step, 2 = no epilogue, 4 = no MFMA                            */
     float alpha;
     int64_t lda, a_bstride;  /* a_bstride != 0: per-batch A (requires tile_n | NP)              */
     int64_t ldb, b_bstride;
@@ -76,7 +78,8 @@ typedef struct vd_gemm_desc {
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
-/* Tile (1: 128x128, 2: 64x128, 3: 64x64) vd_gemm will use for this problem (profiling / tests). */
+/* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4: patch-staged 3x3
+ * convolution kernel (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):

@@ -48,6 +48,9 @@ CONV_CASES = [
     (4, 128, 128, 32, B_CONV3, 1), (2, 256, 128, 16, B_CONV3, 2), (8, 64, 256, 4, B_CONV3, 3), (3, 3, 128, 32, B_CONV3, 0),
     (2, 128, 3, 32, B_CONV3, 0), (2, 96, 80, 8, B_CONV3, 0), (2, 128, 128, 16, B_CONV3_S2, 0), (2, 64, 64, 8, B_CONV3_UP, 0),
     (5, 40, 72, 16, B_CONV3, 1),
+    # tile=0 -> the patch-staged kernel where eligible (C % 8 == 0, W in {16, 32}, M >= 64)
+    (4, 128, 128, 32, B_CONV3, 0), (2, 256, 256, 16, B_CONV3, 0), (2, 384, 128, 32, B_CONV3, 0), (3, 512, 256, 16, B_CONV3, 0),
+    (2, 128, 192, 16, B_CONV3, 0), (2, 256, 256, 16, B_CONV3_UP, 0), (3, 64, 72, 32, B_CONV3, 0),
 ]
 
 
@@ -72,6 +75,7 @@ def test_conv3x3_forward_epilogue(B, Cin, Cout, H, mode, tile):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,mode", [(2, 128, 256, 16, B_CONV3), (4, 256, 256, 4, B_CONV3), (2, 64, 64, 16, B_CONV3_S2),
+                                               (2, 128, 128, 32, B_CONV3), (2, 200, 128, 32, B_CONV3), (2, 128, 128, 16, B_CONV3_UP),
                                                (2, 64, 96, 8, B_CONV3_UP), (2, 3, 128, 32, B_CONV3), (2, 128, 3, 32, B_CONV3)])
 def test_conv3x3_backward(B, Cin, Cout, H, mode):
     x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)

@@ -35,9 +35,8 @@ __device__ __forceinline__ void kdecomp9(int k, int& c, int& r, int& s) {
 // One element of the implicit im2col operand for column `px` and reduction index (c, r, s).
 template <int BMODE>
 __device__ __forceinline__ float conv_gather(const float* __restrict__ src, const vd_gemm_desc& d, const Pix& px,
-                                             int64_t boff, int c, int r, int s) {
+                                             int64_t boff, int c, int r, int s, bool& ok) {
     int iy, ix;
-    bool ok;
     if (BMODE == VD_B_CONV3) {
         iy = px.oy + r - 1;
         ix = px.ox + s - 1;
@@ -63,7 +62,16 @@ __device__ __forceinline__ float conv_gather(const float* __restrict__ src, cons
         ok = ok && iy < d.H && ix < d.W;
     }
     ok = ok && px.valid && c < d.C;
-    return ok ? src[boff + (int64_t)c * d.H * d.W + iy * d.W + ix] : 0.0f;
+    // Branch-free: ALWAYS load (from offset 0 of the batch item when masked) and select afterwards.  A predicated
+    // `ok ? src[..] : 0` makes hipcc branch around every load and wait vmcnt(0) per element (cdna guide §5, trap 4c).
+    const int off = ok ? (c * d.H * d.W + iy * d.W + ix) : 0;
+    return src[boff + off];            // caller zeroes masked elements later (deferred select)
+}
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 sel4(bool ok, f32x4 v) {
+    f32x4 z = zero4();
+    return f32x4{ok ? v[0] : z[0], ok ? v[1] : z[1], ok ? v[2] : z[2], ok ? v[3] : z[3]};
 }
 
 // ---- MFMA over one LDS stage -------------------------------------------------------------------------------------
@@ -87,9 +95,75 @@ __device__ __forceinline__ void mma_stage(const f32x4* __restrict__ As, const f3
     }
 }
 
+// ---- shared epilogue: D = alpha*acc + bias + rowadd + residual (+ D) -------------------------------------------------
+// Optional terms sit behind WAVE-UNIFORM branches (kernel arguments), each covering a block of 8 unconditional loads
+// from clamped addresses, so the loads of a block are in flight together (no per-element branch + wait).
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const vd_gemm_desc& d, f32x16 (&acc)[WM][WN], int m0, int n0, int wm, int wn,
+                                              int lane, int h) {
+    const bool has_bias_m = d.bias != nullptr && !d.bias_on_n;
+    const bool has_bias_n = d.bias != nullptr && d.bias_on_n;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int n = n0 + wn * 32 * WN + ni * 32 + (lane & 31);
+        const bool nok = n < d.N;
+        const int nc = nok ? n : d.N - 1;
+        const int b = nc / d.NP, p = nc - b * d.NP;
+        const int64_t dbase = d.d_trans ? (int64_t)nc * d.ldd : ((int64_t)b * d.d_bstride + p);
+        const int64_t dstr = d.d_trans ? 1 : d.ldd;
+        float bn = 0.f;
+        if (has_bias_n) bn = d.bias[nc];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int mbase = m0 + wm * 32 * WM + mi * 32 + 4 * h + 16 * half;   // rows mbase + (u&3) + 8*(u>>2)
+                float val[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) val[u] = d.alpha * acc[mi][ni][8 * half + u] + bn;
+                if (has_bias_m) {
+                    float t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = d.bias[min(mbase + (u & 3) + 8 * (u >> 2), d.M - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) val[u] += t[u];
+                }
+                if (d.rowadd != nullptr) {
+                    float t[8];
+                    const float* ra_ = d.rowadd + (int64_t)b * d.rowadd_bstride;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = ra_[min(mbase + (u & 3) + 8 * (u >> 2), d.M - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) val[u] += t[u];
+                }
+                if (d.residual != nullptr) {
+                    float t[8];
+                    const float* rs_ = d.residual + (int64_t)b * d.res_bstride + p;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = rs_[(int64_t)min(mbase + (u & 3) + 8 * (u >> 2), d.M - 1) * d.ldd];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) val[u] += t[u];
+                }
+                if (d.accumulate) {
+                    float t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = d.D[dbase + (int64_t)min(mbase + (u & 3) + 8 * (u >> 2), d.M - 1) * dstr];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) val[u] += t[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = mbase + (u & 3) + 8 * (u >> 2);
+                    if (nok && m < d.M) d.D[dbase + (int64_t)m * dstr] = val[u];
+                }
+            }
+        }
+    }
+}
+
 // ---- generic GEMM / conv forward / dgrad -------------------------------------------------------------------------
 template <int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(NT) void gemm_kernel(const vd_gemm_desc d) {
+__global__ __launch_bounds__(NT, 3) void gemm_kernel(const vd_gemm_desc d) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA_ = BM + 1, LDB_ = BN + 1;
     constexpr int A_F4 = BM * KG / NT;  // float4 slots per thread for A
@@ -137,83 +211,102 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vd_gemm_desc d) {
         boff = (int64_t)px.b * d.b_bstride;
     }
 
+    // Global->register staging.  Loads are UNCONDITIONAL (masked lanes read a clamped, valid address) and their
+    // validity bits are kept in amask/bmask; the zeroing select is applied in store_ab(), i.e. after the MFMAs of the
+    // current K-step, so nothing consumes a load result (and forces an s_waitcnt) while the loads are being issued.
     f32x4 ra[A_F4], rb[B_F4];
+    unsigned amask = 0, bmask = 0;      // bit (4*i + j) = element j of slot i is valid
 
     auto load_a = [&](int k0) {
+        amask = 0;
         if (AMODE == VD_A_ROW) {
+            if (a_vec) {                                       // wave-uniform
 #pragma unroll
-            for (int i = 0; i < A_F4; ++i) {
-                const int idx = tid + i * NT;
-                const int m = m0 + (idx >> 3), k = k0 + (idx & 7) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < d.M) {
-                    const float* p = Ap + (int64_t)m * d.lda + k;
-                    if (a_vec) {
-                        if (k < d.K) v = *reinterpret_cast<const f32x4*>(p);
-                    } else {
+                for (int i = 0; i < A_F4; ++i) {
+                    const int idx = tid + i * NT;
+                    const int m = m0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                    const bool ok = m < d.M && k < d.K;
+                    ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)(ok ? m : 0) * d.lda + (ok ? k : 0));
+                    amask |= (ok ? 0xFu : 0u) << (4 * i);
+                }
+            } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (k + j < d.K) v[j] = p[j];
+                for (int i = 0; i < A_F4; ++i) {
+                    const int idx = tid + i * NT;
+                    const int m = m0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                    const bool mok = m < d.M;
+                    const float* p = Ap + (int64_t)(mok ? m : 0) * d.lda;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = mok && (k + j < d.K);
+                        ra[i][j] = p[ok ? k + j : 0];
+                        amask |= (ok ? 1u : 0u) << (4 * i + j);
                     }
                 }
-                ra[i] = v;
             }
         } else {  // VD_A_COL: lanes run along m
             const int m = m0 + (tid % BM);
+            const bool mok = m < d.M;
+            const float* p = Ap + (mok ? m : 0);
             constexpr int KQ_STEP = NT / BM;
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const int k = k0 + ((tid / BM) + i * KQ_STEP) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < d.M) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k + j < d.K) v[j] = Ap[(int64_t)(k + j) * d.lda + m];
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = mok && (k + j < d.K);
+                    ra[i][j] = p[(int64_t)(ok ? k + j : 0) * d.lda];
+                    amask |= (ok ? 1u : 0u) << (4 * i + j);
                 }
-                ra[i] = v;
             }
         }
     };
 
     auto load_b = [&](int k0) {
+        bmask = 0;
         if (BMODE == VD_B_KCONTIG) {
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int idx = tid + i * NT;
                 const int n = n0 + (idx >> 3), k = k0 + (idx & 7) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < d.N) {
-                    const int b = n / d.NP, p = n - b * d.NP;
-                    const float* q = Bp + (int64_t)b * d.b_bstride + (int64_t)p * d.ldb + k;
-                    if (b_vec) {
-                        if (k < d.K) v = *reinterpret_cast<const f32x4*>(q);
-                    } else {
+                const bool nok = n < d.N;
+                const int nn = nok ? n : 0;
+                const int b = nn / d.NP, p = nn - b * d.NP;
+                const float* q = Bp + (int64_t)b * d.b_bstride + (int64_t)p * d.ldb;
+                if (b_vec) {
+                    const bool ok = nok && k < d.K;
+                    rb[i] = *reinterpret_cast<const f32x4*>(q + (ok ? k : 0));
+                    bmask |= (ok ? 0xFu : 0u) << (4 * i);
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (k + j < d.K) v[j] = q[j];
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = nok && (k + j < d.K);
+                        rb[i][j] = q[ok ? k + j : 0];
+                        bmask |= (ok ? 1u : 0u) << (4 * i + j);
                     }
                 }
-                rb[i] = v;
             }
         } else {
             constexpr int KQ_STEP = NT / BN;
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int k = k0 + ((tid / BN) + i * KQ_STEP) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (BMODE == VD_B_PLAIN) {
-                    if (px.valid) {
-                        const float* q = Bp + boff + px.p;
+                    const float* q = Bp + boff + px.p;           // px.p = 0, boff = 0 when the column is out of range
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (k + j < d.K) v[j] = q[(int64_t)(k + j) * d.ldb];
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = px.valid && (k + j < d.K);
+                        rb[i][j] = q[(int64_t)(ok ? k + j : 0) * d.ldb];
+                        bmask |= (ok ? 1u : 0u) << (4 * i + j);
                     }
                 } else {
                     int c, r, s;
                     kdecomp9(k, c, r, s);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        v[j] = conv_gather<BMODE>(Bp, d, px, boff, c, r, s);
+                        bool ok;
+                        rb[i][j] = conv_gather<BMODE>(Bp, d, px, boff, c, r, s, ok);
+                        bmask |= (ok ? 1u : 0u) << (4 * i + j);
                         if (++s == 3) {
                             s = 0;
                             if (++r == 3) {
@@ -223,33 +316,35 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vd_gemm_desc d) {
                         }
                     }
                 }
-                rb[i] = v;
             }
         }
     };
 
+    auto masked = [](f32x4 v, unsigned bits) {
+        return f32x4{(bits & 1u) ? v[0] : 0.f, (bits & 2u) ? v[1] : 0.f, (bits & 4u) ? v[2] : 0.f, (bits & 8u) ? v[3] : 0.f};
+    };
     auto store_ab = [&]() {
         if (AMODE == VD_A_ROW) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const int idx = tid + i * NT;
-                As[(idx & 7) * LDA_ + (idx >> 3)] = ra[i];
+                As[(idx & 7) * LDA_ + (idx >> 3)] = masked(ra[i], amask >> (4 * i));
             }
         } else {
             constexpr int KQ_STEP = NT / BM;
 #pragma unroll
-            for (int i = 0; i < A_F4; ++i) As[((tid / BM) + i * KQ_STEP) * LDA_ + (tid % BM)] = ra[i];
+            for (int i = 0; i < A_F4; ++i) As[((tid / BM) + i * KQ_STEP) * LDA_ + (tid % BM)] = masked(ra[i], amask >> (4 * i));
         }
         if (BMODE == VD_B_KCONTIG) {
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int idx = tid + i * NT;
-                Bs[(idx & 7) * LDB_ + (idx >> 3)] = rb[i];
+                Bs[(idx & 7) * LDB_ + (idx >> 3)] = masked(rb[i], bmask >> (4 * i));
             }
         } else {
             constexpr int KQ_STEP = NT / BN;
 #pragma unroll
-            for (int i = 0; i < B_F4; ++i) Bs[((tid / BN) + i * KQ_STEP) * LDB_ + (tid % BN)] = rb[i];
+            for (int i = 0; i < B_F4; ++i) Bs[((tid / BN) + i * KQ_STEP) * LDB_ + (tid % BN)] = masked(rb[i], bmask >> (4 * i));
         }
     };
 
@@ -270,47 +365,217 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vd_gemm_desc d) {
     load_b(0);
     store_ab();
     __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const bool more = kt + 1 < ktiles;
-        if (more) {
-            load_a((kt + 1) * BK);
-            load_b((kt + 1) * BK);
+    if (d.debug == 0) {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const bool more = kt + 1 < ktiles;
+            if (more) {
+                load_a((kt + 1) * BK);
+                load_b((kt + 1) * BK);
+            }
+            mma_stage<WM, WN, LDA_, LDB_>(As, Bs, arow, bcol, h, acc);
+            __syncthreads();
+            if (more) store_ab();
+            __syncthreads();
         }
-        mma_stage<WM, WN, LDA_, LDB_>(As, Bs, arow, bcol, h, acc);
-        __syncthreads();
-        if (more) store_ab();
-        __syncthreads();
+    } else {  // timing-only ablations (results are invalid)
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const bool more = kt + 1 < ktiles;
+            if (more && !(d.debug & 1)) {
+                load_a((kt + 1) * BK);
+                load_b((kt + 1) * BK);
+            }
+            if (!(d.debug & 4)) mma_stage<WM, WN, LDA_, LDB_>(As, Bs, arow, bcol, h, acc);
+            __syncthreads();
+            if (more && !(d.debug & 8)) store_ab();
+            __syncthreads();
+        }
+        if (d.debug & 2) {
+            float s = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) s += acc[mi][ni][v];
+            if (s == 123456.789f) d.D[0] = s;
+            return;
+        }
     }
 
-    // ---- epilogue: alpha*acc + bias + rowadd + residual (+ D) ----
+    gemm_epilogue<WM, WN>(d, acc, m0, n0, wm, wn, lane, h);
+}
+
+// ---- patch-staged 3x3 convolution (forward / stride-1 dgrad / fused nearest-2x upsample) ---------------------------
+// The im2col gather of gemm_kernel costs ~500 VALU instructions and 16 scalar loads per thread per 32-k step (9 taps
+// re-load every input element).  Here one workgroup owns 128 output channels x (128/W) full-width output rows of one
+// image and, per K-step of CK = 8 input channels (72 k), stages
+//     As[72][128]            the weight slab (k-major, read by lanes along m: conflict-free ds_read_b32)
+//     Ps[8][PR][PW]          the zero-padded input halo patch, each element loaded ONCE
+// MFMA step (channel pair cp, tap (r,s)) reads  A = As[(2cp+h)*9 + 3r+s][m]  and  B = Ps[2cp+h][ty+r][x+s]  with
+// lane-constant bases and IMMEDIATE offsets: no address arithmetic in the inner loop.  The two k-slots of the
+// 32x32x2 MFMA (lane halves h) are the two channels of a pair.  Patch source offsets are computed once per tile.
+constexpr int CK = 8;
+constexpr int KSTEP = CK * 9;
+
+template <int W, int MODE>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution)
+__global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d) {
+    constexpr int WM = 2, WN = 2, BM = 128;
+    constexpr int TR = 128 / W;              // output rows per tile
+    constexpr int PW = W + 2, PR = TR + 2;   // halo patch
+    constexpr int PLANE = PR * PW;
+    constexpr int LDA_ = BM + 1;
+    constexpr int A_F4 = BM * KSTEP / 4 / NT;            // 9 float4 per thread
+    constexpr int P_EL = (CK * PLANE + NT - 1) / NT;     // patch elements per thread (7 / 6)
+    __shared__ float As[KSTEP * LDA_];
+    __shared__ float Ps[CK * PLANE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * 128;
+    const int tiles_per_img = d.NP / 128;
+    const int b = tn / tiles_per_img;
+    const int y0 = (tn - b * tiles_per_img) * TR;        // first output row of this tile
+    const float* __restrict__ Ap = d.A;
+    const float* __restrict__ Xb = d.B + (int64_t)b * d.b_bstride;
+    const int HWs = d.H * d.W;                           // source plane (half resolution for MODE 2)
+
+    // patch element -> source offset (channel 0 of the K-step), fixed for the whole tile
+    int poff[P_EL];
+    unsigned pmask = 0;
+#pragma unroll
+    for (int i = 0; i < P_EL; ++i) {
+        const int e = tid + i * NT;
+        const int c = e / PLANE, rem = e - c * PLANE;
+        const int py = rem / PW, px = rem - py * PW;
+        int iy = y0 + py - 1, ix = px - 1;               // coordinates in the (virtual, for MODE 2: upsampled) input
+        bool ok = e < CK * PLANE;
+        if (MODE == 2) {
+            ok = ok && (unsigned)iy < (unsigned)(2 * d.H) && (unsigned)ix < (unsigned)(2 * d.W);
+            iy >>= 1;
+            ix >>= 1;
+        } else {
+            ok = ok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+        }
+        poff[i] = ok ? (c * HWs + iy * d.W + ix) : 0;
+        pmask |= (ok ? 1u : 0u) << i;
+    }
+
+    f32x4 ra[A_F4];
+    float rp[P_EL];
+    auto load_stage = [&](int c0) {                      // c0: first input channel of the K-step
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * NT;
+            const int m = idx / (KSTEP / 4), q = idx - m * (KSTEP / 4);
+            const int mm = min(m0 + m, d.M - 1);
+            ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)mm * d.lda + c0 * 9 + 4 * q);
+        }
+        const float* __restrict__ xs = Xb + (int64_t)c0 * HWs;
+#pragma unroll
+        for (int i = 0; i < P_EL; ++i) rp[i] = xs[poff[i]];
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * NT;
+            const int m = idx / (KSTEP / 4), q = idx - m * (KSTEP / 4);
+            const bool ok = m0 + m < d.M;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[(4 * q + j) * LDA_ + m] = ok ? ra[i][j] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < P_EL; ++i) {
+            const int e = tid + i * NT;
+            if (e < CK * PLANE) Ps[e] = ((pmask >> i) & 1u) ? rp[i] : 0.f;
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.f;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    // lane-constant LDS bases: A rows of this wave; patch position of this lane's pixel in each of its WN column groups
+    const float* __restrict__ a_base = As + h * 9 * LDA_ + wm * 64 + (lane & 31);
+    const float* __restrict__ p_base[WN];
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
-        const int n = n0 + wn * 32 * WN + ni * 32 + (lane & 31);
-        if (n >= d.N) continue;
-        const int b = n / d.NP, p = n - b * d.NP;
-        const float bn = (d.bias && d.bias_on_n) ? d.bias[n] : 0.f;
+        const int q = (wn * WN + ni) * 32 + (lane & 31);     // pixel within the tile
+        const int ty = q / W, x = q - ty * W;
+        p_base[ni] = Ps + h * PLANE + ty * PW + x;
+    }
+
+    const int nsteps = d.C / CK;
+    load_stage(0);
+    store_stage();
+    __syncthreads();
+    for (int ks = 0; ks < nsteps; ++ks) {
+        const bool more = ks + 1 < nsteps;
+        if (more) load_stage((ks + 1) * CK);
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
+        for (int cp = 0; cp < CK / 2; ++cp) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int m = m0 + wm * 32 * WM + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (m >= d.M) continue;
-                float val = d.alpha * acc[mi][ni][v] + bn;
-                if (d.bias && !d.bias_on_n) val += d.bias[m];
-                if (d.rowadd) val += d.rowadd[(int64_t)b * d.rowadd_bstride + m];
-                const int64_t off = d.d_trans ? ((int64_t)n * d.ldd + m) : ((int64_t)b * d.d_bstride + (int64_t)m * d.ldd + p);
-                if (d.residual) val += d.residual[(int64_t)b * d.res_bstride + (int64_t)m * d.ldd + p];
-                if (d.accumulate) val += d.D[off];
-                d.D[off] = val;
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, sx = t - 3 * r;
+                const int pr = (MODE == 1) ? (2 - r) : r, ps = (MODE == 1) ? (2 - sx) : sx;
+                float a[WM], bb[WN];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) a[mi] = a_base[(2 * cp * 9 + t) * LDA_ + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) bb[ni] = p_base[ni][2 * cp * PLANE + pr * PW + ps];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
             }
         }
+        __syncthreads();
+        if (more) store_stage();
+        __syncthreads();
     }
+    gemm_epilogue<WM, WN>(d, acc, m0, n0, wm, wn, lane, h);
+}
+
+// Eligibility of the patch-staged kernel for a vd_gemm problem.
+static bool patch_eligible(const vd_gemm_desc& d) {
+    if (d.a_mode != VD_A_ROW || d.a_bstride != 0) return false;
+    if (d.b_mode != VD_B_CONV3 && d.b_mode != VD_B_CONV3_T && d.b_mode != VD_B_CONV3_UP) return false;
+    if (d.OW != 16 && d.OW != 32) return false;
+    if (d.C % CK != 0 || d.NP % 128 != 0 || d.OH * d.OW != d.NP) return false;
+    if (d.K != d.C * 9 || (d.lda & 3) != 0 || (((uintptr_t)d.A) & 15) != 0) return false;
+    if (d.debug != 0 || d.tile != 0) return false;
+    return d.M >= 64;
+}
+
+static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
+    const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
+    const int mode = d.b_mode == VD_B_CONV3 ? 0 : (d.b_mode == VD_B_CONV3_T ? 1 : 2);
+#define VD_PATCH_CASE(WW, MD)                                                                        \
+    if (d.OW == WW && mode == MD) {                                                                  \
+        hipLaunchKernelGGL((conv3_patch_kernel<WW, MD>), dim3(grid), dim3(NT), 0, st, d);            \
+        return 0;                                                                                    \
+    }
+    VD_PATCH_CASE(32, 0) VD_PATCH_CASE(32, 1) VD_PATCH_CASE(32, 2)
+    VD_PATCH_CASE(16, 0) VD_PATCH_CASE(16, 1) VD_PATCH_CASE(16, 2)
+#undef VD_PATCH_CASE
+    return VD_EINVAL;
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------
 // D[m][n=(c,t)] = sum_{kk=(b,p)} dY[b][m][p] * gather(X)[b][c][p (+) t];  split-K over kk, slabs reduced afterwards.
 template <int WM, int WN, int BMODE>
-__global__ __launch_bounds__(NT) void wgrad_kernel(const vd_wgrad_desc d, int kk_per_split) {
+__global__ __launch_bounds__(NT, 3) void wgrad_kernel(const vd_wgrad_desc d, int kk_per_split) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA_ = BM + 1, LDB_ = BN + 1;
     constexpr int A_F4 = BM * KG / NT;
@@ -348,68 +613,73 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const vd_wgrad_desc d, int kk
     const int HW = d.H * d.W;
 
     f32x4 ra[A_F4], rb[B_F4];
+    unsigned amask = 0, bmask = 0;     // validity bits; the zeroing select is deferred to store_ab() (after the MFMAs)
     auto load_ab = [&](int kk0) {
-        // A: dY[b][m][p..p+3], lanes: (m = idx>>3, kq = idx&7)
+        amask = bmask = 0;
+        // A: dY[b][m][p..p+3], lanes: (m = idx>>3, kq = idx&7).  Unconditional loads from clamped addresses.
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int idx = tid + i * NT;
             const int m = m0 + (idx >> 3), kk = kk0 + (idx & 7) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < d.M && kk < kk_end) {
-                const int b = kk / d.NP, p = kk - b * d.NP;
-                v = *reinterpret_cast<const f32x4*>(d.dY + (int64_t)b * d.dy_bstride + (int64_t)m * d.NP + p);
-            }
-            ra[i] = v;
+            const bool ok = m < d.M && kk < kk_end;
+            const int kc = ok ? kk : 0;
+            const int b = kc / d.NP, p = kc - b * d.NP;
+            ra[i] = *reinterpret_cast<const f32x4*>(d.dY + (int64_t)b * d.dy_bstride + (int64_t)(ok ? m : 0) * d.NP + p);
+            amask |= (ok ? 0xFu : 0u) << (4 * i);
         }
         // B: gather of X for 4 consecutive output pixels of one row
         const int kk = kk0 + kq * 4;
         const bool kvalid = kk < kk_end;
-        const int b = kvalid ? kk / d.NP : 0;
-        const int p = kvalid ? kk - b * d.NP : 0;
+        const int kc = kvalid ? kk : 0;
+        const int b = kc / d.NP;
+        const int p = kc - b * d.NP;
         const int oy = p / d.OW, ox0 = p - oy * d.OW;
         const float* __restrict__ xb = d.X + (int64_t)b * d.x_bstride;
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kvalid && nc[i] >= 0) {
-                const float* __restrict__ xc = xb + (int64_t)nc[i] * HW;
-                if (BMODE == VD_B_PLAIN) {
-                    v = *reinterpret_cast<const f32x4*>(xc + p);
-                } else {
+            const bool cok = kvalid && nc[i] >= 0;
+            const float* __restrict__ xc = xb + (int64_t)(cok ? nc[i] : 0) * HW;
+            if (BMODE == VD_B_PLAIN) {
+                rb[i] = *reinterpret_cast<const f32x4*>(xc + p);
+                bmask |= (cok ? 0xFu : 0u) << (4 * i);
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int ox = ox0 + j;
-                        int iy, ix;
-                        bool ok;
-                        if (BMODE == VD_B_CONV3) {
-                            iy = oy + nr[i] - 1;
-                            ix = ox + ns[i] - 1;
-                            ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-                        } else if (BMODE == VD_B_CONV3_S2) {
-                            iy = 2 * oy + nr[i];
-                            ix = 2 * ox + ns[i];
-                            ok = iy < d.H && ix < d.W;
-                        } else {  // VD_B_CONV3_UP
-                            const int uy = oy + nr[i] - 1, ux = ox + ns[i] - 1;
-                            ok = (unsigned)uy < (unsigned)(2 * d.H) && (unsigned)ux < (unsigned)(2 * d.W);
-                            iy = uy >> 1;
-                            ix = ux >> 1;
-                        }
-                        v[j] = ok ? xc[iy * d.W + ix] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int ox = ox0 + j;
+                    int iy, ix;
+                    bool ok;
+                    if (BMODE == VD_B_CONV3) {
+                        iy = oy + nr[i] - 1;
+                        ix = ox + ns[i] - 1;
+                        ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                    } else if (BMODE == VD_B_CONV3_S2) {
+                        iy = 2 * oy + nr[i];
+                        ix = 2 * ox + ns[i];
+                        ok = iy < d.H && ix < d.W;
+                    } else {  // VD_B_CONV3_UP
+                        const int uy = oy + nr[i] - 1, ux = ox + ns[i] - 1;
+                        ok = (unsigned)uy < (unsigned)(2 * d.H) && (unsigned)ux < (unsigned)(2 * d.W);
+                        iy = uy >> 1;
+                        ix = ux >> 1;
                     }
+                    ok = ok && cok;
+                    rb[i][j] = xc[ok ? iy * d.W + ix : 0];
+                    bmask |= (ok ? 1u : 0u) << (4 * i + j);
                 }
             }
-            rb[i] = v;
         }
+    };
+    auto masked = [](f32x4 v, unsigned bits) {
+        return f32x4{(bits & 1u) ? v[0] : 0.f, (bits & 2u) ? v[1] : 0.f, (bits & 4u) ? v[2] : 0.f, (bits & 8u) ? v[3] : 0.f};
     };
     auto store_ab = [&]() {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int idx = tid + i * NT;
-            As[(idx & 7) * LDA_ + (idx >> 3)] = ra[i];
+            As[(idx & 7) * LDA_ + (idx >> 3)] = masked(ra[i], amask >> (4 * i));
         }
 #pragma unroll
-        for (int i = 0; i < B_F4; ++i) Bs[kq * LDB_ + (tid >> 3) + 32 * i] = rb[i];
+        for (int i = 0; i < B_F4; ++i) Bs[kq * LDB_ + (tid >> 3) + 32 * i] = masked(rb[i], bmask >> (4 * i));
     };
 
     f32x16 acc[WM][WN];
@@ -529,13 +799,31 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ X
     if (lane == 0) ws[(int64_t)b * ws_ld + m] = s;
 }
 
+// out[c] (+)= sum_b ws[b][c].  64 columns per workgroup; wave w sums rows b = w, w+4, ... with 8 independent loads in
+// flight, then the four partials are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ ws, float* __restrict__ out, int B, int C,
                                                      int64_t ld, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += ws[(int64_t)b * ld + c];
-    out[c] = accumulate ? (out[c] + s) : s;
+    if (c < C) {
+        int b = w;
+        for (; b + 28 < B; b += 32) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = ws[(int64_t)(b + 4 * u) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; b < B; b += 4) s += ws[(int64_t)b * ld + c];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[c] = accumulate ? (out[c] + t) : t;
+    }
 }
 
 template <int WM, int WN>
@@ -593,6 +881,7 @@ int launch_wgrad_t(const vd_wgrad_desc& d, int splits, int kk_per, hipStream_t s
 extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
+    if (patch_eligible(d)) return 4;
     int max_bn = 128;
     if (d.a_bstride != 0 && d.NP % 128 != 0) max_bn = 64;
     int tile = d.tile ? d.tile : pick_tile(d.M, d.N, max_bn);
@@ -619,6 +908,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 1: rc = launch_gemm_t<2, 2>(d, st); break;
         case 2: rc = launch_gemm_t<1, 2>(d, st); break;
         case 3: rc = launch_gemm_t<1, 1>(d, st); break;
+        case 4: rc = launch_patch(d, st); break;
         default: vd_set_error("vd_gemm: bad tile %d", tile); return VD_EINVAL;
     }
     if (rc) return rc;
@@ -728,7 +1018,7 @@ extern "C" int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t
 
 extern "C" int vd_colsum(const float* ws, float* out, int B, int C, int64_t ld, int accumulate, void* stream) {
     VD_REQUIRE(ws && out && B > 0 && C > 0, "vd_colsum: bad args");
-    hipLaunchKernelGGL(colsum_kernel, dim3(vd_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, out, B, C, ld, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(vd_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, out, B, C, ld, accumulate);
     VD_LAUNCH_CHECK("vd_colsum");
     return 0;
 }

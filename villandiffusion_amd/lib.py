@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", _vp), ("B", _vp), ("D", _vp), ("bias", _vp), ("rowadd", _vp), ("residual", _vp),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("a_mode", _i32), ("b_mode", _i32), ("NP", _i32),
                 ("C", _i32), ("H", _i32), ("W", _i32), ("OH", _i32), ("OW", _i32),
-                ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("alpha", _f32),
+                ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("debug", _i32), ("alpha", _f32),
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64)]
 

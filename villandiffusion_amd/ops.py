@@ -26,7 +26,7 @@ def _lib():
 _PROF = None          # list of (kernel_symbol, algorithmic_flops, start_event, end_event) while enabled
 
 _B_NAMES = {0: "PLAIN", 1: "KCONTIG", 2: "CONV3", 3: "CONV3_T", 4: "CONV3_S2", 5: "CONV3_UP", 6: "CONV3_DIL"}
-_TILE_NAMES = {1: "128x128", 2: "64x128", 3: "64x64"}
+_TILE_NAMES = {1: "128x128", 2: "64x128", 3: "64x64", 4: "patch128x128"}
 
 
 def profile_start():
@@ -60,7 +60,7 @@ def _img(t: torch.Tensor):
 # --------------------------------------------------------------------------------------------- GEMM family
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
-         res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0):
+         res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0):
     d = GemmDesc()
     d.A, d.B, d.D = _p(A), _p(B), _p(D)
     d.bias, d.rowadd, d.residual = _p(bias), _p(rowadd), _p(residual)
@@ -71,6 +71,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         d.C, d.H, d.W, d.OH, d.OW = conv
     d.bias_on_n, d.d_trans, d.accumulate, d.tile = int(bias_on_n), int(d_trans), int(accumulate), tile
     d.alpha = alpha
+    d.debug = debug
     d.lda, d.a_bstride, d.ldb, d.b_bstride = lda, a_bstride, ldb, b_bstride
     d.ldd, d.d_bstride, d.res_bstride, d.rowadd_bstride = ldd, d_bstride, res_bstride, rowadd_bstride
     lib = _lib()
@@ -91,7 +92,7 @@ _CONV_OUT = {B_CONV3: lambda h, w: (h, w), B_CONV3_T: lambda h, w: (h, w), B_CON
              B_CONV3_UP: lambda h, w: (2 * h, 2 * w), B_CONV3_DIL: lambda h, w: (2 * h, 2 * w)}
 
 
-def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0):
+def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0):
     """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9]."""
     Bn, Cc, H, W, xbs = _img(x)
     M = w2d.shape[0]
@@ -105,7 +106,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
         assert residual.shape == out.shape
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
                 ldd=OH * OW, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
-                residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile)
+                residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug)
 
 
 def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0):
