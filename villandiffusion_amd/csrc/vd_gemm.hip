@@ -726,6 +726,199 @@ __global__ __launch_bounds__(NT, 3) void wgrad_kernel(const vd_wgrad_desc d, int
     }
 }
 
+// ---- patch-staged weight gradient (3x3, stride 1; optionally through the fused nearest-2x upsample) --------------
+// One workgroup owns 128 output channels (rows, from dY) x 64 input channels x the 3 horizontal taps s of ONE tap row r
+// and a contiguous range of K-steps; a K-step is 32 consecutive output pixels (ROWS = 32/W full rows of one image):
+//     As[8][128][4]        dY in the b128 k-group layout of gemm_kernel (pixel groups of 4)
+//     Bs[64][ROWS][W+2]    the X rows y+r-1 with a one-pixel halo, each element loaded ONCE; the three taps s are
+//                          three LDS address offsets into the same patch (6 ds_read_b32 feed 12 MFMAs per channel group)
+// Per 8 pixels a wave issues 2 ds_read_b128 + 6 ds_read_b32 for 24 MFMAs; no address arithmetic in the inner loop.
+// Split-K partial slabs are reduced in fixed order by slab_reduce_kernel (deterministic).
+template <int W, int MODE>  // MODE 0: CONV3, 2: CONV3_UP (X is the half-resolution source)
+__global__ __launch_bounds__(NT, 3) void wgrad_patch_kernel(const vd_wgrad_desc d, int ksteps_per_split) {
+    constexpr int ROWS = 32 / W;
+    constexpr int PW = W + 2;
+    constexpr int PLn = ROWS * PW;                 // patch floats per channel
+    constexpr int CT = 64;                         // input channels per workgroup
+    constexpr int LDA_ = 128 + 1;                  // float4 units
+    constexpr int LDB_ = (PLn & 1) ? PLn : PLn + 1;
+    constexpr int A_F4 = 128 * 32 / 4 / NT;        // 4
+    constexpr int P_EL = (CT * PLn + NT - 1) / NT; // 9
+    __shared__ f32x4 As[KG * LDA_];
+    __shared__ float Bs[CT * LDB_];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int tiles_m = (d.M + 127) / 128;
+    const int r = blockIdx.x % 3;
+    const int rest = blockIdx.x / 3;
+    const int tm = rest % tiles_m, tc = rest / tiles_m;
+    const int m0 = tm * 128, c0 = tc * CT;
+    const int steps_per_img = d.OH / ROWS;
+    const int ks_total = d.nb * steps_per_img;
+    const int ks_begin = blockIdx.y * ksteps_per_split;
+    const int ks_end = min(ks_total, ks_begin + ksteps_per_split);
+    const int HWs = d.H * d.W;
+
+    // patch element -> column part of the source offset + validity (fixed); the row term is added per K-step
+    int pcol_off[P_EL];
+    unsigned pmask = 0, prowbits = 0;              // bit i: element valid / element lies in patch row 1
+#pragma unroll
+    for (int i = 0; i < P_EL; ++i) {
+        const int e = tid + i * NT;
+        const int c = e / PLn, rem = e - c * PLn;
+        const int rr = rem / PW, px = rem - rr * PW;
+        int ix = px - 1;
+        bool ok = e < CT * PLn && (c0 + c) < d.C;
+        if (MODE == 2) {
+            ok = ok && (unsigned)ix < (unsigned)(2 * d.W);
+            ix >>= 1;
+        } else {
+            ok = ok && (unsigned)ix < (unsigned)d.W;
+        }
+        pcol_off[i] = ok ? ((c0 + c) * HWs + ix) : 0;
+        pmask |= (ok ? 1u : 0u) << i;
+        prowbits |= ((ROWS > 1 && rr > 0) ? 1u : 0u) << i;
+    }
+
+    f32x4 ra[A_F4];
+    float rp[P_EL];
+    unsigned rowmask = 0;                          // bit rr: source row of patch row rr is inside the image
+    auto load_stage = [&](int ks) {
+        const int b = ks / steps_per_img;
+        const int y0 = (ks - b * steps_per_img) * ROWS;
+        const float* __restrict__ dyb = d.dY + (int64_t)b * d.dy_bstride + y0 * W;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * NT;
+            const int m = idx >> 3, q = idx & 7;
+            const int mm = min(m0 + m, d.M - 1);
+            ra[i] = *reinterpret_cast<const f32x4*>(dyb + (int64_t)mm * d.NP + 4 * q);
+        }
+        const float* __restrict__ xb = d.X + (int64_t)b * d.x_bstride;
+        int rowoff[2] = {0, 0};
+        rowmask = 0;
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            int iy = y0 + rr + r - 1;
+            bool ok;
+            if (MODE == 2) {
+                ok = (unsigned)iy < (unsigned)(2 * d.H);
+                iy >>= 1;
+            } else {
+                ok = (unsigned)iy < (unsigned)d.H;
+            }
+            rowoff[rr] = ok ? iy * d.W : 0;
+            rowmask |= (ok ? 1u : 0u) << rr;
+        }
+#pragma unroll
+        for (int i = 0; i < P_EL; ++i) {
+            const int ro = ((prowbits >> i) & 1u) ? rowoff[1] : rowoff[0];
+            rp[i] = xb[pcol_off[i] + ro];
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * NT;
+            const int m = idx >> 3, q = idx & 7;
+            const bool ok = m0 + m < d.M;
+            As[q * LDA_ + m] = ok ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < P_EL; ++i) {
+            const int e = tid + i * NT;
+            if (e < CT * PLn) {
+                const int c = e / PLn, rem = e - c * PLn;
+                const bool ok = ((pmask >> i) & 1u) && ((rowmask >> ((prowbits >> i) & 1u)) & 1u);
+                Bs[c * LDB_ + rem] = ok ? rp[i] : 0.f;
+            }
+        }
+    };
+
+    f32x16 acc[2][3];                              // [m group][tap s]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][sx][v] = 0.f;
+
+    const int wm = wave >> 1, wc = wave & 1;       // 2 x 2 waves: 64 m x 32 c each
+    const f32x4* __restrict__ a_base = As + h * LDA_ + wm * 64 + (lane & 31);
+    const float* __restrict__ b_base = Bs + (wc * 32 + (lane & 31)) * LDB_ + 4 * h;
+
+    if (ks_begin < ks_end) {
+        load_stage(ks_begin);
+        store_stage();
+        __syncthreads();
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const bool more = ks + 1 < ks_end;
+            if (more) load_stage(ks + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {          // 8 pixels: k-slot h covers pixels 8g+4h .. 8g+4h+3
+                const int rr = (8 * g) / W, x0 = 8 * g - rr * W;
+                f32x4 a[2];
+                float bw[6];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = a_base[2 * g * LDA_ + mi * 32];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) bw[j] = b_base[rr * PW + x0 + j];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int sx = 0; sx < 3; ++sx)
+                            acc[mi][sx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], bw[t + sx], acc[mi][sx], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) store_stage();
+            __syncthreads();
+        }
+    }
+
+    const int Ncols = d.C * 9;
+    float* __restrict__ out = (gridDim.y > 1) ? (d.ws + (int64_t)blockIdx.y * d.M * Ncols) : d.dW;
+    const bool accum = (gridDim.y == 1) && d.accumulate;
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (c < d.C) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= d.M) continue;
+                const int64_t off = (int64_t)m * Ncols + c * 9 + r * 3;
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) out[off + sx] = accum ? (out[off + sx] + acc[mi][sx][v]) : acc[mi][sx][v];
+            }
+    }
+}
+
+static bool wgrad_patch_eligible(const vd_wgrad_desc& d) {
+    if (d.T != 9 || (d.mode != VD_B_CONV3 && d.mode != VD_B_CONV3_UP)) return false;
+    if (d.OW != 16 && d.OW != 32) return false;
+    if (d.OH % (32 / d.OW) != 0 || d.NP != d.OH * d.OW) return false;
+    if (d.M < 64 || d.C < 64) return false;
+    if (d.tile != 0) return false;
+    return true;
+}
+
+static void wgrad_patch_plan(const vd_wgrad_desc& d, int& splits, int& ks_per) {
+    const int rows = 32 / d.OW;
+    const int ks_total = d.nb * (d.OH / rows);
+    const int base = vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
+    splits = d.splits;
+    if (splits <= 0) {  // ~3 workgroups per CU, at least 8 K-steps per split
+        splits = vd_cdiv(768, base);
+        const int max_splits = ks_total / 8 > 0 ? ks_total / 8 : 1;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    ks_per = vd_cdiv(ks_total, splits);
+    splits = vd_cdiv(ks_total, ks_per);
+}
+
 // dW[i] (+)= sum_z ws[z][i], fixed order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                           int64_t n4, int splits, int accumulate) {
@@ -917,6 +1110,11 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
 }
 
 static void wgrad_plan(const vd_wgrad_desc& d, int& tile, int& splits, int& kk_per) {
+    if (wgrad_patch_eligible(d)) {
+        tile = 4;
+        wgrad_patch_plan(d, splits, kk_per);
+        return;
+    }
     const int Ncols = d.C * d.T, Ktot = d.nb * d.NP;
     tile = d.tile;
     if (!tile) tile = (d.M > 64 && Ncols > 64) ? 1 : 3;
@@ -959,6 +1157,19 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (tile) {
+        case 4: {
+            dim3 grid(vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3, splits);
+            rc = 0;
+            if (d.OW == 32 && d.mode == VD_B_CONV3)
+                hipLaunchKernelGGL((wgrad_patch_kernel<32, 0>), grid, dim3(NT), 0, st, d, kk_per);
+            else if (d.OW == 32)
+                hipLaunchKernelGGL((wgrad_patch_kernel<32, 2>), grid, dim3(NT), 0, st, d, kk_per);
+            else if (d.mode == VD_B_CONV3)
+                hipLaunchKernelGGL((wgrad_patch_kernel<16, 0>), grid, dim3(NT), 0, st, d, kk_per);
+            else
+                hipLaunchKernelGGL((wgrad_patch_kernel<16, 2>), grid, dim3(NT), 0, st, d, kk_per);
+            break;
+        }
         case 1: rc = launch_wgrad_t<2, 2>(d, splits, kk_per, st); break;
         case 2: rc = launch_wgrad_t<1, 2>(d, splits, kk_per, st); break;
         case 3: rc = launch_wgrad_t<1, 1>(d, splits, kk_per, st); break;

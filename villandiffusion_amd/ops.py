@@ -179,9 +179,13 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     return dw2d
 
 
-def wgrad_ws_floats(M, Cc, T, nb, NP) -> int:
+def wgrad_ws_floats(M, Cc, T, nb, NP, OH=None, OW=None, mode=None) -> int:
+    """Workspace floats vd_conv_wgrad needs (square outputs assumed when OH/OW are omitted)."""
     d = WgradDesc()
-    d.M, d.C, d.T, d.nb, d.NP = M, Cc, T, nb, NP
+    if OH is None:
+        OH = OW = int(round(math.sqrt(NP)))
+    d.M, d.C, d.T, d.nb, d.NP, d.OH, d.OW = M, Cc, T, nb, NP, OH, OW
+    d.mode = (B_PLAIN if T == 1 else B_CONV3) if mode is None else mode
     return int(L.load().vd_conv_wgrad_ws_floats(C.byref(d)))
 
 

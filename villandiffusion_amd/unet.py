@@ -524,7 +524,8 @@ class UNet2DModel(nn.Module):
                 if name.endswith(".weight") and len(shape) == 4:
                     M, Cc, T = shape[0], shape[1], shape[2] * shape[3]
                     for hw in {(S >> k) ** 2 for k in range(len(self.config.block_out_channels))}:
-                        need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw))
+                        for md in ((B_PLAIN,) if T == 1 else (B_CONV3, B_CONV3_UP, B_CONV3_S2)):
+                            need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=md))
             for prefix, ch in self._qkv:
                 for hw in {(S >> k) ** 2 for k in range(len(self.config.block_out_channels))}:
                     need = max(need, ops.wgrad_ws_floats(3 * ch, ch, 1, B, hw), ops.wgrad_ws_floats(ch, ch, 1, B, hw))
