@@ -44,13 +44,15 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int = 16):
+def cpu_baseline(batch: int = 32):
     """The oracle (plain torch fp32 = what the reference's diffusers path executes on a CPU) on the host cores:
     fwd + bwd + clip(1.0) + Adam on a bounded sample of the same workload."""
     from oracle.loss_ref import LossFnRef, SDE_VP
     from oracle.schedulers_ref import DDPMSchedulerRef
     from oracle.unet_ref import UNet2DModelRef
-    ncpu = len(os.sched_getaffinity(0))          # cores this process may run on (cgroup/affinity), not the host total
+    # cores this process may run on, capped at 32: on the 256-thread GPU host oneDNN gets SLOWER beyond ~32 threads for
+    # these 32x32 convolutions (measured: 8 thr 0.28 s, 32 thr 0.39 s, 64 thr 0.79 s per B=8 fwd+bwd)
+    ncpu = min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(max(1, ncpu))
     torch.manual_seed(0)
     net = UNet2DModelRef()
@@ -70,7 +72,7 @@ def cpu_baseline(batch: int = 16):
         opt.step()
 
     step(2)                                     # warm-up (allocator, oneDNN primitives)
-    n_steps = 2
+    n_steps = 6
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step(batch)

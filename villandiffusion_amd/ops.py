@@ -83,7 +83,11 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     L.check(lib.vd_gemm(C.byref(d), _s()), "vd_gemm")
     e1.record()
     flops = 2.0 * M * N * K * (0.25 if b_mode == B_CONV3_DIL else 1.0)     # DIL: 3/4 of the taps are structural zeros
-    name = f"gemm_kernel<{_TILE_NAMES[lib.vd_gemm_tile(C.byref(d))]},{'ROW' if a_mode == A_ROW else 'COL'},{_B_NAMES[b_mode]}>"
+    tl = lib.vd_gemm_tile(C.byref(d))
+    if tl == 4:     # symbol names as rocprofv3 prints them
+        name = f"conv3_patch_kernel<{d.OW}, {0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)}>"
+    else:
+        name = f"gemm_kernel<{_TILE_NAMES[tl]},{'ROW' if a_mode == A_ROW else 'COL'},{_B_NAMES[b_mode]}>"
     _PROF.append((name, flops, e0, e1))
     return D
 
@@ -175,7 +179,11 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     e1.record()
     tl, sp = C.c_int32(0), C.c_int32(0)
     lib.vd_conv_wgrad_plan(C.byref(d), C.byref(tl), C.byref(sp))
-    _PROF.append((f"wgrad_kernel<{_TILE_NAMES[tl.value]},{_B_NAMES[mode]}>(+slab_reduce)", 2.0 * M * Cc * T * Bn * OH * OW, e0, e1))
+    if tl.value == 4:
+        name = f"wgrad_patch_kernel<{OW}, {0 if mode == B_CONV3 else 2}>(+slab_reduce)"
+    else:
+        name = f"wgrad_kernel<{_TILE_NAMES[tl.value]},{_B_NAMES[mode]}>(+slab_reduce)"
+    _PROF.append((name, 2.0 * M * Cc * T * Bn * OH * OW, e0, e1))
     return dw2d
 
 
