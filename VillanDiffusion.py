@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""MI355X-native driver with the reference's command line (VillanDiffusion.py:74-116), modes, config overlay rules,
+result-directory naming and JSON side files (args.json / config.json / sampling.json), so existing recipes
+(`--mode train --dataset CIFAR10 --batch 128 --epoch 50 --poison_rate 0.1 --trigger BOX_14 --target HAT
+--ckpt DDPM-CIFAR10-32 --fclip o -o --gpu 0`) run unchanged.  One process per GPU: multi-GPU = `torchrun --nproc-per-node N`.
+
+Not reproduced on purpose: module-level side effects at import (the reference parses argv and calls wandb.init on import,
+:323), swallowed training exceptions (:1189-1191), nn.DataParallel (:440).  `measure` (FID / SSIM) is a "next" row
+(SURVEY.md §8f.1): this driver samples and writes the PNGs + MSE-to-target, FID needs InceptionV3 weights (no network).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+from dataclasses import asdict, dataclass, field
+from typing import List, Optional
+
+MODE_TRAIN, MODE_RESUME, MODE_SAMPLING, MODE_MEASURE, MODE_TRAIN_MEASURE = "train", "resume", "sampling", "measure", "train+measure"
+TASK_GENERATE = "generate"
+DEFAULT = dict(project="Default", batch=512, eval_max_batch=256, epoch=50, learning_rate=None, clean_rate=1.0, poison_rate=0.007,
+               ext_poison_rate=0.0, trigger="SM_BOX", target="CORNER", dataset_load_mode="FIXED", solver_type="sde", sde_type="SDE-VP",
+               psi=1.0, ve_scale=1.0, vp_scale=1.0, gpu="0", ckpt="DEFAULT", overwrite=False, postfix="", fclip="o", save_image_epochs=20,
+               save_model_epochs=5, is_save_all_model_epochs=False, sample_ep=None, result="exp", dataset="CIFAR10", sched=None,
+               ddim_eta=None, infer_steps=1000, infer_start=0, inpaint_mul=1.0, task=TASK_GENERATE, R_trigger_only=False)
+# per-mode whitelists of options that may be overridden from the command line (reference :17-72)
+NOT_MODE_TRAIN = {"sample_ep"}
+NOT_MODE_TRAIN_MEASURE = {"sample_ep"}
+MODE_RESUME_OPTS = {"project", "mode", "gpu", "ckpt"}
+MODE_SAMPLING_OPTS = {"project", "mode", "eval_max_batch", "gpu", "fclip", "ckpt", "sample_ep", "sched", "ddim_eta", "infer_steps",
+                      "infer_start", "inpaint_mul", "task"}
+MODE_MEASURE_OPTS = MODE_SAMPLING_OPTS
+IGNORE_ARGS = {"overwrite", "R_trigger_only"}
+
+
+def parse_args(argv: Optional[List[str]] = None) -> argparse.Namespace:
+    p = argparse.ArgumentParser(description=globals()["__doc__"])
+    a = p.add_argument
+    a("--project", "-pj", type=str); a("--mode", "-m", type=str, required=True,
+                                       choices=[MODE_TRAIN, MODE_RESUME, MODE_SAMPLING, MODE_MEASURE, MODE_TRAIN_MEASURE])
+    a("--task", "-t", type=str); a("--dataset", "-ds", type=str)
+    a("--sched", "-sc", type=str); a("--ddim_eta", "-det", type=float); a("--infer_steps", "-is", type=int)
+    a("--infer_start", "-ist", type=int); a("--inpaint_mul", "-im", type=float)
+    a("--batch", "-b", type=int); a("--eval_max_batch", "-eb", type=int); a("--epoch", "-e", type=int)
+    a("--learning_rate", "-lr", type=float); a("--clean_rate", "-cr", type=float); a("--poison_rate", "-pr", type=float)
+    a("--ext_poison_rate", "-epr", type=float); a("--trigger", "-tr", type=str); a("--target", "-ta", type=str)
+    a("--dataset_load_mode", "-dlm", type=str); a("--solver_type", "-solt", type=str); a("--sde_type", "-sdet", type=str)
+    a("--psi", "-ps", type=float); a("--ve_scale", "-ves", type=float); a("--vp_scale", "-vps", type=float)
+    a("--gpu", "-g", type=str); a("--ckpt", "-c", type=str); a("--overwrite", "-o", action="store_true")
+    a("--R_trigger_only", "-rto", action="store_true"); a("--postfix", "-p", type=str); a("--fclip", "-fc", type=str, choices=["w", "o"])
+    a("--save_image_epochs", "-sie", type=int); a("--save_model_epochs", "-sme", type=int)
+    a("--is_save_all_model_epochs", "-isame", action="store_true"); a("--sample_ep", "-se", type=int); a("--result", "-res", type=str)
+    return p.parse_args(argv)
+
+
+@dataclass
+class TrainingConfig:
+    project: str = DEFAULT["project"]; batch: int = DEFAULT["batch"]; epoch: int = DEFAULT["epoch"]
+    eval_max_batch: int = DEFAULT["eval_max_batch"]; learning_rate: Optional[float] = None
+    clean_rate: float = 1.0; poison_rate: float = DEFAULT["poison_rate"]; ext_poison_rate: float = 0.0
+    trigger: str = DEFAULT["trigger"]; target: str = DEFAULT["target"]; dataset_load_mode: str = "FIXED"
+    solver_type: str = "sde"; sde_type: str = "SDE-VP"; psi: float = 1.0; ve_scale: float = 1.0; vp_scale: float = 1.0
+    gpu: str = "0"; ckpt: str = "DEFAULT"; overwrite: bool = False; postfix: str = ""; fclip: str = "o"
+    save_image_epochs: int = 20; save_model_epochs: int = 5; is_save_all_model_epochs: bool = False
+    sample_ep: Optional[int] = None; result: str = "exp"; dataset: str = "CIFAR10"; sched: Optional[str] = None
+    ddim_eta: Optional[float] = None; infer_steps: int = 1000; infer_start: int = 0; inpaint_mul: float = 1.0
+    task: str = TASK_GENERATE; R_trigger_only: bool = False; mode: str = MODE_TRAIN
+    eval_sample_n: int = 16; measure_sample_n: int = 16; batch_32: int = 128; batch_256: int = 64
+    gradient_accumulation_steps: int = 1; learning_rate_32_scratch: float = 2e-4; learning_rate_256_scratch: float = 2e-5
+    lr_warmup_steps: int = 500; mixed_precision: str = "no"; seed: int = 0; dataset_path: str = "datasets"
+    ckpt_dir: str = "ckpt"; data_ckpt_dir: str = "data.ckpt"; ep_model_dir: str = "epochs"
+    clip: bool = False; output_dir: str = ""; ckpt_path: Optional[str] = None; data_ckpt_path: Optional[str] = None
+    extra: dict = field(default_factory=dict)
+
+
+def naming_fn(c: TrainingConfig) -> str:
+    """reference :186-190."""
+    add_on = "" if c.sched is None else f"_{c.sched}"
+    add_on += f"_{c.postfix}" if c.postfix else ""
+    return (f"res_{c.ckpt}_{c.dataset}_ep{c.epoch}_{c.solver_type}_c{c.clean_rate}_p{c.poison_rate}_epr{c.ext_poison_rate}_"
+            f"{c.trigger}-{c.target}_psi{c.psi}_lr{c.learning_rate}_vp{c.vp_scale}_ve{c.ve_scale}{add_on}")
+
+
+def setup(args: argparse.Namespace) -> TrainingConfig:
+    """Config overlay of reference :200-321."""
+    cfg = TrainingConfig()
+    given = {k: v for k, v in vars(args).items() if v is not None and not (isinstance(v, bool) and v is False)}
+    mode = args.mode
+    if mode in (MODE_RESUME, MODE_SAMPLING, MODE_MEASURE):
+        base = os.path.join(given.get("result", cfg.result), given["ckpt"]) if not os.path.isdir(given.get("ckpt", "")) else given["ckpt"]
+        with open(os.path.join(base, "args.json")) as f:
+            for k, v in json.load(f).items():
+                if v is not None and hasattr(cfg, k):
+                    setattr(cfg, k, v)
+        allowed = {MODE_RESUME: MODE_RESUME_OPTS, MODE_SAMPLING: MODE_SAMPLING_OPTS, MODE_MEASURE: MODE_MEASURE_OPTS}[mode]
+        for k, v in given.items():
+            if k in allowed:
+                setattr(cfg, k, v)
+            elif k not in IGNORE_ARGS and k != "result":
+                raise NotImplementedError(f"Argument: {k}={v} isn't supported in mode: {mode}")
+        cfg.output_dir = base
+    else:
+        banned = NOT_MODE_TRAIN if mode == MODE_TRAIN else NOT_MODE_TRAIN_MEASURE
+        for k, v in given.items():
+            if k in banned:
+                raise NotImplementedError(f"Argument: {k}={v} isn't supported in mode: {mode}")
+            setattr(cfg, k, v)
+    cfg.mode = mode
+    cfg.clip = cfg.fclip == "w"                                        # :252-258
+    cfg.mixed_precision = "no"                                         # fp32 everywhere (reference: fp16 autocast for VP/LDM)
+    small = cfg.dataset in ("CIFAR10", "MNIST", "SYNTHETIC-CIFAR10", "CELEBA-HQ-LATENT")
+    bs = cfg.batch_32 if small else cfg.batch_256                      # :266-287
+    if cfg.learning_rate is None:
+        scratch = "DEFAULT" in cfg.ckpt
+        cfg.learning_rate = (2e-4 if small else 6e-5) if not scratch else (cfg.learning_rate_32_scratch if small else cfg.learning_rate_256_scratch)
+    if mode in (MODE_TRAIN, MODE_TRAIN_MEASURE):
+        if cfg.batch > bs:
+            cfg.batch = bs
+        if bs % cfg.batch != 0:
+            raise ValueError(f"batch size {cfg.batch} should be divisible to {bs} for dataset {cfg.dataset}")
+        cfg.gradient_accumulation_steps = bs // cfg.batch
+        cfg.output_dir = os.path.join(cfg.result, naming_fn(cfg))
+        if os.path.isdir(cfg.output_dir) and not cfg.overwrite:
+            raise ValueError(f"Overwrite the exist experiment result at {cfg.output_dir}. Please use -o to overwrite")
+        os.makedirs(cfg.output_dir, exist_ok=True)
+        with open(os.path.join(cfg.output_dir, "args.json"), "w") as f:
+            json.dump({k: v for k, v in vars(args).items()}, f, indent=4)
+        with open(os.path.join(cfg.output_dir, "config.json"), "w") as f:
+            json.dump(asdict(cfg), f, indent=4)
+    else:
+        with open(os.path.join(cfg.output_dir, f"{mode}.json"), "w") as f:
+            json.dump({k: v for k, v in vars(args).items()}, f, indent=4)
+    cfg.ckpt_path = os.path.join(cfg.output_dir, cfg.ckpt_dir)
+    cfg.data_ckpt_path = os.path.join(cfg.output_dir, cfg.data_ckpt_dir)
+    return cfg
+
+
+# ----------------------------------------------------------------------------------------------------------------- run
+def _dist():
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and not dist.is_initialized():
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def get_data_loader(cfg: TrainingConfig):
+    from dataset import DatasetLoader
+    vmin, vmax = (0.0, 1.0) if cfg.sde_type == "SDE-VE" else (-1.0, 1.0)          # reference :398-405
+    dsl = DatasetLoader(root=cfg.dataset_path, name=cfg.dataset, batch_size=cfg.batch, vmin=vmin, vmax=vmax)
+    dsl.set_poison(trigger_type=cfg.trigger, target_type=cfg.target, clean_rate=cfg.clean_rate, poison_rate=cfg.poison_rate,
+                   ext_poison_rate=cfg.ext_poison_rate)
+    return dsl.prepare_dataset(mode=cfg.dataset_load_mode, R_trigger_only=cfg.R_trigger_only)
+
+
+def make_grid(images, path):
+    """auto_grid of the reference (:586-613): uint8 = round(img*255), near-square PNG grid."""
+    import numpy as np
+    from PIL import Image
+    arr = (np.asarray(images) * 255).round().astype("uint8")
+    n = len(arr)
+    cols = int(np.ceil(np.sqrt(n)))
+    rows = int(np.ceil(n / cols))
+    h, w, c = arr.shape[1:]
+    grid = np.zeros((rows * h, cols * w, c), dtype="uint8")
+    for i, im in enumerate(arr):
+        grid[(i // cols) * h:(i // cols + 1) * h, (i % cols) * w:(i % cols + 1) * w] = im
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(grid.squeeze()).save(path)
+
+
+def sampling(cfg: TrainingConfig, file_name, pipeline, dsl):
+    """Clean + backdoor sample grids from the same seeded CPU noise (reference :570-676, TASK_GENERATE)."""
+    import torch
+    g = torch.Generator().manual_seed(cfg.seed)
+    n = cfg.eval_sample_n
+    noise = torch.randn((n, pipeline.unet.in_channels, pipeline.unet.sample_size, pipeline.unet.sample_size), generator=g)
+    tag = f"{file_name:04d}" if isinstance(file_name, int) else str(file_name)
+    kw = {} if cfg.ddim_eta is None else {"eta": cfg.ddim_eta}
+    for name, init in (("samples", noise), ("backdoor_samples", noise + pipeline.encode(dsl.trigger.unsqueeze(0)))):
+        res = pipeline(batch_size=n, generator=torch.Generator().manual_seed(cfg.seed), init=init, output_type=None,
+                       num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=True, **kw)
+        make_grid(res.images, os.path.join(cfg.output_dir, name, f"{tag}.png"))
+        make_grid(res.movie[0], os.path.join(cfg.output_dir, name, f"{tag}_sample_t0.png"))
+
+
+def checkpoint(cfg, trainer, pipeline, epoch, step):
+    import torch
+    os.makedirs(cfg.ckpt_path, exist_ok=True)
+    torch.save(trainer.state_dict(), os.path.join(cfg.ckpt_path, "trainer.pt"))
+    torch.save({"epoch": epoch, "step": step}, cfg.data_ckpt_path)
+    pipeline.save_pretrained(cfg.output_dir)
+
+
+def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
+    import torch
+    from loss import LossFn
+    from model import DiffuserModelSched
+    from villandiffusion_amd.trainer import Trainer
+    model, vae, noise_sched, get_pipeline = DiffuserModelSched.get_model_sched(
+        image_size=dsl.image_size, channels=dsl.channel, ckpt=cfg.ckpt, sde_type=cfg.sde_type, clip_sample=cfg.clip,
+        noise_sched_type=cfg.sched)
+    if world > 1:                                                      # identical replicas
+        torch.distributed.broadcast(model.flat_param, src=0)
+    loss_fn = LossFn(noise_sched=noise_sched, sde_type=cfg.sde_type, loss_type="l2", psi=cfg.psi, solver_type=cfg.solver_type,
+                     vp_scale=cfg.vp_scale, ve_scale=cfg.ve_scale)
+    n_batch = (len(dsl) + cfg.batch * world - 1) // (cfg.batch * world)
+    trainer = Trainer(model, loss_fn, lr=cfg.learning_rate, total_steps=n_batch * cfg.epoch, warmup_steps=cfg.lr_warmup_steps,
+                      grad_accum=cfg.gradient_accumulation_steps)
+    start_epoch, step = 0, 0
+    if cfg.mode == MODE_RESUME:
+        trainer.load_state_dict(torch.load(os.path.join(cfg.ckpt_path, "trainer.pt"), map_location=model.device))
+        d = torch.load(cfg.data_ckpt_path)
+        start_epoch, step = d["epoch"], d["step"]
+    pipeline = get_pipeline(None, model, vae, noise_sched)
+    if rank == 0:
+        sampling(cfg, 0, pipeline, dsl)
+    T = noise_sched.config.num_train_timesteps
+    for epoch in range(start_epoch, cfg.epoch):
+        loader = dsl.get_dataloader(rank=rank, world=world, epoch=epoch, full=False)
+        nb = len(loader)
+        for i, batch in enumerate(loader):
+            bs = batch["pixel_values"].shape[0]
+            t = torch.randint(0, T, (bs,), device=model.device).long()            # reference :1151
+            loss = trainer.train_step(batch, t, last_batch=(i == nb - 1))
+            step += 1
+            if rank == 0 and (step % 50 == 0 or i == nb - 1):
+                print(f"epoch {epoch} step {step} loss {float(loss):.5f} lr {trainer.lr:.3e}", flush=True)
+        if rank == 0:
+            if (epoch + 1) % cfg.save_image_epochs == 0 or epoch == cfg.epoch - 1:
+                sampling(cfg, epoch + 1, pipeline, dsl)
+            if (epoch + 1) % cfg.save_model_epochs == 0 or epoch == cfg.epoch - 1:
+                checkpoint(cfg, trainer, pipeline, epoch + 1, step)
+    return pipeline
+
+
+def main(argv: Optional[List[str]] = None):
+    args = parse_args(argv)
+    cfg = setup(args)
+    rank, world, _ = _dist()
+    dsl = get_data_loader(cfg)
+    if cfg.mode in (MODE_TRAIN, MODE_RESUME, MODE_TRAIN_MEASURE):
+        pipeline = train_loop(cfg, dsl, rank, world)
+    else:
+        from model import DiffuserModelSched
+        model, vae, noise_sched, get_pipeline = DiffuserModelSched.get_pretrained(ckpt=cfg.output_dir, clip_sample=cfg.clip,
+                                                                                  noise_sched_type=cfg.sched, sde_type=cfg.sde_type)
+        pipeline = get_pipeline(None, model, vae, noise_sched)
+    if cfg.mode == MODE_SAMPLING and rank == 0:
+        sampling(cfg, cfg.sample_ep if cfg.sample_ep is not None else "final", pipeline, dsl)
+    if cfg.mode in (MODE_MEASURE, MODE_TRAIN_MEASURE):
+        raise NotImplementedError("measure (FID / SSIM, reference :1017-1096) is a 'next' row: InceptionV3 weights need a network")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+"""Host side of the product path (no GPU): coefficient tables against the reference-generated fixtures, Backdoor /
+DatasetLoader partition logic, the model/scheduler factory surface and errors, the CLI's config overlay."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from villandiffusion_amd import dataset as D
+from villandiffusion_amd import loss as PL
+from villandiffusion_amd.model import DiffuserModelSched as DMS
+from villandiffusion_amd.schedulers import DDPMScheduler
+from villandiffusion_amd.unet import UNet2DModel
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TAB = np.load(os.path.join(G, "loss_tables.npz"))
+BOX = np.load(os.path.join(G, "backdoor_boxes.npz"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _VE:
+    def __init__(self):
+        ts = torch.linspace(1, 1e-5, 2000)
+        self.sigmas = torch.tensor([0.01 * (380.0 / 0.01) ** t for t in ts])
+
+
+def test_product_tables_bit_exact_vs_reference_fixtures():
+    for name, kw in (("vp_linear", {}), ("ldm_scaled_linear", dict(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear"))):
+        s = DDPMScheduler(**kw)
+        np.testing.assert_array_equal(PL.get_hs_vp(s.alphas, s.alphas_cumprod).numpy(), TAB[f"{name}/hs"])
+        for psi in (0.0, 0.5, 1.0):
+            for solver in ("sde", "ode"):
+                step, coef = PL.LossFn(s, "SDE-VP", psi=psi, solver_type=solver).get_R_step_coef()
+                np.testing.assert_array_equal(step.numpy(), TAB[f"{name}/psi{psi}/{solver}/step"])
+                np.testing.assert_array_equal(coef.numpy(), TAB[f"{name}/psi{psi}/{solver}/coef"])
+    for solver in ("sde", "ode"):
+        step, coef = PL.LossFn(_VE(), "SDE-VE", psi=0, solver_type=solver).get_R_step_coef()
+        np.testing.assert_array_equal(step.numpy(), TAB[f"ve/psi0/{solver}/step"])
+        np.testing.assert_array_equal(coef.numpy(), TAB[f"ve/psi0/{solver}/coef"])
+    with pytest.raises(NotImplementedError):
+        PL.LossFn(_VE(), "SDE-VE", psi=1).get_R_step_coef()
+    with pytest.raises(NotImplementedError):
+        PL.LossFn(DDPMScheduler(), "SDE-XX")
+    with pytest.raises(NotImplementedError):
+        PL.LossFn(DDPMScheduler(), "SDE-VP", solver_type="xyz").get_R_step_coef()
+    assert PL.LossFn(DDPMScheduler(), "SDE-VP").p_loss(None, torch.zeros(0, 3, 4, 4), torch.zeros(0, 3, 4, 4), torch.zeros(0)) == 0
+
+
+def test_product_backdoor_bit_exact_vs_reference_fixtures():
+    bd = D.Backdoor(root=ROOT)
+    n = 0
+    for key in BOX.files:
+        if not key.endswith("/trigger"):
+            continue
+        S_, v_, tt, _ = key.split("/")
+        vmin, vmax = (float(z) for z in v_[1:].split("_"))
+        trig = bd.get_trigger(tt, 3, int(S_[1:]), vmin, vmax)
+        np.testing.assert_array_equal(trig.numpy(), BOX[key])
+        for tg in ("CORNER", "NOSHIFT", "SHIFT"):
+            k2 = key[:-7] + f"target_{tg}"
+            if k2 in BOX.files:
+                np.testing.assert_array_equal(bd.get_target(tg, trig, vmin=vmin, vmax=vmax).numpy(), BOX[k2])
+                n += 1
+    assert n > 0
+    from oracle import backdoor_ref as BR
+    for tt in ("STOP_SIGN_14", "GLASSES"):
+        assert torch.equal(bd.get_trigger(tt, 3, 32), BR.get_trigger(ROOT, tt, 3, 32))
+    trig = bd.get_trigger("BOX_14", 3, 32)
+    for tg in ("HAT", "BWHAT", "CAT"):
+        assert torch.equal(bd.get_target(tg, trig), BR.get_target(ROOT, tg, trig))
+    with pytest.raises(ValueError):
+        bd.get_trigger("NOPE", 3, 32)
+    assert D.Backdoor.TRIGGER_SM_BOX_MED == "BOX_14" and D.Backdoor.TARGET_FEDORA_HAT == "HAT" and D.Backdoor.TARGET_HAT == "BWHAT"
+
+
+def _dsl(n=1000, **kw):
+    imgs = D.synthetic_images(n=n)
+    return D.DatasetLoader("X", root=ROOT, images=imgs, labels=np.arange(n) % 10, device="cpu", **kw)
+
+
+def test_dataset_partition_modes():
+    d = _dsl().set_poison("BOX_14", "CORNER", poison_rate=0.1).prepare_dataset("FIXED")
+    assert len(d) == 1000 and int((d._flags & 1).sum()) == 100 and len(set(d._index.tolist())) == 1000
+    assert d.num_batch == 2 and d.image_size == 32 and d.channel == 3
+    d = _dsl().set_poison("BOX_14", "CORNER", clean_rate=0.5, poison_rate=0.2).prepare_dataset("FLEX")
+    assert len(d) == 700 and int((d._flags & 1).sum()) == 200
+    d = _dsl().set_poison("BOX_14", "CORNER", poison_rate=1.0).prepare_dataset("FLEX")
+    assert len(d) == 2000 and int((d._flags & 1).sum()) == 1000
+    d = _dsl().set_poison("BOX_14", "CORNER", poison_rate=2.5, ext_poison_rate=0.1).prepare_dataset("EXTEND", ext_R_trigger_only=True)
+    assert len(d) == 900 + 100 + 2500 and int(((d._flags & 4) != 0).sum()) == 100
+    d = _dsl().set_poison("BOX_14", "CORNER", poison_rate=0.3).prepare_dataset("NONE")
+    assert len(d) == 1000 and int(d._flags.sum()) == 0
+    with pytest.raises(ValueError):
+        _dsl().set_poison("BOX_14", "CORNER", poison_rate=1.5).prepare_dataset("FIXED")
+    with pytest.raises(NotImplementedError):
+        _dsl().set_poison("BOX_14", "CORNER").prepare_dataset("WHAT")
+    with pytest.raises(ValueError):
+        D.DatasetLoader("X", images=D.synthetic_images(8), device="cpu").set_poison("BOX_14", "CORNER")
+    d = _dsl(label=3).set_poison("BOX_14", "CORNER", poison_rate=0.5).prepare_dataset("FIXED")
+    assert len(d) == 100 and set((d._labels[d._index]).tolist()) == {3}
+    x = torch.rand(2, 3, 32, 32) * 2 - 1
+    p = d.get_poisoned(x)
+    assert bool((p[:, :, 16:30, 16:30] == 0).all()) and bool((p[:, :, :16] == x[:, :, :16]).all())
+    m = d.get_inpainted_by_type(x, "INPAINT_BOX")
+    assert bool((m[:, :, 11:21, 11:21] == x.min()).all())
+
+
+def test_unet_structure_and_factory_errors():
+    net = UNet2DModel(device="cpu")
+    assert sum(p.numel() for p in net.parameters()) == 35746307
+    from oracle.unet_ref import UNet2DModelRef
+    ref = UNet2DModelRef()
+    assert list(sorted(net.state_dict())) == list(sorted(ref.state_dict()))
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in net.parameters())
+    assert net.Wt_all.shape == (4992, 512) and net.flat_param.numel() == net.flat_grad.numel()
+    with pytest.raises(NotImplementedError):
+        UNet2DModel(device="cpu", time_embedding_type="fourier")
+    with pytest.raises(NotImplementedError):
+        UNet2DModel(device="cpu", down_block_types=("SkipDownBlock2D",) * 4)
+    with pytest.raises(ValueError):
+        DMS.get_model_sched(ckpt=DMS.DDPM_32_DEFAULT)
+    with pytest.raises(NotImplementedError):
+        DMS.get_model_sched(image_size=32, channels=3, ckpt=DMS.DDPM_32_DEFAULT, noise_sched_type="NOPE-SCHED")
+    with pytest.raises(NotImplementedError):
+        DMS.get_model_sched(image_size=32, channels=3, ckpt=DMS.DDPM_32_DEFAULT, sde_type="SDE-XX")
+    with pytest.raises(FileNotFoundError):
+        DMS.get_pretrained(DMS.DDPM_CIFAR10_32)
+    assert DMS.HUB_IDS[DMS.DDPM_CIFAR10_32] == "google/ddpm-cifar10-32" and DMS.SDE_VP == "SDE-VP"
+    assert DMS.DPM_SOLVER_PP_O2_SCHED == "DPM_SOLVER_PP_O2-SCHED" and DMS.UNIPC_SCHED == "UNIPC-SCHED"
+
+
+def test_pretrained_directory_roundtrip(tmp_path):
+    from villandiffusion_amd.pipelines import DDPMPipeline
+    net = UNet2DModel(device="cpu")
+    net.reset_parameters(seed=3)
+    pipe = DDPMPipeline(net, DDPMScheduler(clip_sample=False))
+    pipe.save_pretrained(str(tmp_path / "ck"))
+    idx = json.load(open(tmp_path / "ck" / "model_index.json"))
+    assert idx["unet"] == ["diffusers", "UNet2DModel"] and idx["scheduler"] == ["diffusers", "DDPMScheduler"]
+    assert os.path.exists(tmp_path / "ck" / "unet" / "diffusion_pytorch_model.safetensors")
+    pipe2 = DDPMPipeline.from_pretrained(str(tmp_path / "ck"))
+    assert torch.equal(pipe2.unet.flat_param.cpu(), net.flat_param.cpu()) and pipe2.scheduler.config.clip_sample is False
+    m, vae, sched, gp = DMS.get_pretrained(str(tmp_path / "ck"), clip_sample=True, noise_sched_type=DMS.DDIM_SCHED)
+    assert vae is None and sched.config.clip_sample is True and type(sched).__name__ == "DDIMScheduler"
+    assert type(gp(None, m, None, sched)).__name__ == "DDIMPipeline"
+
+
+def test_cli_config_overlay(tmp_path):
+    import VillanDiffusion as V
+    res = str(tmp_path / "exp")
+    argv = ["--project", "default", "--mode", "train", "--dataset", "CIFAR10", "--batch", "4", "--epoch", "1", "--poison_rate", "0.1",
+            "--trigger", "BOX_14", "--target", "HAT", "--ckpt", "DDPM-CIFAR10-32", "--fclip", "o", "-o", "--gpu", "0", "--result", res,
+            "--sched", "DDPM-SCHED"]
+    cfg = V.setup(V.parse_args(argv))
+    assert cfg.gradient_accumulation_steps == 32 and cfg.learning_rate == 2e-4 and cfg.clip is False
+    assert os.path.basename(cfg.output_dir) == ("res_DDPM-CIFAR10-32_CIFAR10_ep1_sde_c1.0_p0.1_epr0.0_BOX_14-HAT_psi1.0_lr0.0002_vp1.0_ve1.0_DDPM-SCHED")
+    assert json.load(open(os.path.join(cfg.output_dir, "args.json")))["trigger"] == "BOX_14"
+    assert os.path.exists(os.path.join(cfg.output_dir, "config.json"))
+    with pytest.raises(ValueError):                    # existing directory without -o
+        V.setup(V.parse_args([a for a in argv if a != "-o"]))
+    with pytest.raises(ValueError):                    # batch must divide 128
+        V.setup(V.parse_args([("48" if a == "4" else a) for a in argv]))
+    with pytest.raises(NotImplementedError):           # option outside the sampling whitelist
+        V.setup(V.parse_args(["--mode", "sampling", "--ckpt", cfg.output_dir, "--epoch", "3"]))
+    c2 = V.setup(V.parse_args(["--mode", "sampling", "--ckpt", cfg.output_dir, "--sched", "DDIM-SCHED", "--infer_steps", "50", "--fclip", "w"]))
+    assert c2.trigger == "BOX_14" and c2.sched == "DDIM-SCHED" and c2.infer_steps == 50 and c2.clip is True
+    assert os.path.exists(os.path.join(cfg.output_dir, "sampling.json"))
+    c3 = V.setup(V.parse_args(argv[:-2] + ["--ckpt", "DDPM-32-DEFAULT", "--dataset", "CELEBA-HQ"][0:0] + ["--sched", "DDPM-SCHED", "-o"]))
+    assert c3.batch == 4

@@ -189,7 +189,10 @@ class DatasetLoader:
         self._label = None if label is None else (list(label) if isinstance(label, (list, tuple)) else [label])
         self._vmin, self._vmax = float(vmin), float(vmax)
         self._batch_size, self._shuffle, self._seed = batch_size, shuffle, seed
-        self._dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if device is not None:
+            self._dev = torch.device(device)
+        else:
+            self._dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         if images is not None:
             self._images, self._labels = images, labels
         elif name == self.SYNTHETIC_CIFAR10:

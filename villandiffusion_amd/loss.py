@@ -11,7 +11,6 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
-import numpy as np
 import torch
 
 from . import ops
@@ -22,41 +21,38 @@ SDE_VP, SDE_VE, SDE_LDM = "SDE-VP", "SDE-VE", "SDE-LDM"
 # ---------------------------------------------------------------------------------------------- coefficient tables
 def get_hs_vp(alphas: torch.Tensor, alphas_cumprod: torch.Tensor) -> torch.Tensor:
     """h_0 = sqrt(1-abar_0); res_i = sqrt(a_i)(h_{i-1}+res_{i-1}); h_i = sqrt(1-abar_i) - res_i  (loss.py:551-559).
-    Sequential fp32 recurrence, evaluated with numpy float32 scalars (IEEE-identical to the reference's 0-d tensors)."""
-    a = alphas.detach().cpu().numpy().astype(np.float32)
-    ac = alphas_cumprod.detach().cpu().numpy().astype(np.float32)
-    one = np.float32(1.0)
-    h = np.empty(len(a), dtype=np.float32)
-    h[0] = np.sqrt(one - ac[0])
-    res = np.float32(0.0)
+    Sequential recurrence on fp32 0-d CPU tensors -- deliberately the SAME torch scalar kernels the reference runs
+    (torch's CPU `x ** 0.5` is not always the correctly rounded sqrt, so e.g. numpy float32 would differ in the last bit).
+    Runs once per LossFn (the reference caches it too, loss.py:872-874)."""
+    a, ac = alphas.detach().float().cpu(), alphas_cumprod.detach().float().cpu()
+    h = [(1 - ac[0]) ** 0.5]
+    res = torch.zeros(())
     for i in range(1, len(a)):
-        res = np.sqrt(a[i]) * (h[i - 1] + res)
-        h[i] = np.sqrt(one - ac[i]) - res
-    return torch.from_numpy(h)
+        res = (a[i] ** 0.5) * (h[i - 1] + res)
+        h.append((1 - ac[i]) ** 0.5 - res)
+    return torch.stack(h)
 
 
 def get_ws_ve(sigmas: torch.Tensor) -> torch.Tensor:
     """loss.py:466-474."""
-    s = sigmas.detach().cpu().numpy().astype(np.float32)
-    w = np.empty(len(s), dtype=np.float32)
-    w[0] = s[0]
-    res = np.float32(0.0)
-    for i in range(1, len(s)):
-        res = w[i - 1] * w[i - 1] + res
-        w[i] = np.sqrt(s[i] * s[i] - res)
-    return torch.from_numpy(w)
+    s_ = sigmas.detach().float().cpu()
+    w = [s_[0]]
+    res = torch.zeros(())
+    for i in range(1, len(s_)):
+        res = w[i - 1] ** 2 + res
+        w.append((s_[i] ** 2 - res) ** 0.5)
+    return torch.stack(w)
 
 
 def get_hs_ve(rhos_hat: torch.Tensor) -> torch.Tensor:
     """loss.py:476-484."""
-    r = rhos_hat.detach().cpu().numpy().astype(np.float32)
-    h = np.empty(len(r), dtype=np.float32)
-    h[0] = r[0]
-    res = np.float32(0.0)
+    r = rhos_hat.detach().float().cpu()
+    h = [r[0]]
+    res = torch.zeros(())
     for i in range(1, len(r)):
         res = h[i - 1] + res
-        h[i] = r[i] - res
-    return torch.from_numpy(h)
+        h.append(r[i] - res)
+    return torch.stack(h)
 
 
 def _solver(step, coef, solver_type):

@@ -309,7 +309,12 @@ class UNet2DModel(nn.Module):
             center_input_sample=center_input_sample, mid_block_scale_factor=mid_block_scale_factor)
         self.in_channels, self.out_channels, self.sample_size = in_channels, out_channels, sample_size
         self.groups, self.eps = norm_num_groups, norm_eps
-        self._dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if device is not None:
+            self._dev = torch.device(device)
+        elif torch.cuda.is_available():
+            self._dev = torch.device("cuda", torch.cuda.current_device())
+        else:       # structure-only use (state-dict surgery, tests): any compute call still fails loudly in lib.require_device()
+            self._dev = torch.device("cpu")
 
         # ---- declare parameters (order = layout in the flat buffer) ----
         self._decls: List[Tuple[str, Tuple[int, ...], dict]] = []
