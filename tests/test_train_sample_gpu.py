@@ -1,0 +1,162 @@
+"""End-to-end parity on the GPU against the CPU oracle: optimiser steps (accumulate / clip / Adam / LR), full sampling
+loops for every native sampler (north_star: denoised images within 1e-3 relative, timestep indices bit-exact), the GPU
+data path, and the drop-in CLI."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import backdoor_ref as BR  # noqa: E402
+from oracle import schedulers_ref as R  # noqa: E402
+from oracle.loss_ref import LossFnRef, SDE_VP  # noqa: E402
+from oracle.unet_ref import UNet2DModelRef  # noqa: E402
+from villandiffusion_amd import schedulers as S  # noqa: E402
+from villandiffusion_amd.dataset import DatasetLoader, synthetic_images  # noqa: E402
+from villandiffusion_amd.loss import LossFn  # noqa: E402
+from villandiffusion_amd.pipelines import DDIMPipeline, DDPMPipeline, PNDMPipeline  # noqa: E402
+from villandiffusion_amd.trainer import Trainer  # noqa: E402
+from villandiffusion_amd.unet import UNet2DModel  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def nets():
+    torch.manual_seed(0)
+    ref = UNet2DModelRef()
+    net = UNet2DModel()
+    net.load_state_dict(ref.state_dict())
+    return ref, net
+
+
+def test_training_steps_match_oracle(nets):
+    """3 optimiser steps with gradient accumulation 2 (6 micro-batches of 4): loss per micro-step, LR, parameters."""
+    ref, _ = nets
+    import copy
+    ref = copy.deepcopy(ref)
+    net = UNet2DModel()
+    net.load_state_dict(ref.state_dict())
+    G, lr, warm, total = 2, 2e-4, 2, 10
+    opt = torch.optim.Adam(ref.parameters(), lr=lr)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: R.cosine_with_warmup_lambda(s, warm, total))
+    lf_ref = LossFnRef(R.DDPMSchedulerRef(), SDE_VP, psi=0.5, solver_type="ode")
+    lf = LossFn(S.DDPMScheduler(), "SDE-VP", psi=0.5, solver_type="ode")
+    tr = Trainer(net, lf, lr=lr, total_steps=total, warmup_steps=warm, grad_accum=G)
+    g = torch.Generator().manual_seed(7)
+    for micro in range(6):
+        x0 = torch.rand(4, 3, 32, 32, generator=g) * 2 - 1
+        Rr = torch.rand(4, 3, 32, 32, generator=g) * 2 - 1
+        Rr[:2] = 0
+        eps = torch.randn(4, 3, 32, 32, generator=g)
+        t = torch.randint(0, 1000, (4,), generator=g)
+        l_ref = lf_ref.p_loss(ref, x0, Rr, t, noise=eps)
+        (l_ref / G).backward()
+        lr_now = tr.lr
+        l = tr.train_step({"target": x0.cuda(), "pixel_values": Rr.cuda()}, t.cuda(), noise=eps.cuda())
+        assert abs(float(l) - float(l_ref)) <= 2e-5 * abs(float(l_ref)), (micro, float(l), float(l_ref))
+        if (micro + 1) % G == 0:
+            assert abs(lr_now - opt.param_groups[0]["lr"]) < 1e-12
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+    worst = max(rel(net.state_dict()[k], v) for k, v in ref.state_dict().items())
+    print(f"[parity] parameters after 3 optimiser steps: worst rel_err {worst:.3e}")
+    assert worst < 1e-3      # early Adam steps are ~lr*sign(g): elements with rounding-level gradients may differ by O(lr)
+    assert tr.sched_step == 3 and tr.opt.step_count == 3
+
+
+SAMPLERS = [
+    ("DDPM-20", lambda: S.DDPMScheduler(clip_sample=False), lambda: R.DDPMSchedulerRef(clip_sample=False), DDPMPipeline, 20),
+    ("DDPM-clip-20", lambda: S.DDPMScheduler(clip_sample=True), lambda: R.DDPMSchedulerRef(clip_sample=True), DDPMPipeline, 20),
+    ("DDIM-50", lambda: S.DDIMScheduler(clip_sample=False), lambda: R.DDIMSchedulerRef(clip_sample=False), DDIMPipeline, 50),
+    ("DPM_PP_O2-20", lambda: S.DPMSolverMultistepScheduler(), lambda: R.DPMSolverMultistepSchedulerRef(), PNDMPipeline, 20),
+    ("DPM_O3-20", lambda: S.DPMSolverMultistepScheduler(solver_order=3, algorithm_type="dpmsolver"),
+     lambda: R.DPMSolverMultistepSchedulerRef(solver_order=3, algorithm_type="dpmsolver"), PNDMPipeline, 20),
+    ("UNIPC-20", lambda: S.UniPCMultistepScheduler(), lambda: R.UniPCMultistepSchedulerRef(), PNDMPipeline, 20),
+]
+
+
+@pytest.mark.parametrize("name,mk,mkref,pipe_cls,n", SAMPLERS)
+def test_sampling_loop_matches_oracle(nets, name, mk, mkref, pipe_cls, n):
+    ref, net = nets
+    init = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    sched, sref = mk(), mkref()
+    pipe = pipe_cls(net, sched)
+    out = pipe(batch_size=2, generator=torch.Generator().manual_seed(5), init=init, num_inference_steps=n, output_type=None,
+               save_every_step=True)
+    with torch.no_grad():
+        x_ref = R.sample_loop(ref, sref, init.clone(), n, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(sched.timesteps, sref.timesteps) and sched.timesteps.dtype == torch.int64
+    img_ref = (x_ref / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    err = float(np.abs(out.images - img_ref).max() / np.abs(img_ref).max())
+    print(f"[parity] {name}: denoised image max-rel-err {err:.3e}")
+    assert out.images.shape == (2, 32, 32, 3) and out.images.dtype == np.float32
+    assert err <= 1e-3
+    assert len(out.movie) == n + 1 and np.allclose(out.movie[0], (init / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy())
+    assert np.array_equal(out.movie[-1], out.images)
+
+
+def test_start_from_and_device_rng(nets):
+    _, net = nets
+    sched = S.DDPMScheduler(clip_sample=False)
+    pipe = DDPMPipeline(net, sched)
+    init = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    sched.device_rng_seed = 42
+    a = pipe(batch_size=2, init=init, num_inference_steps=1000, start_from=990, return_tensor=True)
+    sched._rng_offset = 0
+    b = pipe(batch_size=2, init=init, num_inference_steps=1000, start_from=990, return_tensor=True)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())          # in-kernel Philox stream is reproducible
+    sched.device_rng_seed = None
+
+
+def test_gpu_data_path_matches_oracle():
+    imgs = synthetic_images(n=512)
+    dsl = DatasetLoader("X", root=ROOT, images=imgs, batch_size=64, seed=3)
+    dsl.set_poison("STOP_SIGN_14", "HAT", poison_rate=0.25).prepare_dataset("FIXED")
+    ids = torch.arange(300, 428)
+    flips = (torch.arange(128) % 3 == 0)
+    batch = dsl.make_batch(ids, flip_bits=flips, full=True)
+    pos = ids.numpy()
+    pv_ref, tg_ref = BR.poison_batch_ref(torch.from_numpy(imgs[dsl._index[pos]]), torch.from_numpy(dsl._flags[pos] & 1), dsl.trigger,
+                                         dsl.target, -1.0, 1.0, flip=flips.to(torch.uint8))
+    assert torch.equal(batch["pixel_values"].cpu(), pv_ref) and torch.equal(batch["target"].cpu(), tg_ref)
+    assert set(batch.keys()) == {"image", "pixel_values", "pixel_values_trigger", "trigger", "target", "label", "is_clean"}
+    assert int((~batch["is_clean"]).sum()) == int((dsl._flags[pos] & 1).sum()) > 0
+    n = sum(b["pixel_values"].shape[0] for b in dsl.get_dataloader(full=False))
+    assert n == 512
+
+
+def test_cli_train_and_sampling_end_to_end(tmp_path):
+    """BASELINE config #1 plumbing at toy size: --batch 4 style accumulation is covered above; here the drop-in CLI runs a
+    1-epoch fine-tune on the synthetic set and re-samples from the saved diffusers-layout checkpoint."""
+    res = str(tmp_path / "exp")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    code = ("import sys, numpy as np; sys.argv=['VillanDiffusion.py']+%r; import villandiffusion_amd.dataset as D;"
+            "D.synthetic_images=(lambda f: (lambda n=60000, **k: f(n=256, **k)))(D.synthetic_images);"
+            "import VillanDiffusion as V; V.TrainingConfig.eval_sample_n=4; V.main()")
+    argv = ["--mode", "train", "--dataset", "SYNTHETIC-CIFAR10", "--batch", "64", "--epoch", "1", "--poison_rate", "0.1", "--trigger", "BOX_14",
+            "--target", "HAT", "--ckpt", "DDPM-32-DEFAULT", "--fclip", "o", "-o", "--result", res, "--sched", "DDIM-SCHED", "--infer_steps", "5",
+            "--save_image_epochs", "1", "--save_model_epochs", "1"]
+    out = subprocess.run([sys.executable, "-c", code % (argv,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    run = os.path.join(res, os.listdir(res)[0])
+    for f in ("args.json", "config.json", "model_index.json", "unet/config.json", "unet/diffusion_pytorch_model.safetensors",
+              "scheduler/scheduler_config.json", "samples/0000.png", "samples/0001.png", "backdoor_samples/0001.png", "ckpt/trainer.pt", "data.ckpt"):
+        assert os.path.exists(os.path.join(run, f)), f
+    assert json.load(open(os.path.join(run, "config.json")))["gradient_accumulation_steps"] == 2
+    argv2 = ["--mode", "sampling", "--ckpt", run, "--sched", "DPM_SOLVER_PP_O2-SCHED", "--infer_steps", "5"]
+    out = subprocess.run([sys.executable, "-c", code % (argv2,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert os.path.exists(os.path.join(run, "samples", "final.png")) and os.path.exists(os.path.join(run, "sampling.json"))
