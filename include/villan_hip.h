@@ -75,9 +75,13 @@ typedef struct vd_gemm_desc {
     int64_t ldb, b_bstride;
     int64_t ldd, d_bstride;
     int64_t res_bstride, rowadd_bstride;
+    float* ws;               /* split-K workspace (vd_gemm_ws_floats() floats), nullable when that is 0        */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
+/* Floats of split-K workspace vd_gemm needs for this problem (0 for most shapes; the patch-staged convolution splits
+ * its channel loop over workgroups for the 8x8 / 4x4 layers, partial slabs are reduced in fixed order). */
+int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
 /* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4: patch-staged 3x3
  * convolution kernel (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);

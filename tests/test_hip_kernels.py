@@ -51,6 +51,9 @@ CONV_CASES = [
     # tile=0 -> the patch-staged kernel where eligible (C % 8 == 0, W in {16, 32}, M >= 64)
     (4, 128, 128, 32, B_CONV3, 0), (2, 256, 256, 16, B_CONV3, 0), (2, 384, 128, 32, B_CONV3, 0), (3, 512, 256, 16, B_CONV3, 0),
     (2, 128, 192, 16, B_CONV3, 0), (2, 256, 256, 16, B_CONV3_UP, 0), (3, 64, 72, 32, B_CONV3, 0),
+    # 8x8 / 4x4: multi-image tiles + deterministic split-K over the channel loop (ragged batch: 5 images, tile = 2 / 8 images)
+    (5, 256, 256, 8, B_CONV3, 0), (16, 512, 256, 4, B_CONV3, 0), (5, 256, 128, 4, B_CONV3, 0), (3, 256, 256, 4, B_CONV3_UP, 0),
+    (128, 256, 256, 4, B_CONV3, 0),
 ]
 
 
@@ -75,6 +78,7 @@ def test_conv3x3_forward_epilogue(B, Cin, Cout, H, mode, tile):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,mode", [(2, 128, 256, 16, B_CONV3), (4, 256, 256, 4, B_CONV3), (2, 64, 64, 16, B_CONV3_S2),
+                                               (9, 256, 256, 8, B_CONV3), (20, 128, 256, 4, B_CONV3),
                                                (2, 128, 128, 32, B_CONV3), (2, 200, 128, 32, B_CONV3), (2, 128, 128, 16, B_CONV3_UP),
                                                (2, 64, 96, 8, B_CONV3_UP), (2, 3, 128, 32, B_CONV3), (2, 128, 3, 32, B_CONV3)])
 def test_conv3x3_backward(B, Cin, Cout, H, mode):

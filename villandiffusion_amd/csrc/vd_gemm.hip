@@ -418,14 +418,16 @@ constexpr int CK = 8;
 constexpr int KSTEP = CK * 9;
 
 template <int W, int MODE>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution)
-__global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d) {
+__global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
     constexpr int WM = 2, WN = 2, BM = 128;
-    constexpr int TR = 128 / W;              // output rows per tile
-    constexpr int PW = W + 2, PR = TR + 2;   // halo patch
-    constexpr int PLANE = PR * PW;
+    constexpr int IMGS = (W * W >= 128) ? 1 : 128 / (W * W);   // whole images per tile for the 8x8 / 4x4 layers
+    constexpr int TR = (IMGS == 1) ? 128 / W : W;               // output rows per image in the tile
+    constexpr int PW = W + 2, PR = TR + 2;                      // halo patch per image
+    constexpr int PIMG = PR * PW;
+    constexpr int PLANE = IMGS * PIMG;                          // patch floats per channel
     constexpr int LDA_ = BM + 1;
-    constexpr int A_F4 = BM * KSTEP / 4 / NT;            // 9 float4 per thread
-    constexpr int P_EL = (CK * PLANE + NT - 1) / NT;     // patch elements per thread (7 / 6)
+    constexpr int A_F4 = BM * KSTEP / 4 / NT;                   // 9 float4 per thread
+    constexpr int P_EL = (CK * PLANE + NT - 1) / NT;            // patch elements per thread
     __shared__ float As[KSTEP * LDA_];
     __shared__ float Ps[CK * PLANE];
 
@@ -438,12 +440,19 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
     }
     const int tm = bid % tiles_m, tn = bid / tiles_m;
     const int m0 = tm * BM, n0 = tn * 128;
-    const int tiles_per_img = d.NP / 128;
-    const int b = tn / tiles_per_img;
-    const int y0 = (tn - b * tiles_per_img) * TR;        // first output row of this tile
+    int b0, y0;
+    if (IMGS == 1) {
+        const int tiles_per_img = d.NP / 128;
+        b0 = tn / tiles_per_img;
+        y0 = (tn - b0 * tiles_per_img) * TR;                    // first output row of this tile
+    } else {
+        b0 = tn * IMGS;
+        y0 = 0;
+    }
     const float* __restrict__ Ap = d.A;
-    const float* __restrict__ Xb = d.B + (int64_t)b * d.b_bstride;
-    const int HWs = d.H * d.W;                           // source plane (half resolution for MODE 2)
+    const float* __restrict__ Xb = d.B + (int64_t)b0 * d.b_bstride;
+    const int HWs = d.H * d.W;                                  // source plane (half resolution for MODE 2)
+    const int nb_total = d.N / d.NP;
 
     // patch element -> source offset (channel 0 of the K-step), fixed for the whole tile
     int poff[P_EL];
@@ -452,9 +461,10 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
     for (int i = 0; i < P_EL; ++i) {
         const int e = tid + i * NT;
         const int c = e / PLANE, rem = e - c * PLANE;
-        const int py = rem / PW, px = rem - py * PW;
-        int iy = y0 + py - 1, ix = px - 1;               // coordinates in the (virtual, for MODE 2: upsampled) input
-        bool ok = e < CK * PLANE;
+        const int img = rem / PIMG, rem2 = rem - img * PIMG;
+        const int py = rem2 / PW, px = rem2 - py * PW;
+        int iy = y0 + py - 1, ix = px - 1;                      // coordinates in the (virtual, MODE 2: upsampled) input
+        bool ok = e < CK * PLANE && (b0 + img) < nb_total;
         if (MODE == 2) {
             ok = ok && (unsigned)iy < (unsigned)(2 * d.H) && (unsigned)ix < (unsigned)(2 * d.W);
             iy >>= 1;
@@ -462,13 +472,13 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
         } else {
             ok = ok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
         }
-        poff[i] = ok ? (c * HWs + iy * d.W + ix) : 0;
+        poff[i] = ok ? (int)(img * d.b_bstride) + c * HWs + iy * d.W + ix : 0;
         pmask |= (ok ? 1u : 0u) << i;
     }
 
     f32x4 ra[A_F4];
     float rp[P_EL];
-    auto load_stage = [&](int c0) {                      // c0: first input channel of the K-step
+    auto load_stage = [&](int c0) {                             // c0: first input channel of the K-step
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int idx = tid + i * NT;
@@ -510,17 +520,20 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
     const float* __restrict__ p_base[WN];
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
-        const int q = (wn * WN + ni) * 32 + (lane & 31);     // pixel within the tile
-        const int ty = q / W, x = q - ty * W;
-        p_base[ni] = Ps + h * PLANE + ty * PW + x;
+        const int q = (wn * WN + ni) * 32 + (lane & 31);        // pixel within the tile
+        const int img = q / (TR * W), r2 = q - img * (TR * W);
+        const int ty = r2 / W, x = r2 - ty * W;
+        p_base[ni] = Ps + h * PLANE + img * PIMG + ty * PW + x;
     }
 
     const int nsteps = d.C / CK;
-    load_stage(0);
+    const int ks_begin = blockIdx.y * ksteps_per_split;
+    const int ks_end = min(nsteps, ks_begin + ksteps_per_split);
+    load_stage(ks_begin * CK);
     store_stage();
     __syncthreads();
-    for (int ks = 0; ks < nsteps; ++ks) {
-        const bool more = ks + 1 < nsteps;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const bool more = ks + 1 < ks_end;
         if (more) load_stage((ks + 1) * CK);
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
@@ -544,32 +557,99 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
         if (more) store_stage();
         __syncthreads();
     }
-    gemm_epilogue<WM, WN>(d, acc, m0, n0, wm, wn, lane, h);
+    if (gridDim.y == 1) {
+        gemm_epilogue<WM, WN>(d, acc, m0, n0, wm, wn, lane, h);
+        return;
+    }
+    // split-K: raw partial tile into slab z = blockIdx.y of ws[z][M][N]; splitk_epilogue_kernel finishes the job
+    float* __restrict__ slab = d.ws + (int64_t)blockIdx.y * d.M * d.N;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+        if (n >= d.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m < d.M) slab[(int64_t)m * d.N + n] = acc[mi][ni][v];
+            }
+    }
+}
+
+// D = alpha * sum_z ws[z] (fixed order) + bias + rowadd + residual (+ D): the epilogue of a split-K launch.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vd_gemm_desc d, int splits) {
+    const int64_t total = (int64_t)d.M * d.N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / d.N), n = (int)(i - (int64_t)m * d.N);
+        float s = d.ws[i];
+        for (int z = 1; z < splits; ++z) s += d.ws[(int64_t)z * total + i];
+        const int b = n / d.NP, p = n - b * d.NP;
+        float val = d.alpha * s;
+        if (d.bias) val += d.bias[d.bias_on_n ? n : m];
+        if (d.rowadd) val += d.rowadd[(int64_t)b * d.rowadd_bstride + m];
+        if (d.residual) val += d.residual[(int64_t)b * d.res_bstride + (int64_t)m * d.ldd + p];
+        const int64_t off = (int64_t)b * d.d_bstride + (int64_t)m * d.ldd + p;
+        if (d.accumulate) val += d.D[off];
+        d.D[off] = val;
+    }
 }
 
 // Eligibility of the patch-staged kernel for a vd_gemm problem.
 static bool patch_eligible(const vd_gemm_desc& d) {
     if (d.a_mode != VD_A_ROW || d.a_bstride != 0) return false;
     if (d.b_mode != VD_B_CONV3 && d.b_mode != VD_B_CONV3_T && d.b_mode != VD_B_CONV3_UP) return false;
-    if (d.OW != 16 && d.OW != 32) return false;
-    if (d.C % CK != 0 || d.NP % 128 != 0 || d.OH * d.OW != d.NP) return false;
+    if (d.OW != 4 && d.OW != 8 && d.OW != 16 && d.OW != 32) return false;
+    if (d.OH != d.OW && d.OW < 16) return false;
+    if (d.C % CK != 0 || d.OH * d.OW != d.NP || d.d_trans) return false;
+    if (d.NP >= 128 ? (d.NP % 128 != 0) : (128 % d.NP != 0)) return false;
     if (d.K != d.C * 9 || (d.lda & 3) != 0 || (((uintptr_t)d.A) & 15) != 0) return false;
     if (d.debug != 0 || d.tile != 0) return false;
+    if (d.b_mode == VD_B_CONV3_UP && d.OW == 4) return false;
     return d.M >= 64;
 }
 
+// Split the channel loop over workgroups when the tile grid alone cannot fill the chip (8x8 / 4x4 layers).
+static void patch_plan(const vd_gemm_desc& d, int& splits, int& ks_per) {
+    const int base = vd_cdiv(d.M, 128) * vd_cdiv(d.N, 128);
+    const int nsteps = d.C / CK;
+    splits = 1;
+    if (base < 256) {
+        splits = vd_cdiv(512, base);
+        const int max_splits = nsteps / 4 > 0 ? nsteps / 4 : 1;      // >= 4 K-steps per split
+        if (splits > max_splits) splits = max_splits;
+    }
+    ks_per = vd_cdiv(nsteps, splits);
+    splits = vd_cdiv(nsteps, ks_per);
+}
+
 static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
-    const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
+    int splits, ks_per;
+    patch_plan(d, splits, ks_per);
+    if (splits > 1 && d.ws == nullptr) {
+        vd_set_error("vd_gemm: split-K workspace required (%d splits): query vd_gemm_ws_floats()", splits);
+        return VD_EINVAL;
+    }
+    dim3 grid(vd_cdiv(d.M, 128) * vd_cdiv(d.N, 128), splits);
     const int mode = d.b_mode == VD_B_CONV3 ? 0 : (d.b_mode == VD_B_CONV3_T ? 1 : 2);
-#define VD_PATCH_CASE(WW, MD)                                                                        \
-    if (d.OW == WW && mode == MD) {                                                                  \
-        hipLaunchKernelGGL((conv3_patch_kernel<WW, MD>), dim3(grid), dim3(NT), 0, st, d);            \
-        return 0;                                                                                    \
+    bool done = false;
+#define VD_PATCH_CASE(WW, MD)                                                                            \
+    if (!done && d.OW == WW && mode == MD) {                                                             \
+        hipLaunchKernelGGL((conv3_patch_kernel<WW, MD>), grid, dim3(NT), 0, st, d, ks_per);              \
+        done = true;                                                                                     \
     }
     VD_PATCH_CASE(32, 0) VD_PATCH_CASE(32, 1) VD_PATCH_CASE(32, 2)
     VD_PATCH_CASE(16, 0) VD_PATCH_CASE(16, 1) VD_PATCH_CASE(16, 2)
+    VD_PATCH_CASE(8, 0) VD_PATCH_CASE(8, 1) VD_PATCH_CASE(8, 2)
+    VD_PATCH_CASE(4, 0) VD_PATCH_CASE(4, 1)
 #undef VD_PATCH_CASE
-    return VD_EINVAL;
+    if (!done) return VD_EINVAL;
+    if (splits > 1) {
+        const int64_t total = (int64_t)d.M * d.N;
+        const int g2 = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g2), dim3(256), 0, st, d, splits);
+    }
+    return 0;
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------
@@ -1070,6 +1150,13 @@ int launch_wgrad_t(const vd_wgrad_desc& d, int splits, int kk_per, hipStream_t s
 }
 
 }  // namespace
+
+extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
+    if (!desc || !patch_eligible(*desc)) return 0;
+    int splits, ks_per;
+    patch_plan(*desc, splits, ks_per);
+    return splits > 1 ? (int64_t)splits * desc->M * desc->N : 0;
+}
 
 extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("C", _i32), ("H", _i32), ("W", _i32), ("OH", _i32), ("OW", _i32),
                 ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("debug", _i32), ("alpha", _f32),
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
-                ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64)]
+                ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -46,6 +46,7 @@ PROTOTYPES = {
     "vd_device_ok": (_i32, []),
     "vd_gemm": (_i32, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_tile": (_i32, [C.POINTER(GemmDesc)]),
+    "vd_gemm_ws_floats": (_i64, [C.POINTER(GemmDesc)]),
     "vd_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "vd_conv_wgrad_plan": (_i32, [C.POINTER(WgradDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),

@@ -58,6 +58,18 @@ def _img(t: torch.Tensor):
 
 
 # --------------------------------------------------------------------------------------------- GEMM family
+_GEMM_WS = {}
+
+
+def _gemm_ws(n_floats: int, device):
+    """Per-device split-K workspace, grown on demand (launches on one stream are ordered, so it can be shared)."""
+    t = _GEMM_WS.get(device)
+    if t is None or t.numel() < n_floats:
+        t = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
+        _GEMM_WS[device] = t
+    return t
+
+
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0):
@@ -75,6 +87,9 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     d.lda, d.a_bstride, d.ldb, d.b_bstride = lda, a_bstride, ldb, b_bstride
     d.ldd, d.d_bstride, d.res_bstride, d.rowadd_bstride = ldd, d_bstride, res_bstride, rowadd_bstride
     lib = _lib()
+    need = lib.vd_gemm_ws_floats(C.byref(d))
+    if need > 0:
+        d.ws = _gemm_ws(need, D.device).data_ptr()
     if _PROF is None:
         L.check(lib.vd_gemm(C.byref(d), _s()), "vd_gemm")
         return D
