@@ -410,3 +410,23 @@ def test_empty_and_invalid_inputs_fail_loudly():
         ops.gemm(torch.empty(4, device=DEV), torch.empty(4, device=DEV), torch.empty(4, device=DEV), M=0, N=4, K=4)
     with pytest.raises(VillanHipError):
         ops.attn_small_fwd(torch.empty(1, 3, 128, device=DEV), torch.empty(1, 1, 128, device=DEV), None, 1, 128, 1.0)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(16, 256, 768, 16), (8, 512, 256, 16), (4, 384, 128, 32), (12, 256, 200, 16)])
+def test_plain_gemm_kernel_paths(B, Cin, Cout, H):
+    """1x1 convolution fwd (row-major A) and dgrad (column-major A) large enough to take gemm_plain_kernel."""
+    x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g(1)) / math.sqrt(Cin)).requires_grad_()
+    b = torch.randn(Cout, generator=g(2))
+    res = torch.randn(B, Cout, H, H, generator=g(3))
+    y = F.conv2d(x, w, b) + res
+    dy = torch.randn(y.shape, generator=g(4))
+    y.backward(dy)
+    out = torch.empty(B, Cout, H, H, device=DEV)
+    ops.conv1x1(x.detach().to(DEV), w.detach().to(DEV).view(Cout, Cin), b.to(DEV), out, residual=res.to(DEV))
+    check(out, y, 2e-5, f"conv1x1 fwd {Cin}->{Cout}@{H}")
+    dx = torch.empty(B, Cin, H, H, device=DEV)
+    HW = H * H
+    ops.gemm(w.detach().to(DEV).view(Cout, Cin), dy.to(DEV), dx, M=Cin, N=B * HW, K=Cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW,
+             lda=Cin, ldb=HW, b_bstride=Cout * HW, ldd=HW, d_bstride=Cin * HW)
+    check(dx, x.grad, 3e-5, "conv1x1 dgrad (A column-major)")

@@ -652,6 +652,118 @@ static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
     return 0;
 }
 
+// ---- plain GEMM with immediate-offset operands (1x1 convolutions, attention contractions) -----------------------------
+// D[b][m][p] = sum_k A[m][k] * B[b][k][p]  for the VD_B_PLAIN operand (pixel-contiguous B).  Same structure as the
+// patch-staged convolution: LDS images are k-major ( As[32][128], Bs[32][128] ), an MFMA step reads A and B with ONE
+// ds_read_b32 each at lane-constant base + immediate offset; B (and a column-major A) are staged with float4 global
+// loads and ds_write_b128, a row-major A (weights) with float4 loads and transposing ds_write_b32.
+template <int AMODE>
+__global__ __launch_bounds__(NT, 3) void gemm_plain_kernel(const vd_gemm_desc d) {
+    constexpr int WM = 2, WN = 2, BM = 128, BN = 128;
+    constexpr int LD_ = 128 + 4;                   // floats; rows stay 16-B aligned, lanes (consecutive n) conflict-free
+    constexpr int LDA_ = (AMODE == VD_A_ROW) ? 129 : 132;   // row-major A is written by transposing b32 stores: odd stride
+    constexpr int F4 = BM * BK / 4 / NT;           // 4 float4 per thread per operand
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA_];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LD_];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int b = n0 / d.NP, p0 = n0 - b * d.NP;   // BN | NP: a tile never straddles batch items
+    const float* __restrict__ Ap = d.A + (int64_t)b * d.a_bstride;
+    const float* __restrict__ Bp = d.B + (int64_t)b * d.b_bstride + p0;
+
+    f32x4 ra[F4], rb[F4];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + i * NT;
+            if (AMODE == VD_A_ROW) {               // A[m][k]: float4 along k
+                const int m = idx >> 3, q = idx & 7;
+                ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)min(m0 + m, d.M - 1) * d.lda + k0 + 4 * q);
+            } else {                               // A[k][m]: float4 along m
+                const int k = idx >> 5, q = idx & 31;
+                ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)(k0 + k) * d.lda + min(m0 + 4 * q, d.M - 4));
+            }
+            const int k = idx >> 5, q = idx & 31;  // B[k][n]: float4 along n
+            rb[i] = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(k0 + k) * d.ldb + 4 * q);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + i * NT;
+            if (AMODE == VD_A_ROW) {
+                const int m = idx >> 3, q = idx & 7;
+                const bool ok = m0 + m < d.M;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(4 * q + j) * LDA_ + m] = ok ? ra[i][j] : 0.f;
+            } else {
+                const int k = idx >> 5, q = idx & 31;
+                // M is a multiple of 4: a float4 group of rows is entirely inside or entirely outside the matrix
+                const bool ok = m0 + 4 * q < d.M;
+                *reinterpret_cast<f32x4*>(&As[k * LDA_ + 4 * q]) = ok ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int k = idx >> 5, q = idx & 31;
+            *reinterpret_cast<f32x4*>(&Bs[k * LD_ + 4 * q]) = rb[i];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.f;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const float* __restrict__ a_base = As + h * LDA_ + wm * 64 + (lane & 31);
+    const float* __restrict__ b_base = Bs + h * LD_ + wn * 64 + (lane & 31);
+
+    const int ksteps = d.K / BK;
+    load_stage(0);
+    store_stage();
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool more = ks + 1 < ksteps;
+        if (more) load_stage((ks + 1) * BK);
+#pragma unroll
+        for (int t = 0; t < BK / 2; ++t) {
+            float a[WM], bb[WN];
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) a[mi] = a_base[2 * t * LDA_ + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) bb[ni] = b_base[2 * t * LD_ + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_stage();
+        __syncthreads();
+    }
+    gemm_epilogue<WM, WN>(d, acc, m0, n0, wm, wn, lane, h);
+}
+
+static bool plain_eligible(const vd_gemm_desc& d) {
+    if (d.b_mode != VD_B_PLAIN || d.d_trans || d.debug != 0 || d.tile != 0) return false;
+    if (d.NP % 128 != 0 || d.N % 128 != 0 || d.K % BK != 0 || d.M < 64) return false;
+    if ((d.ldb & 3) || (d.b_bstride & 3) || (((uintptr_t)d.B) & 15)) return false;
+    if ((d.lda & 3) || (d.a_bstride & 3) || (((uintptr_t)d.A) & 15)) return false;
+    if (d.a_mode == VD_A_COL && (d.M & 3)) return false;
+    // enough tiles to fill the chip, otherwise the smaller generic tiles do better
+    return (int64_t)vd_cdiv(d.M, 128) * (d.N / 128) >= 192;
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------------------
 // D[m][n=(c,t)] = sum_{kk=(b,p)} dY[b][m][p] * gather(X)[b][c][p (+) t];  split-K over kk, slabs reduced afterwards.
 template <int WM, int WN, int BMODE>
@@ -1162,6 +1274,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
     if (patch_eligible(d)) return 4;
+    if (plain_eligible(d)) return 5;
     int max_bn = 128;
     if (d.a_bstride != 0 && d.NP % 128 != 0) max_bn = 64;
     int tile = d.tile ? d.tile : pick_tile(d.M, d.N, max_bn);
@@ -1189,6 +1302,15 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 2: rc = launch_gemm_t<1, 2>(d, st); break;
         case 3: rc = launch_gemm_t<1, 1>(d, st); break;
         case 4: rc = launch_patch(d, st); break;
+        case 5: {
+            const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
+            if (d.a_mode == VD_A_ROW)
+                hipLaunchKernelGGL((gemm_plain_kernel<VD_A_ROW>), dim3(grid), dim3(NT), 0, st, d);
+            else
+                hipLaunchKernelGGL((gemm_plain_kernel<VD_A_COL>), dim3(grid), dim3(NT), 0, st, d);
+            rc = 0;
+            break;
+        }
         default: vd_set_error("vd_gemm: bad tile %d", tile); return VD_EINVAL;
     }
     if (rc) return rc;
