@@ -190,6 +190,8 @@ int vd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const 
 int vd_sched_step(const float* x, const float* eps, const float* z, float* out, float* x0_out, int64_t n,
                   float c_eps, float c_div, float clip, float c_x0, float c_x, float c_e, float c_z,
                   uint64_t seed, uint64_t offset, void* stream);
+/* out[b] = sqrt(sum_i x[b][i]^2): per-sample L2 norms (ScoreSDE-VE corrector step size, diffusers step_correct). */
+int vd_batch_l2norm(const float* x, float* out, int B, int64_t inner, void* stream);
 /* out = clamp(x*mul + add, lo, hi), optionally NCHW -> NHWC (pipeline post-processing). */
 int vd_postprocess(const float* x, float* out, int B, int C, int HW, float mul, float add, float lo, float hi,
                    int to_nhwc, void* stream);

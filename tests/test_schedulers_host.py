@@ -33,10 +33,16 @@ def _fake_lincomb(out, srcs, coefs):
     return out
 
 
+def _fake_batch_l2norm(x, out):
+    out[:x.shape[0]].copy_(torch.norm(x.reshape(x.shape[0], -1), dim=-1))
+    return out
+
+
 @pytest.fixture(autouse=True)
 def _patch(monkeypatch):
     monkeypatch.setattr(ops, "sched_step", _fake_sched_step)
     monkeypatch.setattr(ops, "lincomb", _fake_lincomb)
+    monkeypatch.setattr(ops, "batch_l2norm", _fake_batch_l2norm)
 
 
 def _eps(x, t, ac):
@@ -108,3 +114,24 @@ def test_add_noise_and_surface():
     assert [lam(0), lam(250), lam(500)] == [0.0, 0.5, 1.0] and abs(lam(23450)) < 1e-12
     for k in (0, 100, 600, 12000, 23449):
         assert lam(k) == R.cosine_with_warmup_lambda(k, 500, 23450)
+
+
+def test_score_sde_ve_host_logic_matches_oracle():
+    a = S.ScoreSdeVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, snr=0.075)
+    b = R.ScoreSdeVeSchedulerRef(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, snr=0.075)
+    assert torch.equal(a.sigmas, b.sigmas) and torch.equal(a.discrete_sigmas, b.discrete_sigmas)
+    a.set_timesteps(30); a.set_sigmas(30); b.set_timesteps(30); b.set_sigmas(30)
+    assert torch.equal(a.timesteps, b.timesteps) and torch.equal(a.sigmas, b.sigmas)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 3, 8, 8, generator=g) * 380
+    xa, xb = x.clone(), x.clone()
+    for i, t in enumerate(a.timesteps):
+        z1, z2 = torch.randn(x.shape, generator=g), torch.randn(x.shape, generator=g)
+        sig = a.sigmas[i]
+        score = lambda v: -v / (sig ** 2 + 0.25)
+        xa = a.step_correct(score(xa), xa, noise=z1).prev_sample
+        xb = b.step_correct(score(xb), xb, noise=z1).prev_sample
+        oa, ob = a.step_pred(score(xa), t, xa, noise=z2), b.step_pred(score(xb), t, xb, noise=z2)
+        xa, xb = oa.prev_sample, ob.prev_sample
+    err = float((oa.prev_sample_mean - ob.prev_sample_mean).abs().max() / ob.prev_sample_mean.abs().max())
+    assert err < 1e-4, err

@@ -249,6 +249,16 @@ __global__ void sched_step_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+// one workgroup per sample: deterministic block reduction
+__global__ __launch_bounds__(256) void batch_l2norm_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t inner) {
+    __shared__ float red[4];
+    const float* __restrict__ xb = x + (int64_t)blockIdx.x * inner;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < inner; i += 256) s += xb[i] * xb[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrtf(s);
+}
+
 __global__ void postprocess_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int HW, float mul,
                                    float add, float lo, float hi, int to_nhwc) {
     GRID_STRIDE(i, (int64_t)B * C * HW) {
@@ -409,6 +419,13 @@ extern "C" int vd_sched_step(const float* x, const float* eps, const float* z, f
     StepCoef k{c_eps, c_div, clip, c_x0, c_x, c_e, c_z};
     hipLaunchKernelGGL(sched_step_kernel, dim3(egrid((n + 3) / 4)), dim3(EB), 0, ST, x, eps, z, out, x0_out, n, k, seed, offset);
     VD_LAUNCH_CHECK("vd_sched_step");
+    return 0;
+}
+
+extern "C" int vd_batch_l2norm(const float* x, float* out, int B, int64_t inner, void* stream) {
+    VD_REQUIRE(x && out && B > 0 && inner > 0, "vd_batch_l2norm: bad args");
+    hipLaunchKernelGGL(batch_l2norm_kernel, dim3(B), dim3(256), 0, ST, x, out, inner);
+    VD_LAUNCH_CHECK("vd_batch_l2norm");
     return 0;
 }
 

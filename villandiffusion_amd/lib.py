@@ -71,6 +71,7 @@ PROTOTYPES = {
     "vd_l2norm_sq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "vd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "vd_sched_step": (_i32, [_vp] * 5 + [_i64] + [_f32] * 7 + [C.c_uint64, C.c_uint64, _vp]),
+    "vd_batch_l2norm": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "vd_postprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "vd_randn": (_i32, [_vp, _i64, C.c_uint64, C.c_uint64, _vp]),
     "vd_poison_batch": (_i32, [_vp] * 8 + [_i32] * 4 + [_f32, _f32, _i32, _vp]),

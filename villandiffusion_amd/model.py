@@ -16,8 +16,9 @@ from typing import Optional
 
 import torch
 
-from .pipelines import DDIMPipeline, DDPMPipeline, DiffusionPipeline, PNDMPipeline
-from .schedulers import DDIMScheduler, DDPMScheduler, DPMSolverMultistepScheduler, UniPCMultistepScheduler
+from .pipelines import DDIMPipeline, DDPMPipeline, DiffusionPipeline, PNDMPipeline, ScoreSdeVePipeline
+from .schedulers import (DDIMScheduler, DDPMScheduler, DPMSolverMultistepScheduler, ScoreSdeVeScheduler,
+                         UniPCMultistepScheduler)
 from .unet import UNet2DModel
 
 # model.py:816-834
@@ -131,13 +132,32 @@ class DiffuserModelSched:
         return model, None, noise_sched, cls._pipeline_factory(pipe_cls)
 
     @classmethod
+    def _get_model_sched_ve(cls, ckpt_id, clip_sample, noise_sched_type=None, build_model=True):
+        """model.py:668-703: VE-SDE with T=2000, sigma in [0.01, 380], snr 0.075, one corrector step."""
+        if build_model:
+            raise NotImplementedError(f"pretrained VE checkpoints ('{ckpt_id}') are NCSN++ networks: a 'next' row (SURVEY.md §8f.5); "
+                                      f"from-scratch ids (e.g. {cls.DDPM_32_DEFAULT}) train the DDPM-style UNet under SDE-VE")
+        if noise_sched_type not in (None, cls.SCORE_SDE_VE_SCHED):
+            if noise_sched_type in (cls.EDM_VE_SCHED, cls.EDM_VE_ODE_SCHED, cls.EDM_VE_SDE_SCHED):
+                raise NotImplementedError(f"sampler {noise_sched_type} (KarrasVe) is a 'next' row (SURVEY.md §8f.3)")
+            raise NotImplementedError()
+        sched = ScoreSdeVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, sampling_eps=1e-05, correct_steps=1,
+                                    snr=0.075)
+        clip = cls.get_sample_clip(clip_sample, cls.CLIP_SAMPLE_DEFAULT)
+        if clip is not None:
+            sched.config.clip_sample = clip
+        return None, None, sched, cls._pipeline_factory(ScoreSdeVePipeline)
+
+    @classmethod
     def _get_model_sched(cls, ckpt_id, clip_sample, clip_sample_range=None, noise_sched_type=None, sde_type=SDE_VP,
                          build_model=True):
         if sde_type == cls.SDE_VP:
             model, vae, sched, gp = cls._get_model_sched_vp(ckpt_id, clip_sample, noise_sched_type, clip_sample_range, build_model)
-        elif sde_type in (cls.SDE_VE, cls.SDE_LDM):
-            raise NotImplementedError(f"sde_type {sde_type}: the NCSN++ / latent-diffusion model families are 'next' rows "
-                                      f"(SURVEY.md §8f.4-5); the {sde_type} loss tables are available in loss.LossFn")
+        elif sde_type == cls.SDE_VE:
+            model, vae, sched, gp = cls._get_model_sched_ve(ckpt_id, clip_sample, noise_sched_type, build_model)
+        elif sde_type == cls.SDE_LDM:
+            raise NotImplementedError(f"sde_type {sde_type}: the latent-diffusion (VQ-VAE) model family is a 'next' row "
+                                      f"(SURVEY.md §8f.4); the {sde_type} loss tables are available in loss.LossFn")
         else:
             raise NotImplementedError(f"sde_type {sde_type} not implemented")
         if model is not None:

@@ -378,6 +378,14 @@ def sched_step(x, eps, out, *, c_eps, c_div, clip, c_x0, c_x, c_e, c_z, z=None, 
     return out
 
 
+def batch_l2norm(x, out):
+    """out[b] = ||x[b]||_2 over all non-batch dims."""
+    Bn = x.shape[0]
+    assert x.is_contiguous() and out.numel() >= Bn
+    L.check(_lib().vd_batch_l2norm(_p(x), _p(out), Bn, x.numel() // Bn, _s()), "vd_batch_l2norm")
+    return out
+
+
 def postprocess(x, out, mul, add, lo, hi, to_nhwc):
     Bn, Cc, H, W = x.shape
     assert x.is_contiguous() and out.is_contiguous()

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .schedulers import SCHEDULER_CLASSES, DDIMScheduler, DDPMScheduler
+from .schedulers import SCHEDULER_CLASSES, DDIMScheduler, DDPMScheduler, ScoreSdeVeScheduler
 from .unet import UNet2DModel
 
 
@@ -148,6 +148,52 @@ class DDIMPipeline(DiffusionPipeline):
 
     def _step_kwargs(self, generator, eta):
         return {"generator": generator, "eta": 0.0 if eta is None else eta}
+
+
+class ScoreSdeVePipeline(DiffusionPipeline):
+    """[UPSTREAM] ScoreSdeVePipeline: x = z * sigma_max; per step `correct_steps` Langevin corrections then the
+    predictor; the UNet is called with sigma_t; result = sample_mean.clamp(0, 1) (reference model.py:683-684)."""
+    _class_name = "ScoreSdeVePipeline"
+    default_steps = 2000
+
+    @torch.no_grad()
+    def __call__(self, batch_size: int = 1, generator=None, init=None, num_inference_steps: Optional[int] = None, start_from: int = 0,
+                 save_every_step: bool = False, output_type=None, return_dict: bool = True, return_tensor: bool = False, **_):
+        unet, sched, dev = self.unet, self.scheduler, self.device
+        n = num_inference_steps if num_inference_steps is not None else self.default_steps
+        shape = (batch_size, unet.in_channels, unet.sample_size, unet.sample_size)
+        if init is None:
+            z = torch.randn(shape, generator=generator) if (generator is None or generator.device.type == "cpu") else \
+                torch.randn(shape, generator=generator, device=dev)
+            x = (z * sched.init_noise_sigma).to(dev)
+        else:
+            x = init.to(dev).float().contiguous()
+            batch_size = x.shape[0]
+        sched.set_timesteps(n)
+        sched.set_sigmas(n)
+        mean = x
+
+        def post(t):
+            B, C, H, W = t.shape
+            out = torch.empty((B, H, W, C), device=t.device, dtype=torch.float32)
+            ops.postprocess(t.contiguous(), out, 1.0, 0.0, 0.0, 1.0, True)
+            return out.cpu().numpy()
+
+        movie = [post(x)] if (save_every_step or init is not None) else []
+        sig_tab = sched.sigmas.to(torch.float32).to(dev)[:, None].expand(n, batch_size).contiguous()
+        for i in range(start_from, n):
+            t = sched.timesteps[i]
+            for _k in range(sched.config.correct_steps):
+                score = unet(x, sig_tab[i], return_dict=False)[0]
+                x = sched.step_correct(score, x, generator=generator).prev_sample
+            score = unet(x, sig_tab[i], return_dict=False)[0]
+            out = sched.step_pred(score, t, x, generator=generator)
+            x, mean = out.prev_sample, out.prev_sample_mean
+            if save_every_step:
+                movie.append(post(mean))
+        if return_tensor:
+            return mean
+        return SimpleNamespace(images=post(mean), movie=movie)
 
 
 class PNDMPipeline(DiffusionPipeline):

@@ -362,6 +362,76 @@ class UniPCMultistepScheduler(_Multistep):
         return SimpleNamespace(prev_sample=out)
 
 
+class ScoreSdeVeScheduler:
+    """S5 -- [UPSTREAM] ScoreSdeVeScheduler (predictor-corrector VE-SDE sampler; reference model.py:672-684).
+    Per-sample norms are one reduction kernel, both state updates are one ``vd_lincomb`` each."""
+    _class_name = "ScoreSdeVeScheduler"
+    order = 1
+
+    def __init__(self, num_train_timesteps=2000, snr=0.15, sigma_min=0.01, sigma_max=1348.0, sampling_eps=1e-5, correct_steps=1, **extra):
+        self.config = _Config(num_train_timesteps=num_train_timesteps, snr=snr, sigma_min=sigma_min, sigma_max=sigma_max,
+                              sampling_eps=sampling_eps, correct_steps=correct_steps, clip_sample=False, **extra)
+        self.init_noise_sigma = sigma_max
+        self.timesteps = None
+        self.device_rng_seed: Optional[int] = None
+        self._rng_offset = 0
+        self.set_sigmas(num_train_timesteps)
+
+    def scheduler_config(self) -> dict:
+        d = {k: v for k, v in vars(self.config).items()}
+        d["_class_name"] = self._class_name
+        return d
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, sampling_eps: float = None, device=None):
+        eps = sampling_eps if sampling_eps is not None else self.config.sampling_eps
+        self.timesteps = torch.linspace(1, eps, num_inference_steps)
+
+    def set_sigmas(self, num_inference_steps: int, sigma_min=None, sigma_max=None, sampling_eps=None):
+        smin = self.config.sigma_min if sigma_min is None else sigma_min
+        smax = self.config.sigma_max if sigma_max is None else sigma_max
+        if self.timesteps is None:
+            self.set_timesteps(num_inference_steps, sampling_eps)
+        self.discrete_sigmas = torch.exp(torch.linspace(math.log(smin), math.log(smax), num_inference_steps))
+        self.sigmas = torch.tensor([smin * (smax / smin) ** t for t in self.timesteps])
+
+    def _z(self, x, generator, noise):
+        if noise is not None:
+            return noise
+        if self.device_rng_seed is not None:
+            z = torch.empty_like(x)
+            ops.randn(z, int(self.device_rng_seed), self._rng_offset)
+            self._rng_offset += (x.numel() + 3) // 4
+            return z
+        return _noise_like(x, generator)
+
+    def step_correct(self, model_output, sample, generator=None, noise=None, return_dict=True):
+        z = self._z(sample, generator, noise).contiguous()
+        B = sample.shape[0]
+        norms = torch.empty(2 * B, device=sample.device, dtype=torch.float32)
+        ops.batch_l2norm(model_output.contiguous(), norms[:B])
+        ops.batch_l2norm(z, norms[B:])
+        nrm = norms.cpu()
+        gnorm, znorm = nrm[:B].mean(), nrm[B:].mean()
+        step = (self.config.snr * znorm / gnorm) ** 2 * 2
+        mean = ops.lincomb(torch.empty_like(sample), [sample.contiguous(), model_output.contiguous()], [1.0, float(step)])
+        prev = ops.lincomb(torch.empty_like(sample), [mean, z], [1.0, float((step * 2) ** 0.5)])
+        return SimpleNamespace(prev_sample=prev, prev_sample_mean=mean)
+
+    def step_pred(self, model_output, timestep, sample, generator=None, noise=None, return_dict=True):
+        t = float(timestep)
+        idx = int(torch.tensor(t * (len(self.timesteps) - 1)).long())           # (timestep * (N-1)).long()
+        sigma = self.discrete_sigmas[idx]
+        adj = torch.zeros(()) if idx == 0 else self.discrete_sigmas[idx - 1]
+        diffusion = (sigma ** 2 - adj ** 2) ** 0.5
+        z = self._z(sample, generator, noise).contiguous()
+        mean = ops.lincomb(torch.empty_like(sample), [sample.contiguous(), model_output.contiguous()], [1.0, float(diffusion ** 2)])
+        prev = ops.lincomb(torch.empty_like(sample), [mean, z], [1.0, float(diffusion)])
+        return SimpleNamespace(prev_sample=prev, prev_sample_mean=mean)
+
+
 def get_cosine_schedule_with_warmup_lambda(num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5):
     """[UPSTREAM] diffusers.optimization.get_cosine_schedule_with_warmup's lr_lambda (VillanDiffusion.py:446-450)."""
     def lr_lambda(step: int) -> float:
@@ -373,4 +443,4 @@ def get_cosine_schedule_with_warmup_lambda(num_warmup_steps: int, num_training_s
 
 
 SCHEDULER_CLASSES = {c._class_name: c for c in (DDPMScheduler, DDIMScheduler, DPMSolverMultistepScheduler,
-                                                UniPCMultistepScheduler)}
+                                                UniPCMultistepScheduler, ScoreSdeVeScheduler)}
