@@ -91,3 +91,28 @@ def test_backward_matches_oracle(pair):
     assert abs(float(gn2) - 2 * float(gn)) <= 1e-4 * float(gn2)
     net.zero_grad()
     assert float(net.flat_grad.abs().max()) == 0.0
+
+
+def test_gradient_buckets_are_final_when_their_hook_fires(pair):
+    """The trainer overlaps the all-reduce of bucket i with the rest of backward: at hook(i) the bucket must already hold
+    its final value."""
+    ref, net = pair
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    t = torch.tensor([10, 700])
+    snaps = {}
+
+    def hook(i):
+        s, e = net.grad_buckets[i]
+        snaps[i] = net.flat_grad[s:e].clone()
+
+    net.zero_grad()
+    net.bucket_ready_hook = hook
+    try:
+        net(x.cuda(), t.cuda())[0].square().sum().backward()
+    finally:
+        net.bucket_ready_hook = None
+    assert sorted(snaps) == [0, 1, 2, 3]
+    for i, (s, e) in enumerate(net.grad_buckets):
+        assert torch.equal(snaps[i], net.flat_grad[s:e]), i
+        assert float(snaps[i].abs().max()) > 0
+    net.zero_grad()

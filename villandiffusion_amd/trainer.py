@@ -102,7 +102,18 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.n_buckets = n_allreduce_buckets
         self.loss_fn.grad_scale = 1.0 / self.grad_accum
+        self._pending = []                        # async all-reduce handles of the current optimiser step
+        self._sync_now = False
+        if self.world > 1 and hasattr(model, "grad_buckets"):
+            model.bucket_ready_hook = self._bucket_ready      # overlap the all-reduce with the rest of backward
         model.zero_grad()
+
+    def _bucket_ready(self, i: int):
+        """Called from the UNet's explicit backward when gradient bucket i is final (order: up|out, mid, down, temb)."""
+        if not self._sync_now:
+            return
+        s, e = self.model.grad_buckets[i]
+        self._pending.append(dist.all_reduce(self.model.flat_grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     @property
     def lr(self) -> float:
@@ -111,13 +122,21 @@ class Trainer:
     def train_step(self, batch, timesteps: torch.Tensor, noise: Optional[torch.Tensor] = None, last_batch: bool = False,
                    target_key: str = "target", poison_key: str = "pixel_values"):
         """One micro-step; returns the (un-divided) loss tensor of this micro-batch."""
+        sync = (self.micro + 1) % self.grad_accum == 0 or last_batch   # accelerate: sync on every G-th and on the last batch
+        self._sync_now = sync and self.model.bucket_ready_hook is not None
         loss = self.loss_fn.p_loss_by_keys(batch, self.model, target_latent_key=target_key, poison_latent_key=poison_key,
                                            timesteps=timesteps, noise=noise)
         if torch.is_tensor(loss):
             loss.backward()
         self.micro += 1
-        if self.micro % self.grad_accum == 0 or last_batch:       # accelerate: sync on every G-th and on the last batch
-            allreduce_flat_grad(self.model.flat_grad, self.n_buckets)
+        if sync:
+            if self._sync_now and self._pending:
+                for w in self._pending:                           # bucketed all-reduces were launched during backward
+                    w.wait()
+                self._pending = []
+            else:
+                allreduce_flat_grad(self.model.flat_grad, self.n_buckets)
+            self._sync_now = False
             self.opt.step(lr=self.lr, grad_inv_scale=1.0 / self.world)
             self.sched_step += 1
             self.model.zero_grad()

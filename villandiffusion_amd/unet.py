@@ -447,6 +447,16 @@ class UNet2DModel(nn.Module):
         exponent = exponent / (half - self.config.freq_shift)
         self.freqs = torch.exp(exponent).to(dev)
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        # Gradient buckets in the order backward completes them (flat-buffer ranges): [up blocks | out], [mid], [conv_in |
+        # down blocks], [time-embedding MLP, all time_emb_proj, all q/k/v].  bucket_ready_hook(i) is called from the
+        # explicit backward as soon as bucket i is final, so a trainer can overlap its all-reduce with the rest.
+        def _late(k):     # tensors laid out in the fused head of the buffer (time_emb_proj / q,k,v): bucket 3
+            return ".time_emb_proj." in k or ".to_q." in k or ".to_k." in k or ".to_v." in k
+        o_in = offs["conv_in.weight"][0]
+        o_mid = min(v[0] for k, v in offs.items() if k.startswith("mid_block.") and not _late(k))
+        o_up = min(v[0] for k, v in offs.items() if k.startswith("up_blocks.") and not _late(k))
+        self.grad_buckets = [(o_up, total), (o_mid, o_up), (o_in, o_mid), (0, o_in)]
+        self.bucket_ready_hook = None
         self.reset_parameters()
 
     @torch.no_grad()
@@ -567,6 +577,7 @@ class UNet2DModel(nn.Module):
         B, _, S, _ = x.shape
         st = SimpleNamespace(saved=[], B=B)
         sv = st.saved
+        st.marks = {}                                   # tape length at the end of the down / mid stages
         # ---- time embedding (K3) ----
         emb_sin = torch.empty((B, self.time_dim0), device=dev, dtype=torch.float32)
         ops.timestep_embedding(t, self.freqs, emb_sin, self.config.flip_sin_to_cos)
@@ -630,6 +641,7 @@ class UNet2DModel(nn.Module):
                     sv.append(("ds", blk["ds"], h))
                 h = out
         assert k == n_skip
+        st.marks["down_end"] = len(sv)
         # ---- mid ----
         tmp = self._new(B, self.mid_res[0].cout, sp)
         s = self.mid_res[0].fwd(h, tmp, st, save)
@@ -640,6 +652,7 @@ class UNet2DModel(nn.Module):
         s3 = self.mid_res[1].fwd(tmp2, out, st, save)
         if save:
             sv.append(("res", self.mid_res[0], s)); sv.append(("attn", self.mid_attn, s2)); sv.append(("res", self.mid_res[1], s3))
+        st.marks["mid_end"] = len(sv)
         # ---- up path ----
         final = None
         for bi, blk in enumerate(self.up):
@@ -703,8 +716,13 @@ class UNet2DModel(nn.Module):
         self.norm_out.bwd(da, final, mo, ro, g)
         # `g` is the gradient wrt the output of the most recent forward op; walk the tape backwards.
         slot = n_skip
-        pending_skip = n_skip                                     # skips are consumed in reverse production order
+        hook = self.bucket_ready_hook
         while sv:
+            if hook is not None:                                  # gradient buckets complete in the order up|out, mid, down
+                if len(sv) == st.marks["mid_end"]:
+                    hook(0)
+                elif len(sv) == st.marks["down_end"]:
+                    hook(1)
             rec = sv.pop()
             kind = rec[0]
             if kind in ("res", "attn"):
@@ -736,6 +754,8 @@ class UNet2DModel(nn.Module):
                 self._conv_in.bwd(g, rec[1], None)
             else:
                 raise RuntimeError(kind)
+        if hook is not None:
+            hook(2)
         # ---- time embedding backward ----
         emb_sin, e1, e1a, emb, emb_act = st.temb_saved
         d = st.d_temb_all
@@ -751,6 +771,8 @@ class UNet2DModel(nn.Module):
         d_e1 = ops.silu_bwd(d_e1a, e1, torch.empty_like(e1))
         ops.linear_wgrad(d_e1, emb_sin, self.G["time_embedding.linear_1.weight"], accumulate=True)
         ops.colsum(d_e1, self.G["time_embedding.linear_1.bias"], B, self.temb_dim, accumulate=True)
+        if hook is not None:
+            hook(3)
 
     def _add_skip_grad(self, g, x, st, dcats):
         """If `x` (the input whose gradient `g` was just produced) is a skip tensor living in a concat buffer, add the
