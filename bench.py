@@ -212,8 +212,15 @@ def main():
         kernels = sorted(({"kernel": k, "launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / v[2] / 1e9, 2),
                            "avg_us": round(1e3 * v[2] / v[0], 1)} for k, v in agg.items()), key=lambda r: -r["ms"])
         top = kernels[0]
+        traffic = None          # HBM bytes per launch from the committed PMC pass (rocprofv3 cannot run inside this process)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(top["kernel"], {}).get("traffic_bytes_per_launch")
+        except OSError:
+            pass
         roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
                     "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
                     "all_mfma_kernels_ms": round(sum(k["ms"] for k in kernels), 2)}
 

@@ -26,6 +26,9 @@ for cin, cout, H in shapes:
     line = f"conv3x3 {cin:4d}->{cout:4d} @{H:2d}^2: "
     ms = timeit(lambda: ops.conv3x3(x, w, bias, out, mode=B_CONV3, tile=0))
     print(line + f"AUTO (patch kernel where eligible): {flops / ms / 1e9:6.1f} TF ({ms*1e3:.0f} us)")
+    for dbg, nm in ((17, "patch noload"), (25, "patch noload+nostore")):
+        ms = timeit(lambda: ops.conv3x3(x, w, bias, out, mode=B_CONV3, tile=0, debug=dbg))
+        print(line + f"{nm}: {flops / ms / 1e9:6.1f} TF")
     ms = timeit(lambda: ops.conv3x3(x, w, bias, out, mode=B_CONV3_T, tile=0))
     print(line + f"AUTO dgrad-style (flipped taps): {flops / ms / 1e9:6.1f} TF")
     for tile in (1,):

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
     __syncthreads();
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         const bool more = ks + 1 < ks_end;
-        if (more) load_stage((ks + 1) * CK);
+        if (more && !(d.debug & 1)) load_stage((ks + 1) * CK);       // debug bits: timing-only ablations
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
 #pragma unroll
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
             }
         }
         __syncthreads();
-        if (more) store_stage();
+        if (more && !(d.debug & 8)) store_stage();
         __syncthreads();
     }
     if (gridDim.y == 1) {
@@ -604,7 +604,7 @@ static bool patch_eligible(const vd_gemm_desc& d) {
     if (d.C % CK != 0 || d.OH * d.OW != d.NP || d.d_trans) return false;
     if (d.NP >= 128 ? (d.NP % 128 != 0) : (128 % d.NP != 0)) return false;
     if (d.K != d.C * 9 || (d.lda & 3) != 0 || (((uintptr_t)d.A) & 15) != 0) return false;
-    if (d.debug != 0 || d.tile != 0) return false;
+    if ((d.debug & ~(16 | 1 | 8)) != 0 || (d.debug != 0 && !(d.debug & 16)) || d.tile != 0) return false;   // 16: ablations on this kernel
     if (d.b_mode == VD_B_CONV3_UP && d.OW == 4) return false;
     return d.M >= 64;
 }
