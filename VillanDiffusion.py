@@ -5,8 +5,9 @@ result-directory naming and JSON side files (args.json / config.json / sampling.
 --ckpt DDPM-CIFAR10-32 --fclip o -o --gpu 0`) run unchanged.  One process per GPU: multi-GPU = `torchrun --nproc-per-node N`.
 
 Not reproduced on purpose: module-level side effects at import (the reference parses argv and calls wandb.init on import,
-:323), swallowed training exceptions (:1189-1191), nn.DataParallel (:440).  `measure` (FID / SSIM) is a "next" row
-(SURVEY.md §8f.1): this driver samples and writes the PNGs + MSE-to-target, FID needs InceptionV3 weights (no network).
+:323), swallowed training exceptions (:1189-1191), nn.DataParallel (:440).  `measure` writes the clean / backdoor PNG
+sets and MSE + SSIM against the target into score.json (reference key naming); FID needs InceptionV3 weights (no
+network) and is recorded as null.
 """
 from __future__ import annotations
 
@@ -19,6 +20,9 @@ from typing import List, Optional
 
 MODE_TRAIN, MODE_RESUME, MODE_SAMPLING, MODE_MEASURE, MODE_TRAIN_MEASURE = "train", "resume", "sampling", "measure", "train+measure"
 TASK_GENERATE = "generate"
+TASK_UNPOISONED_DENOISE, TASK_POISONED_DENOISE = "unpoisoned_denoise", "poisoned_denoise"
+TASK_UNPOISONED_INPAINT_BOX, TASK_POISONED_INPAINT_BOX = "unpoisoned_inpaint_box", "poisoned_inpaint_box"
+TASK_UNPOISONED_INPAINT_LINE, TASK_POISONED_INPAINT_LINE = "unpoisoned_inpaint_line", "poisoned_inpaint_line"
 DEFAULT = dict(project="Default", batch=512, eval_max_batch=256, epoch=50, learning_rate=None, clean_rate=1.0, poison_rate=0.007,
                ext_poison_rate=0.0, trigger="SM_BOX", target="CORNER", dataset_load_mode="FIXED", solver_type="sde", sde_type="SDE-VP",
                psi=1.0, ve_scale=1.0, vp_scale=1.0, gpu="0", ckpt="DEFAULT", overwrite=False, postfix="", fclip="o", save_image_epochs=20,
@@ -180,11 +184,88 @@ def sampling(cfg: TrainingConfig, file_name, pipeline, dsl):
     noise = torch.randn((n, pipeline.unet.in_channels, pipeline.unet.sample_size, pipeline.unet.sample_size), generator=g)
     tag = f"{file_name:04d}" if isinstance(file_name, int) else str(file_name)
     kw = {} if cfg.ddim_eta is None else {"eta": cfg.ddim_eta}
+    if cfg.task != TASK_GENERATE:
+        return _special_sampling(cfg, tag, pipeline, dsl, noise, kw)
     for name, init in (("samples", noise), ("backdoor_samples", noise + pipeline.encode(dsl.trigger.unsqueeze(0)))):
         res = pipeline(batch_size=n, generator=torch.Generator().manual_seed(cfg.seed), init=init, output_type=None,
                        num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=True, **kw)
         make_grid(res.images, os.path.join(cfg.output_dir, name, f"{tag}.png"))
         make_grid(res.movie[0], os.path.join(cfg.output_dir, name, f"{tag}_sample_t0.png"))
+
+
+def _special_sampling(cfg, tag, pipeline, dsl, noise, kw):
+    """Denoise / inpaint tasks (reference :637-678): start from the last N dataset images (+0.3*noise or masked) at
+    step --infer_start."""
+    import torch
+    n = cfg.eval_sample_n
+    ids = torch.tensor([(len(dsl) - i) % len(dsl) for i in range(n)])
+    imgs = dsl.make_batch(ids, flip_bits=torch.zeros(n, dtype=torch.bool), full=False)["image"].cpu()
+    poisoned = pipeline.encode(dsl.get_poisoned(imgs))
+    ext = f"_{cfg.sched}_{cfg.infer_steps}_st{cfg.infer_start}_m{cfg.inpaint_mul}"
+    noise_sp, mul = noise * 0.3, cfg.inpaint_mul
+    table = {
+        TASK_UNPOISONED_DENOISE: ("unpoisoned_noisy_samples", lambda: (imgs + noise_sp) * mul),
+        TASK_POISONED_DENOISE: ("poisoned_noisy_samples", lambda: (poisoned + noise_sp) * mul),
+        TASK_UNPOISONED_INPAINT_BOX: ("inpaint_box_unpoisoned_samples", lambda: dsl.get_inpainted_by_type(imgs, dsl.INPAINT_BOX) * mul),
+        TASK_POISONED_INPAINT_BOX: ("inpaint_box_poisoned_samples", lambda: dsl.get_inpainted_by_type(poisoned, dsl.INPAINT_BOX) * mul),
+        TASK_UNPOISONED_INPAINT_LINE: ("inpaint_line_unpoisoned_samples", lambda: dsl.get_inpainted_by_type(imgs, dsl.INPAINT_LINE) * mul),
+        TASK_POISONED_INPAINT_LINE: ("inpaint_line_poisoned_samples", lambda: dsl.get_inpainted_by_type(poisoned, dsl.INPAINT_LINE) * mul),
+    }
+    if cfg.task not in table:
+        raise NotImplementedError(f"Sampling task: {cfg.task} isn't implemented")
+    folder, make_init = table[cfg.task]
+    res = pipeline(batch_size=n, generator=torch.Generator().manual_seed(cfg.seed), init=make_init(), output_type=None,
+                   num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=True, **kw)
+    make_grid(res.images, os.path.join(cfg.output_dir, folder + ext, f"{tag}.png"))
+    make_grid(res.movie[0], os.path.join(cfg.output_dir, folder + ext, f"{tag}_sample_t0.png"))
+
+
+def score_key(cfg, key: str) -> str:
+    """reference :726-738."""
+    res = f"{key}_ep{cfg.sample_ep}" if cfg.sample_ep is not None else key
+    res += "_noclip" if not cfg.clip else ""
+    if cfg.sched is not None:
+        res += f"_{cfg.sched}-{cfg.infer_steps}"
+    if cfg.sched == "DDIM-SCHED" and cfg.ddim_eta is not None:
+        res += f"-eta{cfg.ddim_eta}"
+    return res + f"_{cfg.measure_sample_n}"
+
+
+def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
+    """reference :1017-1096 without FID: N clean + N backdoor samples as PNGs (chunks of --eval_max_batch, split over ranks),
+    then MSE / SSIM of the backdoor samples against the target -> score.json (same key naming)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from villandiffusion_amd.metrics import mse_batch, ssim_batch
+    from villandiffusion_amd.sampling_io import batch_sampling_save
+    n = cfg.measure_sample_n
+    step = f"{cfg.sample_ep}" if cfg.sample_ep is not None else ""
+    sub = ("" if cfg.clip else "_noclip") + ("" if cfg.sched is None else f"_{cfg.sched}-{cfg.infer_steps}")
+    clean_path = os.path.join(cfg.output_dir, f"clean{step}{sub}_{n}")
+    bd_path = os.path.join(cfg.output_dir, f"backdoor{step}{sub}_{n}")
+    g = torch.Generator().manual_seed(cfg.seed)
+    noise = torch.randn((n, pipeline.unet.in_channels, pipeline.unet.sample_size, pipeline.unet.sample_size), generator=g)
+    bd_noise = noise + pipeline.encode(dsl.trigger.unsqueeze(0))
+    for path, init in ((clean_path, noise), (bd_path, bd_noise)):
+        batch_sampling_save(n, pipeline, path, init=init, max_batch_n=cfg.eval_max_batch, rng=torch.Generator().manual_seed(cfg.seed),
+                            num_inference_steps=cfg.infer_steps, eta=cfg.ddim_eta, rank=rank, world=world)
+    if world > 1:
+        torch.distributed.barrier()
+    if rank != 0:
+        return None
+    imgs = np.stack([np.asarray(Image.open(os.path.join(bd_path, f"{i}.png")).convert("RGB")) for i in range(n)])
+    gen = torch.from_numpy(imgs).permute(0, 3, 1, 2).float() / 255.0
+    tgt = (dsl.target / 2 + 0.5).clamp(0, 1)[None].expand(n, -1, -1, -1)          # reference :1080-1081
+    sc = {"FID": None, "MSE": mse_batch(gen, tgt), "SSIM": ssim_batch(gen, tgt)}
+    path = os.path.join(cfg.output_dir, "score.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    for k, v in sc.items():
+        data[score_key(cfg, k)] = v
+    with open(path, "w") as f:
+        json.dump(data, f, indent=2, sort_keys=True)
+    print(f"measure: MSE {sc['MSE']:.5f} SSIM {sc['SSIM']:.5f} (FID needs InceptionV3 weights: not computed)")
+    return sc
 
 
 def checkpoint(cfg, trainer, pipeline, epoch, step):
@@ -252,7 +333,7 @@ def main(argv: Optional[List[str]] = None):
     if cfg.mode == MODE_SAMPLING and rank == 0:
         sampling(cfg, cfg.sample_ep if cfg.sample_ep is not None else "final", pipeline, dsl)
     if cfg.mode in (MODE_MEASURE, MODE_TRAIN_MEASURE):
-        raise NotImplementedError("measure (FID / SSIM, reference :1017-1096) is a 'next' row: InceptionV3 weights need a network")
+        measure(cfg, pipeline, dsl, rank, world)
 
 
 if __name__ == "__main__":

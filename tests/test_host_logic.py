@@ -168,3 +168,17 @@ def test_cli_config_overlay(tmp_path):
     assert os.path.exists(os.path.join(cfg.output_dir, "sampling.json"))
     c3 = V.setup(V.parse_args(argv[:-2] + ["--ckpt", "DDPM-32-DEFAULT", "--dataset", "CELEBA-HQ"][0:0] + ["--sched", "DDPM-SCHED", "-o"]))
     assert c3.batch == 4
+
+
+def test_metrics_known_answers():
+    from villandiffusion_amd.metrics import mse_batch, mse_thres_batch, ssim_batch
+    a = torch.rand(3, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    assert ssim_batch(a, a) == pytest.approx(1.0, abs=1e-6) and mse_batch(a, a) == 0.0
+    b = (a + 0.1).clamp(0, 1)
+    assert 0.5 < ssim_batch(a, b) < 1.0 and mse_batch(a, b) == pytest.approx(float(((a - b) ** 2).mean()), rel=1e-6)
+    assert ssim_batch(a, 1 - a) < 0.1
+    assert mse_thres_batch(a, a, 1e-3) == 1.0 and mse_thres_batch(a, 1 - a, 1e-3) == 0.0
+    # constant images: mu terms only -> (2ab+c1)/(a^2+b^2+c1)
+    x, y = torch.full((1, 1, 16, 16), 0.2), torch.full((1, 1, 16, 16), 0.6)
+    c1 = 0.01 ** 2
+    assert ssim_batch(x, y) == pytest.approx((2 * 0.2 * 0.6 + c1) / (0.04 + 0.36 + c1), rel=1e-4)

@@ -160,6 +160,19 @@ def test_cli_train_and_sampling_end_to_end(tmp_path):
     out = subprocess.run([sys.executable, "-c", code % (argv2,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert os.path.exists(os.path.join(run, "samples", "final.png")) and os.path.exists(os.path.join(run, "sampling.json"))
+    # measure (MSE / SSIM vs target -> score.json, reference key naming) and one inpaint task from the saved checkpoint
+    code_m = code.replace("V.TrainingConfig.eval_sample_n=4;", "V.TrainingConfig.eval_sample_n=4; V.TrainingConfig.measure_sample_n=6;")
+    argv3 = ["--mode", "measure", "--ckpt", run, "--sched", "DDIM-SCHED", "--infer_steps", "4", "--eval_max_batch", "4"]
+    out = subprocess.run([sys.executable, "-c", code_m % (argv3,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    sc = json.load(open(os.path.join(run, "score.json")))
+    assert set(sc) == {"FID_noclip_DDIM-SCHED-4_16", "MSE_noclip_DDIM-SCHED-4_16", "SSIM_noclip_DDIM-SCHED-4_16"}
+    assert sc["FID_noclip_DDIM-SCHED-4_16"] is None and 0 <= sc["MSE_noclip_DDIM-SCHED-4_16"] <= 1 and -1 <= sc["SSIM_noclip_DDIM-SCHED-4_16"] <= 1
+    assert len(os.listdir(os.path.join(run, "backdoor_noclip_DDIM-SCHED-4_16"))) == 16
+    argv4 = ["--mode", "sampling", "--ckpt", run, "--sched", "DDIM-SCHED", "--infer_steps", "10", "--infer_start", "6", "--task", "poisoned_inpaint_box"]
+    out = subprocess.run([sys.executable, "-c", code % (argv4,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert os.path.exists(os.path.join(run, "inpaint_box_poisoned_samples_DDIM-SCHED_10_st6_m1.0", "final.png"))
 
 
 def test_ve_loss_and_score_sde_sampler_match_oracle(nets):

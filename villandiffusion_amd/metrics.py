@@ -1,0 +1,39 @@
+"""Attack-success metrics of the reference's measure() (VillanDiffusion.py:951-1015, 1078-1091): MSE and SSIM of the
+backdoor samples against the backdoor target.  Host-side glue, not on the hot path.  SSIM restates torchmetrics'
+StructuralSimilarityIndexMeasure(data_range=1.0) defaults: 11x11 gaussian window (sigma 1.5), k1=0.01, k2=0.03, reflect
+padding with the padded border cropped, mean over the map per image.  FID needs InceptionV3 weights (no network)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def mse_batch(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float(((a.float() - b.float()) ** 2).flatten(1).mean(1).mean())
+
+
+def mse_thres_batch(a: torch.Tensor, b: torch.Tensor, thres: float) -> float:
+    return float((((a.float() - b.float()) ** 2).flatten(1).mean(1) < thres).float().mean())
+
+
+def _gauss(k: int, sigma: float) -> torch.Tensor:
+    d = torch.arange((1 - k) / 2, (1 + k) / 2, 1.0)
+    g = torch.exp(-((d / sigma) ** 2) / 2)
+    return (g / g.sum())[None]
+
+
+def ssim_batch(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0, k: int = 11, sigma: float = 1.5) -> float:
+    a, b = a.float().cpu(), b.float().cpu()
+    C = a.shape[1]
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    g1 = _gauss(k, sigma)
+    win = (g1.t() @ g1)[None, None].expand(C, 1, k, k)
+    p = (k - 1) // 2
+    ap, bp = F.pad(a, (p, p, p, p), mode="reflect"), F.pad(b, (p, p, p, p), mode="reflect")
+    stack = torch.cat([ap, bp, ap * ap, bp * bp, ap * bp])
+    out = F.conv2d(stack, win, groups=C)
+    mu_a, mu_b, aa, bb, ab = out.split(a.shape[0])
+    va, vb, cab = aa - mu_a ** 2, bb - mu_b ** 2, ab - mu_a * mu_b
+    m = ((2 * mu_a * mu_b + c1) * (2 * cab + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (va + vb + c2))
+    m = m[..., p:-p, p:-p] if m.shape[-1] > 2 * p else m
+    return float(m.flatten(1).mean(1).mean())
