@@ -535,23 +535,35 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         const bool more = ks + 1 < ks_end;
         if (more && !(d.debug & 1)) load_stage((ks + 1) * CK);       // debug bits: timing-only ablations
+        // software-pipelined operand fetch: the ds_reads of MFMA step u+1 are issued before the MFMAs of step u
+        // (hipcc otherwise places each read right in front of its use and waits lgkmcnt(0): LDS latency per 4 MFMAs)
+        auto fetch = [&](int u, float (&a)[WM], float (&bb)[WN]) {
+            const int cp = u / 9, t = u - 9 * cp;
+            const int r = t / 3, sx = t - 3 * r;
+            const int pr = (MODE == 1) ? (2 - r) : r, ps = (MODE == 1) ? (2 - sx) : sx;
 #pragma unroll
-        for (int cp = 0; cp < CK / 2; ++cp) {
+            for (int mi = 0; mi < WM; ++mi) a[mi] = a_base[(2 * cp * 9 + t) * LDA_ + mi * 32];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, sx = t - 3 * r;
-                const int pr = (MODE == 1) ? (2 - r) : r, ps = (MODE == 1) ? (2 - sx) : sx;
-                float a[WM], bb[WN];
+            for (int ni = 0; ni < WN; ++ni) bb[ni] = p_base[ni][2 * cp * PLANE + pr * PW + ps];
+        };
+        float a0[WM], b0[WN], a1[WM], b1[WN];
+        fetch(0, a0, b0);
 #pragma unroll
-                for (int mi = 0; mi < WM; ++mi) a[mi] = a_base[(2 * cp * 9 + t) * LDA_ + mi * 32];
+        for (int u = 0; u < (CK / 2) * 9; u += 2) {
+            fetch(u + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ni = 0; ni < WN; ++ni) bb[ni] = p_base[ni][2 * cp * PLANE + pr * PW + ps];
+            for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
+                for (int ni = 0; ni < WN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+            if (u + 2 < (CK / 2) * 9) fetch(u + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int ni = 0; ni < WN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
-            }
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
         if (more && !(d.debug & 8)) store_stage();
@@ -734,18 +746,30 @@ __global__ __launch_bounds__(NT, 3) void gemm_plain_kernel(const vd_gemm_desc d)
     for (int ks = 0; ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
         if (more) load_stage((ks + 1) * BK);
-#pragma unroll
-        for (int t = 0; t < BK / 2; ++t) {
-            float a[WM], bb[WN];
+        auto fetch = [&](int t, float (&a)[WM], float (&bb)[WN]) {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) a[mi] = a_base[2 * t * LDA_ + mi * 32];
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) bb[ni] = b_base[2 * t * LD_ + ni * 32];
+        };
+        float a0[WM], b0[WN], a1[WM], b1[WN];
+        fetch(0, a0, b0);
+#pragma unroll
+        for (int t = 0; t < BK / 2; t += 2) {     // operands of step t+1 are in flight while step t's MFMAs issue
+            fetch(t + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+            if (t + 2 < BK / 2) fetch(t + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
         if (more) store_stage();
