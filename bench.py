@@ -105,10 +105,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_id = local_rank % max(1, ndev)                    # one GPU per rank on a real node (local_rank < ndev)
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" IS RCCL on ROCm.  VD_BENCH_BACKEND=gloo exists only to exercise the multi-process path on a 1-GPU box.
+        dist.init_process_group(os.environ.get("VD_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from villandiffusion_amd import ops
     from villandiffusion_amd.dataset import DatasetLoader
@@ -197,12 +200,14 @@ def main():
 
     # ---- roofline: per-launch HIP-event timing of the MFMA kernels over one extra training step ----
     roofline, kernels = None, None
-    if not args.no_roofline and rank == 0:
-        for _ in range(2):
+    if not args.no_roofline:
+        for _ in range(2):                       # every rank runs the step (it contains the all-reduce); rank 0 reports
             ops.profile_start()
             one_step(10_000)
             torch.cuda.synchronize()
             rec = ops.profile_stop()
+        barrier()
+    if not args.no_roofline and rank == 0:
         agg = {}
         for name, flops, e0, e1 in rec:
             a = agg.setdefault(name, [0, 0.0, 0.0])

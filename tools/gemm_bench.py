@@ -47,3 +47,18 @@ for cin, cout, H in shapes:
             print(f"   wgrad splits={splits:2d}: {flops / ms / 1e9:6.1f} TF  ({ms*1e3:.0f} us)")
         except Exception as e:
             print("   wgrad splits", splits, "failed", str(e)[:80])
+
+print("---- 1x1 wgrad (PLAIN) ----")
+for cin, cout, H in [(256, 256, 16), (256, 768, 16), (512, 256, 16), (384, 128, 32), (256, 256, 8)]:
+    x = torch.randn(B, cin, H, H, device="cuda")
+    dy = torch.randn(B, cout, H, H, device="cuda")
+    dw = torch.empty(cout, cin, device="cuda")
+    flops = 2.0 * cout * cin * B * H * H
+    for tile in (1, 3):
+        for splits in (0, 8, 32):
+            ws = torch.empty(max(64 * cout * cin, 4), device="cuda")
+            try:
+                ms = timeit(lambda: ops.conv_wgrad(dy, x, dw, B_PLAIN, ws, splits=splits, tile=tile))
+                print(f"1x1 wgrad {cin}->{cout}@{H}: tile{tile} splits={splits}: {flops / ms / 1e9:6.1f} TF ({ms*1e3:.0f} us)")
+            except Exception as e:
+                print("fail", str(e)[:60])

@@ -13,6 +13,7 @@
 // Reference ops replaced: F.conv2d 3x3/1x1 (ResnetBlock2D, Downsample2D, Upsample2D, conv_in/out), F.linear
 // (time embedding, attention projections), torch.bmm (attention) -- diffusers UNet2DModel reached from loss.py:993.
 #include "vd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -1126,7 +1127,8 @@ static void wgrad_patch_plan(const vd_wgrad_desc& d, int& splits, int& ks_per) {
     const int base = vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
     splits = d.splits;
     if (splits <= 0) {  // ~3 workgroups per CU, at least 8 K-steps per split
-        splits = vd_cdiv(768, base);
+        static const int target = getenv("VD_WGRAD_TARGET") ? atoi(getenv("VD_WGRAD_TARGET")) : 768;
+        splits = vd_cdiv(target, base);
         const int max_splits = ks_total / 8 > 0 ? ks_total / 8 : 1;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
