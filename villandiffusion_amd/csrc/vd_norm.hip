@@ -10,6 +10,60 @@
 
 namespace {
 
+// Register-resident variant: the whole (batch item, group) slab (<= NV float4 per thread) is read ONCE, kept in
+// registers for the mean / variance / normalise passes and written once: HBM traffic = the algorithmic 8 B / element.
+template <int NV>
+__global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out, int C,
+                                                         int HW, int G, float eps, int apply_silu, int64_t x_bs, int64_t y_bs) {
+    __shared__ float red[8];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cpg = C / G;
+    const int n4 = (cpg * HW) >> 2;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + (int64_t)g * cpg * HW);
+    f32x4* __restrict__ y4 = reinterpret_cast<f32x4*>(y + (int64_t)b * y_bs + (int64_t)g * cpg * HW);
+    const int tid = threadIdx.x;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        v[i] = (idx < n4) ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float inv_n = 1.f / (float)(cpg * HW);
+    const float mean = block_sum_256(s, red) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (tid + i * 256 < n4) {
+            const float a0 = v[i][0] - mean, a1 = v[i][1] - mean, a2 = v[i][2] - mean, a3 = v[i][3] - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(block_sum_256(q, red + 4) * inv_n + eps);
+    if (tid == 0) {
+        mean_out[blockIdx.x] = mean;
+        rstd_out[blockIdx.x] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < n4) {
+            const int c = g * cpg + (idx * 4) / HW;
+            const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = v[i][j] * ga + be;
+                o[j] = apply_silu ? z * sigmoidf_(z) : z;
+            }
+            y4[idx] = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int HW,
@@ -186,8 +240,21 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
                                 void* stream) {
     VD_REQUIRE(x && gamma && beta && y && mean && rstd, "vd_groupnorm_fwd: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "vd_groupnorm_fwd: bad dims B=%d C=%d HW=%d G=%d", B, C, HW, G);
-    hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, C, HW, G,
-                       eps, apply_silu, x_bstride, y_bstride);
+    const int64_t slab = (int64_t)(C / G) * HW;
+    const bool reg_ok = (HW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) && ((((uintptr_t)x) & 15) == 0) &&
+                        ((((uintptr_t)y) & 15) == 0) && slab <= 12 * 1024;
+#define VD_GN_FWD(NVV)                                                                                                       \
+    hipLaunchKernelGGL((gn_fwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, \
+                       C, HW, G, eps, apply_silu, x_bstride, y_bstride)
+    if (reg_ok && slab <= 1024) VD_GN_FWD(1);
+    else if (reg_ok && slab <= 2048) VD_GN_FWD(2);
+    else if (reg_ok && slab <= 4096) VD_GN_FWD(4);
+    else if (reg_ok && slab <= 8192) VD_GN_FWD(8);
+    else if (reg_ok) VD_GN_FWD(12);
+    else
+        hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, C, HW, G,
+                           eps, apply_silu, x_bstride, y_bstride);
+#undef VD_GN_FWD
     VD_LAUNCH_CHECK("vd_groupnorm_fwd");
     return 0;
 }
