@@ -418,19 +418,25 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const vd_gemm_desc d) {
 constexpr int CK = 8;
 constexpr int KSTEP = CK * 9;
 
-template <int W, int MODE>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution)
-__global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
-    constexpr int WM = 2, WN = 2, BM = 128;
-    constexpr int IMGS = (W * W >= 128) ? 1 : 128 / (W * W);   // whole images per tile for the 8x8 / 4x4 layers
-    constexpr int TR = (IMGS == 1) ? 128 / W : W;               // output rows per image in the tile
+// WN = 2: 128 x 128 tile, 3 workgroups / CU.  WN = 4: 128 x 256 tile (8 accumulators per wave, 2 workgroups / CU), used
+// where it makes the grid an exact multiple of the 512 resident workgroups (128-channel layers at 32x32: 1024 tiles of
+// 128 px on 768 slots leave a 1/3-occupied tail wave).
+template <int W, int MODE, int WN>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution)
+__global__ __launch_bounds__(NT, (WN == 4) ? 2 : 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
+    constexpr int WM = 2, BM = 128;
+    constexpr int CKK = CK;                                     // input channels per K-step
+    constexpr int KSTEPK = CKK * 9;
+    constexpr int NPIX = 64 * WN;                               // output pixels per tile
+    constexpr int IMGS = (W * W >= NPIX) ? 1 : NPIX / (W * W);  // whole images per tile for the 8x8 / 4x4 layers
+    constexpr int TR = (IMGS == 1) ? NPIX / W : W;              // output rows per image in the tile
     constexpr int PW = W + 2, PR = TR + 2;                      // halo patch per image
     constexpr int PIMG = PR * PW;
     constexpr int PLANE = IMGS * PIMG;                          // patch floats per channel
     constexpr int LDA_ = BM + 1;
-    constexpr int A_F4 = BM * KSTEP / 4 / NT;                   // 9 float4 per thread
-    constexpr int P_EL = (CK * PLANE + NT - 1) / NT;            // patch elements per thread
-    __shared__ float As[KSTEP * LDA_];
-    __shared__ float Ps[CK * PLANE];
+    constexpr int A_F4 = BM * KSTEPK / 4 / NT;                   // 9 float4 per thread
+    constexpr int P_EL = (CKK * PLANE + NT - 1) / NT;            // patch elements per thread
+    __shared__ float As[KSTEPK * LDA_];
+    __shared__ float Ps[CKK * PLANE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int tiles_m = (d.M + BM - 1) / BM;
@@ -440,10 +446,10 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
         if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     }
     const int tm = bid % tiles_m, tn = bid / tiles_m;
-    const int m0 = tm * BM, n0 = tn * 128;
+    const int m0 = tm * BM, n0 = tn * NPIX;
     int b0, y0;
     if (IMGS == 1) {
-        const int tiles_per_img = d.NP / 128;
+        const int tiles_per_img = d.NP / NPIX;
         b0 = tn / tiles_per_img;
         y0 = (tn - b0 * tiles_per_img) * TR;                    // first output row of this tile
     } else {
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
         const int img = rem / PIMG, rem2 = rem - img * PIMG;
         const int py = rem2 / PW, px = rem2 - py * PW;
         int iy = y0 + py - 1, ix = px - 1;                      // coordinates in the (virtual, MODE 2: upsampled) input
-        bool ok = e < CK * PLANE && (b0 + img) < nb_total;
+        bool ok = e < CKK * PLANE && (b0 + img) < nb_total;
         if (MODE == 2) {
             ok = ok && (unsigned)iy < (unsigned)(2 * d.H) && (unsigned)ix < (unsigned)(2 * d.W);
             iy >>= 1;
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int idx = tid + i * NT;
-            const int m = idx / (KSTEP / 4), q = idx - m * (KSTEP / 4);
+            const int m = idx / (KSTEPK / 4), q = idx - m * (KSTEPK / 4);
             const int mm = min(m0 + m, d.M - 1);
             ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)mm * d.lda + c0 * 9 + 4 * q);
         }
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int idx = tid + i * NT;
-            const int m = idx / (KSTEP / 4), q = idx - m * (KSTEP / 4);
+            const int m = idx / (KSTEPK / 4), q = idx - m * (KSTEPK / 4);
             const bool ok = m0 + m < d.M;
 #pragma unroll
             for (int j = 0; j < 4; ++j) As[(4 * q + j) * LDA_ + m] = ok ? ra[i][j] : 0.f;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
 #pragma unroll
         for (int i = 0; i < P_EL; ++i) {
             const int e = tid + i * NT;
-            if (e < CK * PLANE) Ps[e] = ((pmask >> i) & 1u) ? rp[i] : 0.f;
+            if (e < CKK * PLANE) Ps[e] = ((pmask >> i) & 1u) ? rp[i] : 0.f;
         }
     };
 
@@ -527,15 +533,15 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
         p_base[ni] = Ps + h * PLANE + img * PIMG + ty * PW + x;
     }
 
-    const int nsteps = d.C / CK;
+    const int nsteps = d.C / CKK;
     const int ks_begin = blockIdx.y * ksteps_per_split;
     const int ks_end = min(nsteps, ks_begin + ksteps_per_split);
-    load_stage(ks_begin * CK);
+    load_stage(ks_begin * CKK);
     store_stage();
     __syncthreads();
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         const bool more = ks + 1 < ks_end;
-        if (more && !(d.debug & 1)) load_stage((ks + 1) * CK);       // debug bits: timing-only ablations
+        if (more && !(d.debug & 1)) load_stage((ks + 1) * CKK);       // debug bits: timing-only ablations
         // software-pipelined operand fetch: the ds_reads of MFMA step u+1 are issued before the MFMAs of step u
         // (hipcc otherwise places each read right in front of its use and waits lgkmcnt(0): LDS latency per 4 MFMAs)
         auto fetch = [&](int u, float (&a)[WM], float (&bb)[WN]) {
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
         float a0[WM], b0[WN], a1[WM], b1[WN];
         fetch(0, a0, b0);
 #pragma unroll
-        for (int u = 0; u < (CK / 2) * 9; u += 2) {
+        for (int u = 0; u < (CKK / 2) * 9; u += 2) {
             fetch(u + 1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
-            if (u + 2 < (CK / 2) * 9) fetch(u + 2, a0, b0);
+            if (u + 2 < (CKK / 2) * 9) fetch(u + 2, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(NT, 3) void conv3_patch_kernel(const vd_gemm_desc d
     float* __restrict__ slab = d.ws + (int64_t)blockIdx.y * d.M * d.N;
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+        const int n = n0 + wn * 32 * WN + ni * 32 + (lane & 31);
         if (n >= d.N) continue;
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
@@ -636,9 +642,24 @@ static void patch_plan(const vd_gemm_desc& d, int& splits, int& ks_per) {
     splits = vd_cdiv(nsteps, ks_per);
 }
 
+// 128 x 256 tiles where that makes the grid a multiple of the 512 co-resident workgroups (2 / CU).
+static bool patch_wide(const vd_gemm_desc& d) {
+    if (d.OW != 32 || d.NP % 256 != 0) return false;
+    const int64_t wgs = (int64_t)vd_cdiv(d.M, 128) * (d.N / 256);
+    return wgs >= 512 && wgs % 512 == 0;
+}
+
 static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
     int splits, ks_per;
     patch_plan(d, splits, ks_per);
+    const int mode_ = d.b_mode == VD_B_CONV3 ? 0 : (d.b_mode == VD_B_CONV3_T ? 1 : 2);
+    if (splits == 1 && patch_wide(d)) {
+        dim3 grid(vd_cdiv(d.M, 128) * (d.N / 256), 1);
+        if (mode_ == 0) hipLaunchKernelGGL((conv3_patch_kernel<32, 0, 4>), grid, dim3(NT), 0, st, d, ks_per);
+        else if (mode_ == 1) hipLaunchKernelGGL((conv3_patch_kernel<32, 1, 4>), grid, dim3(NT), 0, st, d, ks_per);
+        else hipLaunchKernelGGL((conv3_patch_kernel<32, 2, 4>), grid, dim3(NT), 0, st, d, ks_per);
+        return 0;
+    }
     if (splits > 1 && d.ws == nullptr) {
         vd_set_error("vd_gemm: split-K workspace required (%d splits): query vd_gemm_ws_floats()", splits);
         return VD_EINVAL;
@@ -648,7 +669,7 @@ static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
     bool done = false;
 #define VD_PATCH_CASE(WW, MD)                                                                            \
     if (!done && d.OW == WW && mode == MD) {                                                             \
-        hipLaunchKernelGGL((conv3_patch_kernel<WW, MD>), grid, dim3(NT), 0, st, d, ks_per);              \
+        hipLaunchKernelGGL((conv3_patch_kernel<WW, MD, 2>), grid, dim3(NT), 0, st, d, ks_per);              \
         done = true;                                                                                     \
     }
     VD_PATCH_CASE(32, 0) VD_PATCH_CASE(32, 1) VD_PATCH_CASE(32, 2)
@@ -1299,7 +1320,11 @@ extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
 extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
-    if (patch_eligible(d)) return 4;
+    if (patch_eligible(d)) {
+        int splits, ks_per;
+        patch_plan(d, splits, ks_per);
+        return (splits == 1 && patch_wide(d)) ? 6 : 4;      // 6: the 128 x 256 tile variant of the patch kernel
+    }
     if (plain_eligible(d)) return 5;
     int max_bn = 128;
     if (d.a_bstride != 0 && d.NP % 128 != 0) max_bn = 64;
@@ -1327,7 +1352,8 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 1: rc = launch_gemm_t<2, 2>(d, st); break;
         case 2: rc = launch_gemm_t<1, 2>(d, st); break;
         case 3: rc = launch_gemm_t<1, 1>(d, st); break;
-        case 4: rc = launch_patch(d, st); break;
+        case 4:
+        case 6: rc = launch_patch(d, st); break;
         case 5: {
             const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
             if (d.a_mode == VD_A_ROW)
