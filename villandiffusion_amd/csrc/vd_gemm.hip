@@ -1116,9 +1116,27 @@ __global__ __launch_bounds__(NT, 3) void wgrad_patch_kernel(const vd_wgrad_desc 
     }
 
     const int Ncols = d.C * 9;
-    float* __restrict__ out = (gridDim.y > 1) ? (d.ws + (int64_t)blockIdx.y * d.M * Ncols) : d.dW;
-    const bool accum = (gridDim.y == 1) && d.accumulate;
     const int c = c0 + wc * 32 + (lane & 31);
+    if (gridDim.y > 1) {
+        // split-K slab in the PERMUTED layout ws[z][r][m][c][3]: for one row m the 32 lanes (consecutive c) write 32 x 12 B
+        // contiguous bytes, instead of 12-B pieces at a 36-B stride in the weight layout; slab_reduce_perm_kernel un-permutes.
+        float* __restrict__ slab = d.ws + (int64_t)blockIdx.y * d.M * Ncols + (int64_t)r * d.M * d.C * 3;
+        if (c < d.C) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = m0 + wm * 64 + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    if (m >= d.M) continue;
+                    float* __restrict__ o = slab + ((int64_t)m * d.C + c) * 3;
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) o[sx] = acc[mi][sx][v];
+                }
+        }
+        return;
+    }
+    float* __restrict__ out = d.dW;
+    const bool accum = d.accumulate;
     if (c < d.C) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -1170,6 +1188,24 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         o4[i] = s;
     }
 }
+// Reduce of the permuted wgrad slabs ws[z][r][m][c][3] -> dW[m][c][r][3]: slab-order iteration (the splits x larger read
+// side is coalesced), fixed summation order.
+__global__ __launch_bounds__(256) void slab_reduce_perm_kernel(const float* __restrict__ ws, float* __restrict__ out, int M,
+                                                               int C, int splits, int accumulate) {
+    const int64_t n = (int64_t)M * C * 9;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = ws[i];
+        for (int z = 1; z < splits; ++z) s += ws[(int64_t)z * n + i];
+        const int sx = (int)(i % 3);
+        const int64_t t = i / 3;
+        const int c = (int)(t % C);
+        const int64_t t2 = t / C;
+        const int m = (int)(t2 % M), r = (int)(t2 / M);
+        const int64_t o = ((int64_t)m * C + c) * 9 + r * 3 + sx;
+        out[o] = accumulate ? (out[o] + s) : s;
+    }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_scalar_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                                  int64_t n, int splits, int accumulate) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1443,7 +1479,12 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
     }
     if (rc) return rc;
     VD_LAUNCH_CHECK("vd_conv_wgrad");
-    if (splits > 1) {
+    if (splits > 1 && tile == 4) {
+        const int64_t n = (int64_t)d.M * Ncols;
+        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(slab_reduce_perm_kernel, dim3(grid), dim3(256), 0, st, d.ws, d.dW, d.M, d.C, splits, d.accumulate);
+        VD_LAUNCH_CHECK("vd_conv_wgrad/reduce");
+    } else if (splits > 1) {
         const int64_t n = (int64_t)d.M * Ncols;
         if ((n & 3) == 0 && ((((uintptr_t)d.dW) & 15) == 0) && ((((uintptr_t)d.ws) & 15) == 0)) {
             const int grid = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048);
