@@ -113,6 +113,11 @@ int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* st
 /* dX[b][c][y][x] (+)= sum_{2x2} dU[b][c][2y+i][2x+j]   (Upsample2D backward). */
 int vd_sumpool2x2(const float* dU, float* dX, int B, int C, int H, int W, int64_t du_bstride, int64_t dx_bstride,
                   int accumulate, void* stream);
+/* Stride-2 conv dgrad, second half: dX[b][c][y][x] = sum_{r,s: y-r, x-s even} G[b][(c*9+r*3+s)][(y-r)/2][(x-s)/2], where
+ * G[b] = W2d^T[C*9, M] . dY[b][M, OH*OW] comes from vd_gemm (VD_A_COL, VD_B_PLAIN) -- the zero-padded (0,1,0,1) stride-2
+ * Downsample2D conv of the reference UNet (diffusers Downsample2D, padding=0). */
+int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int W, int OH, int OW, int64_t g_bstride,
+                 int64_t dx_bstride, void* stream);
 /* ws[b*ws_ld + m] = sum_p X[b][m][p]  (bias / temb-projection gradients), then vd_colsum over b. */
 int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t x_bstride, int64_t ws_ld, void* stream);
 /* out[c] (+)= sum_b ws[b*ld + c]  -- fixed order, deterministic. */

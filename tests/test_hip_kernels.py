@@ -107,6 +107,9 @@ def test_conv3x3_backward(B, Cin, Cout, H, mode):
         ops.conv3x3(dyd, wt, None, dx, mode=B_CONV3_T)
     elif mode == B_CONV3_S2:
         ops.conv3x3(dyd, wt, None, dx, mode=B_CONV3_DIL)
+        dx2 = torch.full_like(dx, 7.0)                       # the product path: plain GEMM + col2im gather
+        ops.conv3x3_s2_dgrad(dyd, wd.view(Cout, Cin * 9), dx2)
+        check(dx2, x.grad, 3e-5, "dgrad stride-2 via GEMM + col2im")
     else:
         dU = torch.empty(B, Cin, OH, OH, device=DEV)
         ops.conv3x3(dyd, wt, None, dU, mode=B_CONV3_T)

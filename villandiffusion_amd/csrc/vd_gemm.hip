@@ -1245,6 +1245,33 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict
     }
 }
 
+// col2im of the stride-2 dgrad: G[b][(c,r,s)][oy][ox] = sum_m W[m][c][r][s] dY[b][m][oy][ox] (a plain GEMM, no structural
+// zeros) is gathered into dX[b][c][y][x] = sum_{r,s : y-r, x-s even} G[b][(c,r,s)][(y-r)/2][(x-s)/2]; fixed tap order.
+__global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ G, float* __restrict__ dX, int B, int C,
+                                                        int H, int W, int OH, int OW, int64_t g_bs, int64_t dx_bs) {
+    const int64_t per = (int64_t)C * H * W, total = per * B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const int64_t q = i - (int64_t)b * per;
+        const int x = (int)(q % W);
+        const int64_t cy = q / W;
+        const int y = (int)(cy % H);
+        const int c = (int)(cy / H);
+        const float* g = G + (int64_t)b * g_bs + (int64_t)c * 9 * OH * OW;
+        float acc = 0.f;
+        for (int r = y & 1; r < 3; r += 2) {
+            const int iy = (y - r) >> 1;
+            if (y < r || iy >= OH) continue;
+            for (int s = x & 1; s < 3; s += 2) {
+                const int ix = (x - s) >> 1;
+                if (x < s || ix >= OW) continue;
+                acc += g[(r * 3 + s) * OH * OW + iy * OW + ix];
+            }
+        }
+        dX[(int64_t)b * dx_bs + q] = acc;
+    }
+}
+
 // ws[b][m] = sum_p X[b][m][p] ; one wave per (b, m) row.
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ X, float* __restrict__ ws, int B, int M, int P,
                                                      int64_t x_bs, int64_t ws_ld) {
@@ -1523,6 +1550,17 @@ extern "C" int vd_sumpool2x2(const float* dU, float* dX, int B, int C, int H, in
     hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dU, dX, B, C, H, W, du_bstride,
                        dx_bstride, accumulate);
     VD_LAUNCH_CHECK("vd_sumpool2x2");
+    return 0;
+}
+
+extern "C" int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int W, int OH, int OW, int64_t g_bstride,
+                            int64_t dx_bstride, void* stream) {
+    VD_REQUIRE(G && dX && B > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "vd_col2im_s2: bad args");
+    const int64_t total = (int64_t)B * C * H * W;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G, dX, B, C, H, W, OH, OW, g_bstride,
+                       dx_bstride);
+    VD_LAUNCH_CHECK("vd_col2im_s2");
     return 0;
 }
 

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),
     "vd_weight_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
+    "vd_col2im_s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_rowsum": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_colsum": (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     "vd_groupnorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i64, _i64, _vp]),

@@ -73,11 +73,11 @@ class _Conv:
                        accumulate=True)
         if dx is None:
             return None
+        if self.mode == B_CONV3_S2:
+            return ops.conv3x3_s2_dgrad(dout, self.w2d(), dx)
         wt = net.wt_view(self.prefix, self.cout, self.cin, 9)     # [C, M*9]
         if self.mode == B_CONV3:
             ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T)
-        elif self.mode == B_CONV3_S2:
-            ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_DIL)
         elif self.mode == B_CONV3_UP:
             B, _, OH, OW = dout.shape
             dU = torch.empty((B, self.cin, OH, OW), device=dout.device, dtype=torch.float32)
