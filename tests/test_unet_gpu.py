@@ -116,3 +116,52 @@ def test_gradient_buckets_are_final_when_their_hook_fires(pair):
         assert torch.equal(snaps[i], net.flat_grad[s:e]), i
         assert float(snaps[i].abs().max()) > 0
     net.zero_grad()
+
+
+def _fwd_bwd_parity(cfg, B, tol_f=1e-4, tol_g=1e-3, seed=0):
+    torch.manual_seed(seed)
+    ref = UNet2DModelRef(**cfg)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    net = UNet2DModel(**cfg)
+    net.load_state_dict(ref.state_dict())
+    S, Cin = cfg["sample_size"], cfg.get("in_channels", 3)
+    x = torch.randn(B, Cin, S, S, generator=torch.Generator().manual_seed(seed + 1))
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(seed + 2))
+    y_ref = ref(x, t)[0]
+    w = torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(seed + 3))
+    (y_ref * w).sum().backward()
+    net.zero_grad()
+    y = net(x.cuda(), t.cuda())[0]
+    ef = rel(y, y_ref)
+    (y * w.cuda()).sum().backward()
+    gref = {n: p.grad for n, p in ref.named_parameters()}
+    gmax = max(float(g.abs().max()) for g in gref.values())
+    worst = (0.0, "")
+    for n, p in net.named_parameters():
+        a, b = p.grad.detach().double().cpu(), gref[n].double()
+        e = float((a - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        if e > worst[0]:
+            worst = (e, n)
+    print(f"[parity] fwd rel_err={ef:.3e}; worst param-grad rel_err={worst[0]:.3e} at {worst[1]}")
+    assert ef < tol_f, ef
+    assert worst[0] < tol_g, worst
+
+
+def test_multihead_attention_config_matches_oracle():
+    """attention_head_dim != None (the LDM UNet of BASELINE config #5 uses head_dim 32): heads are channel slices."""
+    cfg = dict(sample_size=32, block_out_channels=(32, 64, 64),
+               down_block_types=("DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"),
+               up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"), layers_per_block=1, norm_num_groups=8,
+               attention_head_dim=8)
+    _fwd_bwd_parity(cfg, B=3)
+
+
+def test_celebahq256_config_matches_oracle():
+    """BASELINE config #4: the google/ddpm-ema-celebahq-256 architecture (6 levels, attention at 16x16), B=1."""
+    cfg = dict(sample_size=256, block_out_channels=(128, 128, 256, 256, 512, 512),
+               down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4)
+    _fwd_bwd_parity(cfg, B=1)

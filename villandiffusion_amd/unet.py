@@ -182,15 +182,19 @@ class _Resnet:
 
 
 class _Attn:
-    """Single-head spatial self-attention in NCHW (no transposes): see csrc/vd_attn.hip."""
+    """Spatial self-attention in NCHW (no transposes): see csrc/vd_attn.hip.  heads = ch // attention_head_dim (1 for
+    the DDPM checkpoints); a head is a channel slice of q/k/v, so multi-head is the same GEMMs on offset views."""
 
-    def __init__(self, net, prefix, ch):
+    def __init__(self, net, prefix, ch, head_dim=None):
         self.net, self.prefix, self.ch = net, prefix, ch
+        self.heads = 1 if head_dim is None else ch // head_dim
+        if ch % self.heads:
+            raise ValueError(f"{prefix}: {ch} channels do not split into heads of {head_dim}")
         self.norm = _Norm(net, prefix + ".group_norm", ch, False)
         self.qkv_w, self.qkv_b = net._decl_qkv(prefix, ch)
         net._decl(prefix + ".to_out.0.weight", (ch, ch), fan_in=ch)
         net._decl(prefix + ".to_out.0.bias", (ch,), fan_in=ch, is_bias=True)
-        self.scale = 1.0 / math.sqrt(ch)
+        self.scale = 1.0 / math.sqrt(ch // self.heads)
 
     def fwd(self, x, out, st, save):
         net, Cc = self.net, self.ch
@@ -202,8 +206,20 @@ class _Attn:
         qkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv)
         o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
-        P = torch.empty((B, N, N), device=dev, dtype=torch.float32)
-        if N <= 64:
+        nh, dh = self.heads, Cc // self.heads
+        P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
+        if nh > 1:
+            bs = 3 * Cc * N
+            for h in range(nh):
+                q, k = qkv[:, h * dh:(h + 1) * dh], qkv[:, Cc + h * dh:Cc + (h + 1) * dh]
+                ops.gemm(k, q, P[:, h], M=N, N=B * N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
+                         b_bstride=bs, ldd=N, d_bstride=nh * N * N, alpha=self.scale)
+            ops.softmax_col_fwd(P, B * nh, N)
+            for h in range(nh):
+                v = qkv[:, 2 * Cc + h * dh:2 * Cc + (h + 1) * dh]
+                ops.gemm(v, P[:, h], o[:, h * dh:(h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N,
+                         lda=N, a_bstride=bs, ldb=N, b_bstride=nh * N * N, ldd=N, d_bstride=Cc * N)
+        elif N <= 64:
             ops.attn_small_fwd(qkv, o, P, Cc, N, self.scale)
         else:
             q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
@@ -235,7 +251,24 @@ class _Attn:
         ops.gemm(wo, dout, do, M=Cc, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
                  b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N)
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
-        if N <= 64:
+        nh, dh = self.heads, Cc // self.heads
+        if nh > 1:
+            bs, pbs = 3 * Cc * N, nh * N * N
+            dP = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
+            for h in range(nh):
+                v, doh = qkv[:, 2 * Cc + h * dh:2 * Cc + (h + 1) * dh], do[:, h * dh:(h + 1) * dh]
+                ops.gemm(doh, P[:, h], dqkv[:, 2 * Cc + h * dh:2 * Cc + (h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW,
+                         b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=Cc * N, ldb=N, b_bstride=pbs, ldd=N, d_bstride=bs)
+                ops.gemm(v, doh, dP[:, h], M=N, N=B * N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs,
+                         ldb=N, b_bstride=Cc * N, ldd=N, d_bstride=pbs)
+            ops.softmax_col_bwd(P, dP, B * nh, N, self.scale)
+            for h in range(nh):
+                q, k = qkv[:, h * dh:(h + 1) * dh], qkv[:, Cc + h * dh:Cc + (h + 1) * dh]
+                ops.gemm(k, dP[:, h], dqkv[:, h * dh:(h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N,
+                         lda=N, a_bstride=bs, ldb=N, b_bstride=pbs, ldd=N, d_bstride=bs)
+                ops.gemm(q, dP[:, h], dqkv[:, Cc + h * dh:Cc + (h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW,
+                         b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=bs, ldb=N, b_bstride=pbs, ldd=N, d_bstride=bs)
+        elif N <= 64:
             ops.attn_small_bwd(qkv, P, do, dqkv, Cc, N, self.scale)
         else:
             q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
@@ -294,8 +327,6 @@ class UNet2DModel(nn.Module):
         super().__init__()
         if time_embedding_type != "positional" or act_fn != "silu" or downsample_padding != 0 or center_input_sample:
             raise NotImplementedError("only the DDPM-style UNet2DModel configuration is implemented natively")
-        if attention_head_dim is not None:
-            raise NotImplementedError("multi-head attention blocks are not implemented (attention_head_dim must be None)")
         for t in tuple(down_block_types) + tuple(up_block_types):
             if t not in ("DownBlock2D", "AttnDownBlock2D", "UpBlock2D", "AttnUpBlock2D"):
                 raise NotImplementedError(f"block type {t}")
@@ -337,14 +368,14 @@ class UNet2DModel(nn.Module):
             for j in range(layers_per_block):
                 blk["res"].append(_Resnet(self, f"down_blocks.{i}.resnets.{j}", cin if j == 0 else ch, ch))
                 if typ == "AttnDownBlock2D":
-                    blk["attn"].append(_Attn(self, f"down_blocks.{i}.attentions.{j}", ch))
+                    blk["attn"].append(_Attn(self, f"down_blocks.{i}.attentions.{j}", ch, attention_head_dim))
                 skip_ch.append(ch)
             if i != len(boc) - 1:
                 blk["ds"] = _Conv(self, f"down_blocks.{i}.downsamplers.0.conv", ch, ch, mode=B_CONV3_S2)
                 skip_ch.append(ch)
             self.down.append(blk)
         self.mid_res = [_Resnet(self, "mid_block.resnets.0", ch, ch), _Resnet(self, "mid_block.resnets.1", ch, ch)]
-        self.mid_attn = _Attn(self, "mid_block.attentions.0", ch)
+        self.mid_attn = _Attn(self, "mid_block.attentions.0", ch, attention_head_dim)
 
         rev = boc[::-1]
         self.up: List[dict] = []
@@ -362,7 +393,7 @@ class UNet2DModel(nn.Module):
                 blk["h_ch"].append(h_ch)
                 blk["skip_ch"].append(s_ch)
                 if typ == "AttnUpBlock2D":
-                    blk["attn"].append(_Attn(self, f"up_blocks.{i}.attentions.{j}", out_ch))
+                    blk["attn"].append(_Attn(self, f"up_blocks.{i}.attentions.{j}", out_ch, attention_head_dim))
             if i != len(boc) - 1:
                 blk["us"] = _Conv(self, f"up_blocks.{i}.upsamplers.0.conv", out_ch, out_ch, mode=B_CONV3_UP)
             self.up.append(blk)
