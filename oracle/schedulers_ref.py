@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED: the scheduler
 arithmetic is in the un-vendored diffusers fork (requirement.txt:37); this file
 restates the published upstream algorithms (diffusers ~0.16: DDPMScheduler,
 DDIMScheduler, DPMSolverMultistepScheduler, UniPCMultistepScheduler,
-ScoreSdeVeScheduler) as summarised in SURVEY.md §8a rows S1-S5, with every
+ScoreSdeVeScheduler, PNDMScheduler, DEISMultistepScheduler, HeunDiscreteScheduler,
+LMSDiscreteScheduler, KarrasVeScheduler) as summarised in SURVEY.md §8a rows S1-S5, with every
 coefficient computed by the same fp32 torch op sequence upstream uses.
 Checked by analytic identities in tests/test_schedulers_oracle.py.
 """
@@ -326,6 +327,316 @@ class UniPCMultistepSchedulerRef(_MultistepBase):
         return SimpleNamespace(prev_sample=prev)
 
 
+class PNDMSchedulerRef(_VPBase):
+    """[UPSTREAM] PNDMScheduler (reference model.py:641-643 builds it with defaults: skip_prk_steps=False, set_alpha_to_one=False,
+    steps_offset=0, epsilon prediction): 4th-order Runge-Kutta warm-up (12 UNet calls) then linear multistep (PLMS)."""
+
+    def __init__(self, *a, skip_prk_steps=False, set_alpha_to_one=False, steps_offset=0, **k):
+        k.setdefault("clip_sample", False)
+        super().__init__(*a, **k)
+        self.config.skip_prk_steps, self.config.set_alpha_to_one, self.config.steps_offset = skip_prk_steps, set_alpha_to_one, steps_offset
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.pndm_order = 4
+        self.cur_model_output, self.counter, self.cur_sample, self.ets = 0, 0, None, []
+        self.prk_timesteps = self.plms_timesteps = None
+
+    def set_timesteps(self, n: int):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = n
+        step_ratio = T // n
+        self._timesteps = (np.arange(0, n) * step_ratio).round() + self.config.steps_offset
+        if self.config.skip_prk_steps:
+            self.prk_timesteps = np.array([])
+            self.plms_timesteps = np.concatenate([self._timesteps[:-1], self._timesteps[-2:-1], self._timesteps[-1:]])[::-1].copy()
+        else:
+            prk = np.array(self._timesteps[-self.pndm_order:]).repeat(2) + np.tile(np.array([0, T // n // 2]), self.pndm_order)
+            self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+            self.plms_timesteps = self._timesteps[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64))
+        self.ets, self.counter, self.cur_model_output, self.cur_sample = [], 0, 0, None
+
+    def step(self, model_output, timestep, sample, **_):
+        if self.counter < len(self.prk_timesteps) and not self.config.skip_prk_steps:
+            return self.step_prk(model_output, int(timestep), sample)
+        return self.step_plms(model_output, int(timestep), sample)
+
+    def step_prk(self, model_output, timestep, sample):
+        T, n = self.config.num_train_timesteps, self.num_inference_steps
+        diff_to_prev = 0 if self.counter % 2 else T // n // 2
+        prev_timestep = timestep - diff_to_prev
+        timestep = int(self.prk_timesteps[self.counter // 4 * 4])
+        if self.counter % 4 == 0:
+            self.cur_model_output = self.cur_model_output + 1 / 6 * model_output
+            self.ets.append(model_output)
+            self.cur_sample = sample
+        elif (self.counter - 1) % 4 == 0:
+            self.cur_model_output = self.cur_model_output + 1 / 3 * model_output
+        elif (self.counter - 2) % 4 == 0:
+            self.cur_model_output = self.cur_model_output + 1 / 3 * model_output
+        elif (self.counter - 3) % 4 == 0:
+            model_output = self.cur_model_output + 1 / 6 * model_output
+            self.cur_model_output = 0
+        cur_sample = self.cur_sample if self.cur_sample is not None else sample
+        prev = self._get_prev_sample(cur_sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return SimpleNamespace(prev_sample=prev)
+
+    def step_plms(self, model_output, timestep, sample):
+        T, n = self.config.num_train_timesteps, self.num_inference_steps
+        prev_timestep = timestep - T // n
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep = timestep
+            timestep = timestep + T // n
+        e = self.ets
+        if len(e) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(e) == 1 and self.counter == 1:
+            model_output = (model_output + e[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(e) == 2:
+            model_output = (3 * e[-1] - e[-2]) / 2
+        elif len(e) == 3:
+            model_output = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4])
+        prev = self._get_prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return SimpleNamespace(prev_sample=prev)
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        sample_coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        return sample_coeff * sample - (a_prev - a_t) * model_output / denom
+
+
+class DEISMultistepSchedulerRef(_MultistepBase):
+    """[UPSTREAM] DEISMultistepScheduler (reference model.py:644-646, defaults: solver_order=2, algorithm_type 'deis',
+    solver_type 'logrho', lower_order_final=True): exponential integrator with a log-rho polynomial fit of eps."""
+
+    def __init__(self, *a, lower_order_final=True, **k):
+        super().__init__(*a, **k)
+        self.config.lower_order_final = lower_order_final
+
+    def convert_model_output(self, eps, t, sample):
+        a, sg = self.alpha_t[t], self.sigma_t[t]
+        x0 = (sample - sg * eps) / a
+        return (sample - a * x0) / sg            # upstream round-trips eps through x0 (thresholding hook)
+
+    def _first(self, m, s, t, x):
+        h = self.lambda_t[t] - self.lambda_t[s]
+        return (self.alpha_t[t] / self.alpha_t[s]) * x - (self.sigma_t[t] * (torch.exp(h) - 1.0)) * m
+
+    def _second(self, ms, ss, t, x):
+        s0, s1 = ss[-1], ss[-2]
+        m0, m1 = ms[-1], ms[-2]
+        at, a0, a1 = self.alpha_t[t], self.alpha_t[s0], self.alpha_t[s1]
+        rt, r0, r1 = self.sigma_t[t] / at, self.sigma_t[s0] / a0, self.sigma_t[s1] / a1
+
+        def ind(t_, b, c):
+            return t_ * (-torch.log(c) + torch.log(t_) - 1) / (torch.log(b) - torch.log(c))
+
+        c1 = ind(rt, r0, r1) - ind(r0, r0, r1)
+        c2 = ind(rt, r1, r0) - ind(r0, r1, r0)
+        return at * (x / a0 + c1 * m0 + c2 * m1)
+
+    def _third(self, ms, ss, t, x):
+        s0, s1, s2 = ss[-1], ss[-2], ss[-3]
+        m0, m1, m2 = ms[-1], ms[-2], ms[-3]
+        at, a0, a1, a2 = self.alpha_t[t], self.alpha_t[s0], self.alpha_t[s1], self.alpha_t[s2]
+        rt, r0, r1, r2 = self.sigma_t[t] / at, self.sigma_t[s0] / a0, self.sigma_t[s1] / a1, self.sigma_t[s2] / a2
+
+        def ind(t_, b, c, d):
+            lt, lb, lc, ld = torch.log(t_), torch.log(b), torch.log(c), torch.log(d)
+            num = t_ * (lc * (ld - lt + 1) - ld * lt + ld + lt ** 2 - 2 * lt + 2)
+            return num / ((lb - lc) * (lb - ld))
+
+        c1 = ind(rt, r0, r1, r2) - ind(r0, r0, r1, r2)
+        c2 = ind(rt, r1, r2, r0) - ind(r0, r1, r2, r0)
+        c3 = ind(rt, r2, r0, r1) - ind(r0, r2, r0, r1)
+        return at * (x / a0 + c1 * m0 + c2 * m1 + c3 * m2)
+
+    step = DPMSolverMultistepSchedulerRef.step
+
+
+class _SigmaBase(_VPBase):
+    """k-diffusion style samplers on the VP model: sigma = sqrt((1-abar)/abar), state x_sigma = x_vp * sqrt(sigma^2+1)."""
+
+    def _interp_sigmas(self, n):
+        T = self.config.num_train_timesteps
+        ts = np.linspace(0, T - 1, n, dtype=float)[::-1].copy()
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        return ts, np.concatenate([sig, [0.0]]).astype(np.float32)
+
+
+class HeunDiscreteSchedulerRef(_SigmaBase):
+    """[UPSTREAM] HeunDiscreteScheduler (reference model.py:647-649): Heun's 2nd-order method in sigma space (Karras
+    et al. 2022, Alg. 1 with gamma=0); 2n-1 UNet calls; timesteps are floats, every inner one repeated."""
+
+    def __init__(self, *a, **k):
+        k.setdefault("clip_sample", False)
+        super().__init__(*a, **k)
+        self.set_timesteps(self.config.num_train_timesteps)
+
+    def set_timesteps(self, n: int):
+        self.num_inference_steps = n
+        ts, sig = self._interp_sigmas(n)
+        sig = torch.from_numpy(sig)
+        self.sigmas = torch.cat([sig[:1], sig[1:-1].repeat_interleave(2), sig[-1:]])
+        self.init_noise_sigma = self.sigmas.max()
+        ts = torch.from_numpy(ts)
+        self.timesteps = torch.cat([ts[:1], ts[1:].repeat_interleave(2)])
+        self.prev_derivative = self.dt = self.sample = None
+
+    @property
+    def state_in_first_order(self):
+        return self.dt is None
+
+    def index_for_timestep(self, timestep):
+        idx = (self.timesteps == timestep).nonzero()
+        return int(idx[-1 if self.state_in_first_order else 0].item())
+
+    def scale_model_input(self, sample, timestep):
+        sigma = self.sigmas[self.index_for_timestep(timestep)]
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output, timestep, sample, **_):
+        i = self.index_for_timestep(timestep)
+        if self.state_in_first_order:
+            sigma, sigma_next = self.sigmas[i], self.sigmas[i + 1]
+        else:
+            sigma, sigma_next = self.sigmas[i - 1], self.sigmas[i]
+        sigma_hat = sigma * (0 + 1)
+        sigma_input = sigma_hat if self.state_in_first_order else sigma_next
+        pred_original = sample - sigma_input * model_output
+        if self.state_in_first_order:
+            derivative = (sample - pred_original) / sigma_hat
+            dt = sigma_next - sigma_hat
+            self.prev_derivative, self.dt, self.sample = derivative, dt, sample
+        else:
+            derivative = (sample - pred_original) / sigma_next
+            derivative = (self.prev_derivative + derivative) / 2
+            dt, sample = self.dt, self.sample
+            self.prev_derivative = self.dt = self.sample = None
+        return SimpleNamespace(prev_sample=sample + derivative * dt)
+
+
+class LMSDiscreteSchedulerRef(_SigmaBase):
+    """[UPSTREAM] LMSDiscreteScheduler (reference model.py:650-652): linear multistep (order 4) in sigma space, the
+    Lagrange-basis integrals by scipy.integrate.quad(epsrel=1e-4) as upstream."""
+
+    def __init__(self, *a, **k):
+        k.setdefault("clip_sample", False)
+        super().__init__(*a, **k)
+        self.set_timesteps(self.config.num_train_timesteps)
+
+    def set_timesteps(self, n: int):
+        self.num_inference_steps = n
+        ts, sig = self._interp_sigmas(n)
+        self.sigmas = torch.from_numpy(sig)
+        self.init_noise_sigma = self.sigmas.max()
+        self.timesteps = torch.from_numpy(ts)
+        self.derivatives = []
+
+    def scale_model_input(self, sample, timestep):
+        i = int((self.timesteps == timestep).nonzero().item())
+        return sample / ((self.sigmas[i] ** 2 + 1) ** 0.5)
+
+    def get_lms_coefficient(self, order, t, current_order):
+        from scipy import integrate
+
+        def lms_derivative(tau):
+            prod = 1.0
+            for k in range(order):
+                if current_order == k:
+                    continue
+                prod *= (tau - self.sigmas[t - k]) / (self.sigmas[t - current_order] - self.sigmas[t - k])
+            return prod
+
+        return integrate.quad(lms_derivative, self.sigmas[t], self.sigmas[t + 1], epsrel=1e-4)[0]
+
+    def step(self, model_output, timestep, sample, order: int = 4, **_):
+        i = int((self.timesteps == timestep).nonzero().item())
+        sigma = self.sigmas[i]
+        pred_original = sample - sigma * model_output
+        self.derivatives.append((sample - pred_original) / sigma)
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(i + 1, order)
+        coeffs = [self.get_lms_coefficient(order, i, c) for c in range(order)]
+        prev = sample + sum(c * d for c, d in zip(coeffs, reversed(self.derivatives)))
+        return SimpleNamespace(prev_sample=prev)
+
+
+class KarrasVeSchedulerRef:
+    """[UPSTREAM] KarrasVeScheduler (reference model.py:685-693, sigma_min 0.01, sigma_max 380, s_churn 80 / 100 / 0):
+    stochastic sampler of Karras et al. 2022 Alg. 2.  Upstream's `schedule` holds sigma_max^2 (sigma_min^2/sigma_max^2)^(i/(n-1))
+    and the pipeline uses those values as sigma -- reproduced as is."""
+
+    def __init__(self, sigma_min=0.02, sigma_max=100.0, s_noise=1.007, s_churn=80.0, s_min=0.05, s_max=50.0, num_train_timesteps=None):
+        self.config = SimpleNamespace(sigma_min=sigma_min, sigma_max=sigma_max, s_noise=s_noise, s_churn=s_churn, s_min=s_min,
+                                      s_max=s_max, clip_sample=False)
+        self.init_noise_sigma = sigma_max
+        self.num_inference_steps = None
+        self.timesteps = self.schedule = None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, n: int):
+        self.num_inference_steps = n
+        ts = np.arange(0, n)[::-1].copy()
+        self.timesteps = torch.from_numpy(ts)
+        c = self.config
+        sched = [c.sigma_max ** 2 * (c.sigma_min ** 2 / c.sigma_max ** 2) ** (i / (n - 1)) for i in self.timesteps]
+        self.schedule = torch.tensor(sched, dtype=torch.float32)
+
+    def add_noise_to_input(self, sample, sigma, generator=None, noise=None):
+        c = self.config
+        gamma = min(c.s_churn / self.num_inference_steps, 2 ** 0.5 - 1) if c.s_min <= sigma <= c.s_max else 0
+        eps = c.s_noise * (noise if noise is not None else _randn(sample.shape, generator, sample.device, sample.dtype))
+        sigma_hat = sigma + gamma * sigma
+        return sample + ((sigma_hat ** 2 - sigma ** 2) ** 0.5 * eps), sigma_hat
+
+    def step(self, model_output, sigma_hat, sigma_prev, sample_hat):
+        pred_original = sample_hat + sigma_hat * model_output
+        derivative = (sample_hat - pred_original) / sigma_hat
+        return SimpleNamespace(prev_sample=sample_hat + (sigma_prev - sigma_hat) * derivative, derivative=derivative,
+                               pred_original_sample=pred_original)
+
+    def step_correct(self, model_output, sigma_hat, sigma_prev, sample_hat, sample_prev, derivative):
+        pred_original = sample_prev + sigma_prev * model_output
+        derivative_corr = (sample_prev - pred_original) / sigma_prev
+        return SimpleNamespace(prev_sample=sample_hat + (sigma_prev - sigma_hat) * (0.5 * derivative + 0.5 * derivative_corr),
+                               derivative=derivative, pred_original_sample=pred_original)
+
+
+@torch.no_grad()
+def karras_ve_loop(unet, sched: KarrasVeSchedulerRef, init: torch.Tensor, n_steps: int, generator=None, noises=None):
+    """[UPSTREAM] KarrasVePipeline.__call__; `init` is the already sigma_max-scaled start (fork contract)."""
+    sched.set_timesteps(n_steps)
+    x = init
+    B = x.shape[0]
+    for k, t in enumerate(sched.timesteps):
+        sigma = sched.schedule[t]
+        sigma_prev = sched.schedule[t - 1] if t > 0 else 0
+        x_hat, sigma_hat = sched.add_noise_to_input(x, sigma, generator=generator, noise=None if noises is None else noises[k])
+        mo = (sigma_hat / 2) * unet((x_hat + 1) / 2, (sigma_hat / 2).expand(B))[0]
+        out = sched.step(mo, sigma_hat, sigma_prev, x_hat)
+        if sigma_prev != 0:
+            mo = (sigma_prev / 2) * unet((out.prev_sample + 1) / 2, (sigma_prev / 2).expand(B))[0]
+            out = sched.step_correct(mo, sigma_hat, sigma_prev, x_hat, out.prev_sample, out.derivative)
+        x = out.prev_sample
+    return x
+
+
 class ScoreSdeVeSchedulerRef:
     """S5.  Predictor-corrector VE-SDE sampler."""
 
@@ -385,9 +696,15 @@ def sample_loop(unet, sched, init: torch.Tensor, n_steps: int, generator=None, e
     """Fork pipeline contract for the VP samplers: x=init; for t: x=step(unet(x,t),t,x)."""
     sched.set_timesteps(n_steps)
     x = init
+    if float(sched.init_noise_sigma) != 1.0:          # sigma-space samplers (Heun / LMSD) start from init * sigma_max
+        x = x * sched.init_noise_sigma
     for k, t in enumerate(sched.timesteps[start_from:]):
-        tb = torch.full((x.shape[0],), int(t), dtype=torch.long)
-        eps = unet(x, tb)[0]
+        if sched.timesteps.dtype.is_floating_point:
+            tb = torch.full((x.shape[0],), float(t), dtype=torch.float32)
+        else:
+            tb = torch.full((x.shape[0],), int(t), dtype=torch.long)
+        x_in = sched.scale_model_input(x, t) if hasattr(sched, "scale_model_input") else x
+        eps = unet(x_in, tb)[0]
         kw = {}
         if isinstance(sched, DDIMSchedulerRef):
             kw["eta"] = 0.0 if eta is None else eta

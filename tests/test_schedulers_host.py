@@ -75,6 +75,16 @@ PAIRS = [
     (lambda: S.UniPCMultistepScheduler(solver_order=3), lambda: R.UniPCMultistepSchedulerRef(solver_order=3), 20, 20),
     (lambda: S.UniPCMultistepScheduler(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear"),
      lambda: R.UniPCMultistepSchedulerRef(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear"), 20, 20),
+    # SURVEY §8f.3 samplers (reference model.py:641-652)
+    (lambda: S.PNDMScheduler(), lambda: R.PNDMSchedulerRef(), 50, 100),
+    (lambda: S.PNDMScheduler(skip_prk_steps=True), lambda: R.PNDMSchedulerRef(skip_prk_steps=True), 20, 100),
+    (lambda: S.DEISMultistepScheduler(), lambda: R.DEISMultistepSchedulerRef(), 20, 20),
+    (lambda: S.DEISMultistepScheduler(solver_order=3), lambda: R.DEISMultistepSchedulerRef(solver_order=3), 20, 20),
+    (lambda: S.DEISMultistepScheduler(solver_order=3), lambda: R.DEISMultistepSchedulerRef(solver_order=3), 10, 10),
+    (lambda: S.HeunDiscreteScheduler(), lambda: R.HeunDiscreteSchedulerRef(), 20, 100),
+    (lambda: S.LMSDiscreteScheduler(), lambda: R.LMSDiscreteSchedulerRef(), 20, 100),
+    (lambda: S.LMSDiscreteScheduler(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear"),
+     lambda: R.LMSDiscreteSchedulerRef(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear"), 10, 100),
 ]
 
 
@@ -82,14 +92,21 @@ PAIRS = [
 def test_sampler_host_logic_matches_oracle(mk, mkref, n, steps):
     a, b = mk(), mkref()
     a.set_timesteps(n); b.set_timesteps(n)
-    assert torch.equal(a.timesteps, b.timesteps) and a.timesteps.dtype == torch.int64      # bit-exact index tables
+    assert torch.equal(a.timesteps, b.timesteps) and a.timesteps.dtype == b.timesteps.dtype      # bit-exact tables
+    sigma_space = hasattr(b, "sigmas")
+    assert sigma_space or a.timesteps.dtype == torch.int64
     assert torch.equal(a.alphas_cumprod, b.alphas_cumprod)
     x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(0))
+    if sigma_space:
+        assert torch.equal(a.sigmas, b.sigmas) and float(a.init_noise_sigma) == float(b.init_noise_sigma)
+        x = x * b.init_noise_sigma
     xa, xb = x.clone(), x.clone()
     ga, gb = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
     for t in a.timesteps[:steps]:
-        xa = a.step(_eps(xa, t, a.alphas_cumprod), t, xa, generator=ga).prev_sample
-        xb = b.step(_eps(xb, t, b.alphas_cumprod), t, xb, generator=gb).prev_sample
+        ia = a.scale_model_input(xa, t) if sigma_space else xa
+        ib = b.scale_model_input(xb, t) if sigma_space else xb
+        xa = a.step(_eps(ia, t, a.alphas_cumprod), t, xa, generator=ga).prev_sample
+        xb = b.step(_eps(ib, t, b.alphas_cumprod), t, xb, generator=gb).prev_sample
     err = float((xa - xb).abs().max() / xb.abs().max())
     assert err < 2e-5, err
 
@@ -135,3 +152,28 @@ def test_score_sde_ve_host_logic_matches_oracle():
         xa, xb = oa.prev_sample, ob.prev_sample
     err = float((oa.prev_sample_mean - ob.prev_sample_mean).abs().max() / ob.prev_sample_mean.abs().max())
     assert err < 1e-4, err
+
+
+def test_karras_ve_host_logic_matches_oracle(monkeypatch):
+    """KarrasVeScheduler (model.py:685-693): sigma table, churn noise injection, Euler step and 2nd-order correction."""
+    for churn in (80.0, 100.0, 0.0):
+        a = S.KarrasVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, s_churn=churn)
+        b = R.KarrasVeSchedulerRef(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, s_churn=churn)
+        a.set_timesteps(12); b.set_timesteps(12)
+        assert torch.equal(a.timesteps, b.timesteps) and torch.equal(a.schedule, b.schedule)
+        assert a.init_noise_sigma == b.init_noise_sigma == 380.0
+        f = lambda x, s: -x / (0.25 + float(s) ** 2) ** 0.5          # stand-in score network
+        x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(0)) * 380.0
+        xa, xb = x.clone(), x.clone()
+        ga, gb = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+        for t in a.timesteps.tolist():
+            sg, sp = a.schedule[t], (a.schedule[t - 1] if t > 0 else 0)
+            ha, sha = a.add_noise_to_input(xa, sg, generator=ga)
+            hb, shb = b.add_noise_to_input(xb, sg, generator=gb)
+            assert float(sha) == float(shb)
+            oa, ob = a.step(f(ha, sha), sha, sp, ha), b.step(f(hb, shb), shb, sp, hb)
+            if sp != 0:
+                oa = a.step_correct(f(oa.prev_sample, sp), sha, sp, ha, oa.prev_sample, oa.derivative)
+                ob = b.step_correct(f(ob.prev_sample, sp), shb, sp, hb, ob.prev_sample, ob.derivative)
+            xa, xb = oa.prev_sample, ob.prev_sample
+        assert float((xa - xb).abs().max() / xb.abs().max()) < 2e-5

@@ -2,6 +2,8 @@
 import numpy as np
 import torch
 
+from oracle import schedulers_ref as R
+
 from oracle.schedulers_ref import (DDIMSchedulerRef, DDPMSchedulerRef, DPMSolverMultistepSchedulerRef,
                                    ScoreSdeVeSchedulerRef, UniPCMultistepSchedulerRef, cosine_with_warmup_lambda)
 
@@ -144,3 +146,43 @@ def test_cosine_warmup():
     assert abs(cosine_with_warmup_lambda(23450, 500, 23450)) < 1e-12
     mid = 500 + (23450 - 500) // 2
     assert abs(cosine_with_warmup_lambda(mid, 500, 23450) - 0.5) < 1e-3
+
+
+def test_pndm_timestep_table_and_next_row_sampler_convergence():
+    """§8f.3 samplers.  PNDM table for (T=1000, n=50): 12 Runge-Kutta calls at 980..920 then PLMS down to 0 (59 UNet calls);
+    all of PNDM / DEIS / Heun / LMSD must converge to the exact probability-flow solution of a Gaussian data model."""
+    s = R.PNDMSchedulerRef()
+    s.set_timesteps(50)
+    assert s.timesteps[:13].tolist() == [980, 970, 970, 960, 960, 950, 950, 940, 940, 930, 930, 920, 920]
+    assert len(s.timesteps) == 59 and s.timesteps[-1] == 0 and s.timesteps.dtype == torch.int64
+    h = R.HeunDiscreteSchedulerRef()
+    h.set_timesteps(10)
+    assert len(h.timesteps) == 19 and len(h.sigmas) == 20 and float(h.sigmas[-1]) == 0.0
+    assert abs(float(h.init_noise_sigma) - float(((1 - h.alphas_cumprod[-1]) / h.alphas_cumprod[-1]) ** 0.5)) < 1e-4
+
+    ac = R._VPBase().alphas_cumprod.double()
+    sg_tab = ((1 - ac) / ac) ** 0.5
+    v0 = 0.25                                             # data ~ N(0, v0 I): eps*(x_vp, abar) = sqrt(1-abar) x / (abar v0 + 1 - abar)
+
+    def run(sc, n, x):
+        sc.set_timesteps(n)
+        sig_space = hasattr(sc, "sigmas")
+        if sig_space:
+            x = x * sc.init_noise_sigma
+        for t in sc.timesteps:
+            tf = float(t)
+            lo = int(np.floor(tf)); hi = min(lo + 1, 999); w = tf - lo
+            sig = sg_tab[lo] * (1 - w) + sg_tab[hi] * w
+            a = 1 / (sig ** 2 + 1)
+            xin = sc.scale_model_input(x, t) if sig_space else x
+            x = sc.step(((1 - a) ** 0.5 * xin / (a * v0 + 1 - a)).float(), t, x).prev_sample
+        return x
+
+    x = torch.randn(4, 3, 8, 8, generator=torch.Generator().manual_seed(0))
+    sm = float(sg_tab[999])
+    exact_vp = x * float(((v0 * ac[0] + 1 - ac[0]) / (v0 * ac[999] + 1 - ac[999])) ** 0.5)
+    exact_sigma = x * sm * (v0 / (v0 + sm ** 2)) ** 0.5
+    for mk, exact in [(R.PNDMSchedulerRef, exact_vp), (R.DEISMultistepSchedulerRef, exact_vp),
+                      (R.HeunDiscreteSchedulerRef, exact_sigma), (R.LMSDiscreteSchedulerRef, exact_sigma)]:
+        errs = [float((run(mk(), n, x.clone()) - exact).abs().max() / exact.abs().max()) for n in (20, 80)]
+        assert errs[1] < errs[0] and errs[1] < 6e-3, (mk.__name__, errs)

@@ -16,8 +16,9 @@ from typing import Optional
 
 import torch
 
-from .pipelines import DDIMPipeline, DDPMPipeline, DiffusionPipeline, PNDMPipeline, ScoreSdeVePipeline
-from .schedulers import (DDIMScheduler, DDPMScheduler, DPMSolverMultistepScheduler, ScoreSdeVeScheduler,
+from .pipelines import DDIMPipeline, DDPMPipeline, DiffusionPipeline, KarrasVePipeline, PNDMPipeline, ScoreSdeVePipeline
+from .schedulers import (DDIMScheduler, DDPMScheduler, DEISMultistepScheduler, DPMSolverMultistepScheduler,
+                         HeunDiscreteScheduler, KarrasVeScheduler, LMSDiscreteScheduler, PNDMScheduler, ScoreSdeVeScheduler,
                          UniPCMultistepScheduler)
 from .unet import UNet2DModel
 
@@ -85,9 +86,11 @@ class DiffuserModelSched:
             cls.DPM_SOLVER_PP_O2_SCHED: dpm(2, "dpmsolver++"), cls.DPM_SOLVER_O2_SCHED: dpm(2, "dpmsolver"),
             cls.DPM_SOLVER_PP_O3_SCHED: dpm(3, "dpmsolver++"), cls.DPM_SOLVER_O3_SCHED: dpm(3, "dpmsolver"),
             cls.UNIPC_SCHED: (partial(UniPCMultistepScheduler, **beta), "pndm"),
+            cls.PNDM_SCHED: (partial(PNDMScheduler, **beta), "pndm"),                      # model.py:641-652
+            cls.DEIS_SCHED: (partial(DEISMultistepScheduler, **beta), "pndm"),
+            cls.HEUN_SCHED: (partial(HeunDiscreteScheduler, **beta), "pndm"),
+            cls.LMSD_SCHED: (partial(LMSDiscreteScheduler, **beta), "pndm"),
         }
-        if noise_sched_type in (cls.PNDM_SCHED, cls.DEIS_SCHED, cls.HEUN_SCHED, cls.LMSD_SCHED):
-            raise NotImplementedError(f"sampler {noise_sched_type} is a 'next' row (SURVEY.md §8f.3)")
         if noise_sched_type not in table:
             raise NotImplementedError()
         ctor, fam = table[noise_sched_type]
@@ -137,16 +140,20 @@ class DiffuserModelSched:
         if build_model:
             raise NotImplementedError(f"pretrained VE checkpoints ('{ckpt_id}') are NCSN++ networks: a 'next' row (SURVEY.md §8f.5); "
                                       f"from-scratch ids (e.g. {cls.DDPM_32_DEFAULT}) train the DDPM-style UNet under SDE-VE")
-        if noise_sched_type not in (None, cls.SCORE_SDE_VE_SCHED):
-            if noise_sched_type in (cls.EDM_VE_SCHED, cls.EDM_VE_ODE_SCHED, cls.EDM_VE_SDE_SCHED):
-                raise NotImplementedError(f"sampler {noise_sched_type} (KarrasVe) is a 'next' row (SURVEY.md §8f.3)")
+        karras = {cls.EDM_VE_SCHED: {}, cls.EDM_VE_SDE_SCHED: {"s_churn": 100}, cls.EDM_VE_ODE_SCHED: {"s_churn": 0}}   # model.py:685-693
+        if noise_sched_type in karras:
+            sched = KarrasVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, **karras[noise_sched_type])
+            pipe_cls = KarrasVePipeline
+        elif noise_sched_type in (None, cls.SCORE_SDE_VE_SCHED):
+            sched = ScoreSdeVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, sampling_eps=1e-05, correct_steps=1,
+                                        snr=0.075)
+            pipe_cls = ScoreSdeVePipeline
+        else:
             raise NotImplementedError()
-        sched = ScoreSdeVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, sampling_eps=1e-05, correct_steps=1,
-                                    snr=0.075)
         clip = cls.get_sample_clip(clip_sample, cls.CLIP_SAMPLE_DEFAULT)
         if clip is not None:
             sched.config.clip_sample = clip
-        return None, None, sched, cls._pipeline_factory(ScoreSdeVePipeline)
+        return None, None, sched, cls._pipeline_factory(pipe_cls)
 
     @classmethod
     def _get_model_sched(cls, ckpt_id, clip_sample, clip_sample_range=None, noise_sched_type=None, sde_type=SDE_VP,

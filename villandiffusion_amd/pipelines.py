@@ -78,8 +78,12 @@ class DiffusionPipeline:
         t_tab = ts.to(torch.float32).to(dev)[:, None].expand(len(ts), batch_size).contiguous()
         movie = [_post(x)] if (save_every_step or init is not None) else []
         kw = self._step_kwargs(generator, eta)
-        for k, t in enumerate(ts.tolist()):
-            eps = unet(x, t_tab[k], return_dict=False)[0]
+        sigma_space = float(sched.init_noise_sigma) != 1.0      # Heun / LMSD: state lives in sigma space (schedulers._SigmaSpace)
+        if sigma_space and start_from == 0:
+            x = ops.lincomb(torch.empty_like(x), [x], [float(sched.init_noise_sigma)])
+        for k, t in enumerate(ts if sigma_space else ts.tolist()):
+            x_in = sched.scale_model_input(x, t) if sigma_space else x
+            eps = unet(x_in, t_tab[k], return_dict=False)[0]
             x = sched.step(eps, t, x, **kw).prev_sample
             if save_every_step:
                 movie.append(_post(x))
@@ -194,6 +198,54 @@ class ScoreSdeVePipeline(DiffusionPipeline):
         if return_tensor:
             return mean
         return SimpleNamespace(images=post(mean), movie=movie)
+
+
+class KarrasVePipeline(DiffusionPipeline):
+    """[UPSTREAM] KarrasVePipeline (reference model.py:685-693): stochastic 2nd-order sampler of Karras et al. 2022; the
+    UNet is called as  (sigma/2) * unet((x+1)/2, sigma/2)  twice per step (predictor + Heun-style correction)."""
+    _class_name = "KarrasVePipeline"
+    default_steps = 50
+
+    @torch.no_grad()
+    def __call__(self, batch_size: int = 1, generator=None, init=None, num_inference_steps: Optional[int] = None, start_from: int = 0,
+                 save_every_step: bool = False, output_type=None, return_dict: bool = True, return_tensor: bool = False, **_):
+        unet, sched, dev = self.unet, self.scheduler, self.device
+        n = num_inference_steps if num_inference_steps is not None else self.default_steps
+        shape = (batch_size, unet.in_channels, unet.sample_size, unet.sample_size)
+        if init is None:
+            z = torch.randn(shape, generator=generator) if (generator is None or generator.device.type == "cpu") else \
+                torch.randn(shape, generator=generator, device=dev)
+            x = (z * sched.init_noise_sigma).to(dev)
+        else:
+            x = init.to(dev).float().contiguous()
+            batch_size = x.shape[0]
+        sched.set_timesteps(n)
+        B, C, H, W = x.shape
+        inf = float("inf")
+
+        def half(t):          # (t + 1) / 2 on the device
+            return ops.postprocess(t.contiguous(), torch.empty_like(t), 0.5, 0.5, -inf, inf, False)
+
+        def model(xx, sigma):
+            sig = torch.full((batch_size,), float(sigma) / 2, device=dev, dtype=torch.float32)
+            mo = unet(half(xx), sig, return_dict=False)[0]
+            return ops.lincomb(torch.empty_like(mo), [mo.contiguous()], [float(sigma) / 2])
+
+        movie = [_post(x)] if (save_every_step or init is not None) else []
+        for t in sched.timesteps[start_from:].tolist():
+            sigma = sched.schedule[t]
+            sigma_prev = sched.schedule[t - 1] if t > 0 else 0
+            x_hat, sigma_hat = sched.add_noise_to_input(x, sigma, generator=generator)
+            out = sched.step(model(x_hat, sigma_hat), sigma_hat, sigma_prev, x_hat)
+            if sigma_prev != 0:
+                out = sched.step_correct(model(out.prev_sample, sigma_prev), sigma_hat, sigma_prev, x_hat, out.prev_sample,
+                                         out.derivative)
+            x = out.prev_sample
+            if save_every_step:
+                movie.append(_post(x))
+        if return_tensor:
+            return x
+        return SimpleNamespace(images=_post(x), movie=movie)
 
 
 class PNDMPipeline(DiffusionPipeline):

@@ -1,4 +1,5 @@
-"""Reverse-diffusion samplers (S1-S4 of SURVEY.md §8a) with the per-step tensor update on the GPU.
+"""Reverse-diffusion samplers (S1-S5 of SURVEY.md §8a, plus the §8f.3 ones: PNDM, DEIS, Heun, LMSD, KarrasVe) with the
+per-step tensor update on the GPU.
 
 Same surface the reference touches on its diffusers schedulers (model.py:599-665, loss.py:830-834,
 VillanDiffusion.py:1151): ``.betas/.alphas/.alphas_cumprod`` (fp32, CPU), ``.config.num_train_timesteps``,
@@ -362,6 +363,300 @@ class UniPCMultistepScheduler(_Multistep):
         return SimpleNamespace(prev_sample=out)
 
 
+class PNDMScheduler(SchedulerBase):
+    """[UPSTREAM] PNDMScheduler as the reference builds it (model.py:641-643): Runge-Kutta warm-up then PLMS.  Every step
+    is ONE vd_lincomb: the RK / Adams-Bashforth weights of the stored eps history are folded into per-tensor scalars."""
+    _class_name = "PNDMScheduler"
+
+    def __init__(self, *a, skip_prk_steps=False, set_alpha_to_one=False, steps_offset=0, **k):
+        k.setdefault("clip_sample", False)
+        super().__init__(*a, skip_prk_steps=skip_prk_steps, set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset, **k)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.pndm_order = 4
+        self.prk_timesteps = self.plms_timesteps = None
+        self._reset()
+
+    def _reset(self):
+        self.counter, self.cur_sample, self.ets = 0, None, []
+        self._rk: List[torch.Tensor] = []            # eps of the current Runge-Kutta stage sequence
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T, n = self.config.num_train_timesteps, num_inference_steps
+        self.num_inference_steps = n
+        base = (np.arange(0, n) * (T // n)).round() + self.config.steps_offset
+        if self.config.skip_prk_steps:
+            self.prk_timesteps = np.array([])
+            self.plms_timesteps = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+        else:
+            prk = np.array(base[-self.pndm_order:]).repeat(2) + np.tile(np.array([0, T // n // 2]), self.pndm_order)
+            self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+            self.plms_timesteps = base[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64))
+        self._reset()
+
+    def _prev(self, sample, t, prev_t, outs: List[torch.Tensor], weights: List[float]):
+        """x_prev = c_s*sample - c_m * sum_j w_j outs_j  (upstream _get_prev_sample with model_output = sum_j w_j outs_j)."""
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        c_s = (a_prev / a_t) ** 0.5
+        c_m = -float((a_prev - a_t) / (a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5))
+        return ops.lincomb(torch.empty_like(sample), [sample.contiguous()] + [o.contiguous() for o in outs],
+                           [float(c_s)] + [c_m * w for w in weights])
+
+    def step(self, model_output, timestep, sample, return_dict=True, **_):
+        t = int(timestep)
+        T, n = self.config.num_train_timesteps, self.num_inference_steps
+        if self.counter < len(self.prk_timesteps) and not self.config.skip_prk_steps:
+            c = self.counter
+            prev_t = t - (0 if c % 2 else T // n // 2)
+            t0 = int(self.prk_timesteps[c // 4 * 4])
+            stage = c % 4
+            if stage == 0:
+                self._rk = [model_output]
+                self.ets.append(model_output)
+                self.cur_sample = sample
+            else:
+                self._rk.append(model_output)
+            if stage == 3:
+                outs, w = self._rk, [1 / 6, 1 / 3, 1 / 3, 1 / 6]
+            else:
+                outs, w = [model_output], [1.0]
+            out = self._prev(self.cur_sample if self.cur_sample is not None else sample, t0, prev_t, outs, w)
+            self.counter += 1
+            return SimpleNamespace(prev_sample=out)
+        prev_t = t - T // n
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_t, t = t, t + T // n
+        e = self.ets
+        if len(e) == 1 and self.counter == 0:
+            outs, w = [model_output], [1.0]
+            self.cur_sample = sample
+        elif len(e) == 1 and self.counter == 1:
+            outs, w = [model_output, e[-1]], [0.5, 0.5]
+            sample, self.cur_sample = self.cur_sample, None
+        elif len(e) == 2:
+            outs, w = [e[-1], e[-2]], [1.5, -0.5]
+        elif len(e) == 3:
+            outs, w = [e[-1], e[-2], e[-3]], [23 / 12, -16 / 12, 5 / 12]
+        else:
+            outs, w = [e[-1], e[-2], e[-3], e[-4]], [55 / 24, -59 / 24, 37 / 24, -9 / 24]
+        out = self._prev(sample, t, prev_t, outs, w)
+        self.counter += 1
+        return SimpleNamespace(prev_sample=out)
+
+
+class DEISMultistepScheduler(_Multistep):
+    """[UPSTREAM] DEISMultistepScheduler (reference model.py:644-646: defaults, order 2, 'deis' / 'logrho')."""
+    _class_name = "DEISMultistepScheduler"
+
+    def __init__(self, *a, algorithm_type="deis", solver_type="logrho", lower_order_final=True, **k):
+        super().__init__(*a, algorithm_type=algorithm_type, solver_type=solver_type, lower_order_final=lower_order_final, **k)
+        if algorithm_type != "deis" or solver_type != "logrho":
+            raise NotImplementedError(f"{algorithm_type}/{solver_type}")
+
+    def convert_model_output(self, eps, t, sample):
+        """upstream: eps -> x0 -> eps round trip (the x0 leg is the thresholding hook)."""
+        x0 = self._x0_pred(eps, t, sample)
+        return ops.lincomb(torch.empty_like(sample), [sample.contiguous(), x0],
+                           [float(1.0 / self.sigma_t[t]), -float(self.alpha_t[t] / self.sigma_t[t])])
+
+    def _coefs(self, ss: List[int], t: int):
+        al, sg, lam = self.alpha_t.double(), self.sigma_t.double(), self.lambda_t.double()
+        s0 = ss[-1]
+        at = float(al[t])
+        if len(ss) == 1:
+            h = float(lam[t] - lam[s0])
+            return float(al[t] / al[s0]), [-float(sg[t]) * (math.exp(h) - 1.0)]
+        rho = lambda u: float(sg[u] / al[u])
+        lg = math.log
+        if len(ss) == 2:
+            rt, r0, r1 = rho(t), rho(s0), rho(ss[-2])
+            ind = lambda q, b, c: q * (-lg(c) + lg(q) - 1) / (lg(b) - lg(c))
+            c1 = ind(rt, r0, r1) - ind(r0, r0, r1)
+            c2 = ind(rt, r1, r0) - ind(r0, r1, r0)
+            return at / float(al[s0]), [at * c1, at * c2]
+        rt, r0, r1, r2 = rho(t), rho(s0), rho(ss[-2]), rho(ss[-3])
+
+        def ind(q, b, c, d):
+            lq, lb, lc, ld = lg(q), lg(b), lg(c), lg(d)
+            return q * (lc * (ld - lq + 1) - ld * lq + ld + lq ** 2 - 2 * lq + 2) / ((lb - lc) * (lb - ld))
+
+        c1 = ind(rt, r0, r1, r2) - ind(r0, r0, r1, r2)
+        c2 = ind(rt, r1, r2, r0) - ind(r0, r1, r2, r0)
+        c3 = ind(rt, r2, r0, r1) - ind(r0, r2, r0, r1)
+        return at / float(al[s0]), [at * c1, at * c2, at * c3]
+
+    step = DPMSolverMultistepScheduler.step
+
+
+class _SigmaSpace(SchedulerBase):
+    """k-diffusion style samplers on the VP network: sigma = sqrt((1-abar)/abar); the state is x_vp*sqrt(sigma^2+1), so the
+    pipeline starts from init*init_noise_sigma and feeds the UNet scale_model_input(x, t) with FLOAT timesteps."""
+
+    def __init__(self, *a, **k):
+        k.setdefault("clip_sample", False)
+        super().__init__(*a, **k)
+        self.set_timesteps(self.config.num_train_timesteps)
+
+    def _interp_sigmas(self, n):
+        T = self.config.num_train_timesteps
+        ts = np.linspace(0, T - 1, n, dtype=float)[::-1].copy()
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        return ts, np.concatenate([sig, [0.0]]).astype(np.float32)
+
+    def _scaled(self, sample, sigma):
+        return ops.lincomb(torch.empty_like(sample), [sample.contiguous()], [float(1.0 / ((sigma ** 2 + 1) ** 0.5))])
+
+
+class HeunDiscreteScheduler(_SigmaSpace):
+    """[UPSTREAM] HeunDiscreteScheduler (reference model.py:647-649): 2n-1 UNet calls, inner timesteps repeated."""
+    _class_name = "HeunDiscreteScheduler"
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ts, sig = self._interp_sigmas(num_inference_steps)
+        sig = torch.from_numpy(sig)
+        self.sigmas = torch.cat([sig[:1], sig[1:-1].repeat_interleave(2), sig[-1:]])
+        self.init_noise_sigma = self.sigmas.max()
+        ts = torch.from_numpy(ts)
+        self.timesteps = torch.cat([ts[:1], ts[1:].repeat_interleave(2)])
+        self._eps1 = self._x1 = self._s = None
+
+    @property
+    def state_in_first_order(self):
+        return self._s is None
+
+    def index_for_timestep(self, timestep):
+        idx = (self.timesteps == timestep).nonzero()
+        return int(idx[-1 if self.state_in_first_order else 0].item())
+
+    def scale_model_input(self, sample, timestep=None):
+        return self._scaled(sample, self.sigmas[self.index_for_timestep(timestep)])
+
+    def step(self, model_output, timestep, sample, return_dict=True, **_):
+        i = self.index_for_timestep(timestep)
+        if self.state_in_first_order:
+            sigma, sigma_next = self.sigmas[i], self.sigmas[i + 1]
+            # derivative = (x - (x - sigma*eps))/sigma = eps (up to rounding);  x' = x + eps*dt
+            dt = float(sigma_next - sigma)
+            out = ops.lincomb(torch.empty_like(sample), [sample.contiguous(), model_output.contiguous()], [1.0, dt])
+            self._eps1, self._x1, self._s = model_output, sample, dt
+        else:
+            dt = self._s
+            out = ops.lincomb(torch.empty_like(sample), [self._x1.contiguous(), self._eps1.contiguous(), model_output.contiguous()],
+                              [1.0, 0.5 * dt, 0.5 * dt])
+            self._eps1 = self._x1 = self._s = None
+        return SimpleNamespace(prev_sample=out)
+
+
+class LMSDiscreteScheduler(_SigmaSpace):
+    """[UPSTREAM] LMSDiscreteScheduler (reference model.py:650-652): order-4 linear multistep, Lagrange-basis integrals by
+    scipy.integrate.quad(epsrel=1e-4) like upstream."""
+    _class_name = "LMSDiscreteScheduler"
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ts, sig = self._interp_sigmas(num_inference_steps)
+        self.sigmas = torch.from_numpy(sig)
+        self.init_noise_sigma = self.sigmas.max()
+        self.timesteps = torch.from_numpy(ts)
+        self.derivatives: List[torch.Tensor] = []
+
+    def _index(self, timestep):
+        return int((self.timesteps == timestep).nonzero().item())
+
+    def scale_model_input(self, sample, timestep=None):
+        return self._scaled(sample, self.sigmas[self._index(timestep)])
+
+    def get_lms_coefficient(self, order, t, current_order):
+        from scipy import integrate
+
+        def lms_derivative(tau):
+            prod = 1.0
+            for k in range(order):
+                if current_order == k:
+                    continue
+                prod *= (tau - self.sigmas[t - k]) / (self.sigmas[t - current_order] - self.sigmas[t - k])
+            return prod
+
+        return integrate.quad(lms_derivative, self.sigmas[t], self.sigmas[t + 1], epsrel=1e-4)[0]
+
+    def step(self, model_output, timestep, sample, order: int = 4, return_dict=True, **_):
+        i = self._index(timestep)
+        self.derivatives.append(model_output)            # (x - (x - sigma*eps))/sigma == eps up to rounding
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(i + 1, order)
+        coeffs = [float(self.get_lms_coefficient(order, i, c)) for c in range(order)]
+        ders = list(reversed(self.derivatives))[:order]
+        out = ops.lincomb(torch.empty_like(sample), [sample.contiguous()] + [d.contiguous() for d in ders], [1.0] + coeffs[:len(ders)])
+        return SimpleNamespace(prev_sample=out)
+
+
+class KarrasVeScheduler:
+    """[UPSTREAM] KarrasVeScheduler (reference model.py:685-693: sigma_min 0.01, sigma_max 380, s_churn 80 / 100 / 0).
+    `schedule` holds sigma_max^2 (sigma_min^2/sigma_max^2)^(i/(n-1)) and is used as sigma, exactly as upstream does."""
+    _class_name = "KarrasVeScheduler"
+    order = 2
+
+    def __init__(self, sigma_min=0.02, sigma_max=100.0, s_noise=1.007, s_churn=80.0, s_min=0.05, s_max=50.0,
+                 num_train_timesteps=None, **extra):
+        self.config = _Config(sigma_min=sigma_min, sigma_max=sigma_max, s_noise=s_noise, s_churn=s_churn, s_min=s_min, s_max=s_max,
+                              clip_sample=False)
+        self.init_noise_sigma = sigma_max
+        self.num_inference_steps = None
+        self.timesteps = self.schedule = None
+        self.device_rng_seed: Optional[int] = None
+        self._rng_offset = 0
+
+    def scheduler_config(self) -> dict:
+        d = {k: v for k, v in vars(self.config).items() if k != "clip_sample"}
+        d["_class_name"] = self._class_name
+        return d
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        n = self.num_inference_steps = num_inference_steps
+        self.timesteps = torch.from_numpy(np.arange(0, n)[::-1].copy())
+        c = self.config
+        self.schedule = torch.tensor([c.sigma_max ** 2 * (c.sigma_min ** 2 / c.sigma_max ** 2) ** (i / (n - 1)) for i in self.timesteps],
+                                     dtype=torch.float32)
+
+    def add_noise_to_input(self, sample, sigma, generator=None, noise=None):
+        c = self.config
+        gamma = min(c.s_churn / self.num_inference_steps, 2 ** 0.5 - 1) if c.s_min <= sigma <= c.s_max else 0
+        sigma_hat = sigma + gamma * sigma
+        cz = float((sigma_hat ** 2 - sigma ** 2) ** 0.5) * c.s_noise
+        if noise is None:
+            if self.device_rng_seed is not None:
+                noise = ops.randn(torch.empty_like(sample), int(self.device_rng_seed), self._rng_offset)
+                self._rng_offset += (sample.numel() + 3) // 4
+            else:
+                noise = _noise_like(sample, generator)
+        out = ops.lincomb(torch.empty_like(sample), [sample.contiguous(), noise.contiguous()], [1.0, cz])
+        return out, sigma_hat
+
+    def step(self, model_output, sigma_hat, sigma_prev, sample_hat, return_dict=True):
+        """derivative = (x_hat - (x_hat + sigma_hat*mo))/sigma_hat = -mo ; x_prev = x_hat + (sigma_prev - sigma_hat)*derivative."""
+        mo = model_output.contiguous()
+        derivative = ops.lincomb(torch.empty_like(mo), [mo], [-1.0])
+        out = ops.lincomb(torch.empty_like(sample_hat), [sample_hat.contiguous(), derivative], [1.0, float(sigma_prev - sigma_hat)])
+        return SimpleNamespace(prev_sample=out, derivative=derivative)
+
+    def step_correct(self, model_output, sigma_hat, sigma_prev, sample_hat, sample_prev, derivative, return_dict=True):
+        d = 0.5 * float(sigma_prev - sigma_hat)
+        out = ops.lincomb(torch.empty_like(sample_hat), [sample_hat.contiguous(), derivative.contiguous(), model_output.contiguous()],
+                          [1.0, d, -d])
+        return SimpleNamespace(prev_sample=out, derivative=derivative)
+
+
 class ScoreSdeVeScheduler:
     """S5 -- [UPSTREAM] ScoreSdeVeScheduler (predictor-corrector VE-SDE sampler; reference model.py:672-684).
     Per-sample norms are one reduction kernel, both state updates are one ``vd_lincomb`` each."""
@@ -443,4 +738,6 @@ def get_cosine_schedule_with_warmup_lambda(num_warmup_steps: int, num_training_s
 
 
 SCHEDULER_CLASSES = {c._class_name: c for c in (DDPMScheduler, DDIMScheduler, DPMSolverMultistepScheduler,
-                                                UniPCMultistepScheduler, ScoreSdeVeScheduler)}
+                                                UniPCMultistepScheduler, ScoreSdeVeScheduler, PNDMScheduler,
+                                                DEISMultistepScheduler, HeunDiscreteScheduler, LMSDiscreteScheduler,
+                                                KarrasVeScheduler)}
