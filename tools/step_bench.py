@@ -1,0 +1,62 @@
+"""Time one training step (fwd + bwd + clip + Adam) of a named UNet configuration and list the MFMA kernels by time.
+   python tools/step_bench.py [cifar10|celebahq256|ldm64] [batch]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from villandiffusion_amd import ops, schedulers as S
+from villandiffusion_amd.loss import LossFn
+from villandiffusion_amd.trainer import Trainer
+from villandiffusion_amd.unet import UNet2DModel
+
+CFG = {
+    "cifar10": (dict(), 128),
+    "celebahq256": (dict(sample_size=256, block_out_channels=(128, 128, 256, 256, 512, 512),
+                         down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+                         up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4), 8),
+    "ldm64": (dict(sample_size=64, block_out_channels=(224, 448, 672, 896), attention_head_dim=32,
+                   down_block_types=("DownBlock2D",) + ("AttnDownBlock2D",) * 3,
+                   up_block_types=("AttnUpBlock2D",) * 3 + ("UpBlock2D",)), 8),
+}
+name = sys.argv[1] if len(sys.argv) > 1 else "celebahq256"
+cfg, B = CFG[name]
+if len(sys.argv) > 2:
+    B = int(sys.argv[2])
+net = UNet2DModel(**cfg)
+net.reset_parameters(0)
+sched = S.DDPMScheduler()
+tr = Trainer(net, LossFn(sched, "SDE-VP"), lr=2e-4, total_steps=1000)
+Sz = net.sample_size
+g = torch.Generator(device="cuda").manual_seed(0)
+x0 = torch.randn(B, 3, Sz, Sz, device="cuda", generator=g)
+R = torch.zeros_like(x0)
+t = torch.randint(0, 1000, (B,), device="cuda", generator=g)
+
+
+def step():
+    return tr.train_step({"target": x0, "pixel_values": R}, t)
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 5
+e0.record()
+for _ in range(n):
+    step()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+print(f"{name} B={B}: {ms:.1f} ms/step = {B / ms * 1e3:.1f} img/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+ops.profile_start()
+step()
+rec = ops.profile_stop()
+torch.cuda.synchronize()
+agg = {}
+for nm, fl, a, b in rec:
+    d = agg.setdefault(nm, [0, 0.0, 0.0])
+    d[0] += 1; d[1] += fl; d[2] += a.elapsed_time(b)
+tot = sum(v[2] for v in agg.values())
+print(f"MFMA kernels: {tot:.1f} ms, {sum(v[1] for v in agg.values()) / tot / 1e9:.1f} TF avg")
+for nm, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:14]:
+    print(f"  {nm:55s} n={v[0]:3d} {v[2]:8.2f} ms {v[1] / v[2] / 1e9:6.1f} TF")

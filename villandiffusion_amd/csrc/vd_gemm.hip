@@ -1450,8 +1450,9 @@ static void wgrad_plan(const vd_wgrad_desc& d, int& tile, int& splits, int& kk_p
     const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
     const int tiles = vd_cdiv(d.M, bm) * vd_cdiv(Ncols, bn);
     splits = d.splits;
-    if (splits <= 0) {  // fill ~2 workgroups per CU, keep >= 8 K-steps per split
-        splits = vd_cdiv(512, tiles);
+    if (splits <= 0) {  // one full wave of 3 workgroups per CU (768 slots; measured: 528 or 576 WGs leave a half-empty tail)
+        static const int target = getenv("VD_WGRAD_GEN_TARGET") ? atoi(getenv("VD_WGRAD_GEN_TARGET")) : 768;
+        splits = tiles >= target ? 1 : target / tiles;
         const int max_splits = Ktot / (BK * 8) > 0 ? Ktot / (BK * 8) : 1;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
