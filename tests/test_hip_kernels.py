@@ -79,6 +79,9 @@ def test_conv3x3_forward_epilogue(B, Cin, Cout, H, mode, tile):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,mode", [(2, 128, 256, 16, B_CONV3), (4, 256, 256, 4, B_CONV3), (2, 64, 64, 16, B_CONV3_S2),
                                                (9, 256, 256, 8, B_CONV3), (20, 128, 256, 4, B_CONV3),
+                                               (8, 128, 200, 8, B_CONV3), (6, 96, 128, 4, B_CONV3), (3, 128, 64, 4, B_CONV3),
+                                               (1, 64, 128, 64, B_CONV3), (2, 72, 64, 128, B_CONV3), (2, 64, 64, 32, B_CONV3_UP),
+                                               (4, 128, 128, 4, B_CONV3_UP), (2, 64, 64, 2, B_CONV3_UP),
                                                (2, 128, 128, 32, B_CONV3), (2, 200, 128, 32, B_CONV3), (2, 128, 128, 16, B_CONV3_UP),
                                                (2, 64, 96, 8, B_CONV3_UP), (2, 3, 128, 32, B_CONV3), (2, 128, 3, 32, B_CONV3)])
 def test_conv3x3_backward(B, Cin, Cout, H, mode):

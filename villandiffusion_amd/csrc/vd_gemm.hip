@@ -1151,18 +1151,214 @@ __global__ __launch_bounds__(NT, 3) void wgrad_patch_kernel(const vd_wgrad_desc 
     }
 }
 
-static bool wgrad_patch_eligible(const vd_wgrad_desc& d) {
-    if (d.T != 9 || (d.mode != VD_B_CONV3 && d.mode != VD_B_CONV3_UP)) return false;
-    if (d.OW != 16 && d.OW != 32) return false;
-    if (d.OH % (32 / d.OW) != 0 || d.NP != d.OH * d.OW) return false;
-    if (d.M < 64 || d.C < 64) return false;
-    if (d.tile != 0) return false;
-    return true;
+// Epilogue shared by the two patch weight-gradient kernels: split-K slab in the permuted layout, or dW directly.
+__device__ __forceinline__ void wgrad_patch_store(const vd_wgrad_desc& d, const f32x16 (&acc)[2][3], int r, int m0, int c0, int wm,
+                                                  int wc, int lane, int h) {
+    const int Ncols = d.C * 9;
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (c >= d.C) return;
+    if (gridDim.y > 1) {
+        float* __restrict__ slab = d.ws + (int64_t)blockIdx.y * d.M * Ncols + (int64_t)r * d.M * d.C * 3;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= d.M) continue;
+                float* __restrict__ o = slab + ((int64_t)m * d.C + c) * 3;
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) o[sx] = acc[mi][sx][v];
+            }
+        return;
+    }
+    float* __restrict__ out = d.dW;
+    const bool accum = d.accumulate;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int m = m0 + wm * 64 + mi * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+            if (m >= d.M) continue;
+            const int64_t off = (int64_t)m * Ncols + c * 9 + r * 3;
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) out[off + sx] = accum ? (out[off + sx] + acc[mi][sx][v]) : acc[mi][sx][v];
+        }
 }
 
+// Generalisation of wgrad_patch_kernel to the other image widths.  A K-step is still 32 output pixels = ROWS rows of
+// TW = 32/ROWS pixels.  Rows are numbered globally (gr = image*OH + y, OH a power of two), so a step may span images
+// (4x4 outputs: ROWS = 8 = two images); for OW >= 64 (ROWS == 1) a step is one 32-pixel segment of a row and the halo
+// columns come from the neighbouring segments.  Same LDS images, MFMA schedule and epilogue as wgrad_patch_kernel; the
+// source offsets of the patch elements are recomputed per K-step (a dozen integer ops per element against 96 MFMAs).
+// 2 workgroups/CU: at 3 the per-step address state spills (26-41 VGPRs) and the kernel drops from 115 to 85 TF.
+template <int ROWS, int MODE>  // MODE 0: CONV3, 2: CONV3_UP (X is the half-resolution source)
+__global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_desc d, int ksteps_per_split, int oh_shift,
+                                                                 int segs_shift) {
+    constexpr int TW = 32 / ROWS;
+    constexpr int PW = TW + 2;
+    constexpr int PLn = ROWS * PW;
+    constexpr int CT = 64;
+    constexpr int LDA_ = 128 + 1;
+    constexpr int LDB_ = (PLn & 1) ? PLn : PLn + 1;
+    constexpr int A_F4 = 128 * 32 / 4 / NT;
+    constexpr int P_EL = (CT * PLn + NT - 1) / NT;
+    __shared__ f32x4 As[KG * LDA_];
+    __shared__ float Bs[CT * LDB_];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int tiles_m = (d.M + 127) / 128;
+    const int r = blockIdx.x % 3;
+    const int rest = blockIdx.x / 3;
+    const int tm = rest % tiles_m, tc = rest / tiles_m;
+    const int m0 = tm * 128, c0 = tc * CT;
+    const int ks_total = (d.nb * d.NP) >> 5;
+    const int ks_begin = blockIdx.y * ksteps_per_split;
+    const int ks_end = min(ks_total, ks_begin + ksteps_per_split);
+    const int HWs = d.H * d.W;
+    const int oh_mask = d.OH - 1, seg_mask = (1 << segs_shift) - 1;
+    const int xbs32 = (int)d.x_bstride;
+
+    // per patch element ONE packed register: LDS slot (12 bits) | channel (6) | patch row (4) | patch column (6) | exists (1)
+    unsigned pk[P_EL];
+#pragma unroll
+    for (int i = 0; i < P_EL; ++i) {
+        const int e = tid + i * NT;
+        const int c = e / PLn, rem = e - c * PLn;
+        const int rr = rem / PW, px = rem - rr * PW;
+        const bool in = e < CT * PLn;
+        pk[i] = in ? ((unsigned)(c * LDB_ + rem) | ((unsigned)c << 12) | ((unsigned)rr << 18) | ((unsigned)px << 22) |
+                      (((c0 + c) < d.C ? 1u : 0u) << 28) | (1u << 29))
+                   : 0u;
+    }
+    const int qa = tid & 7;                        // this thread's k-group (4 pixels) in the dY loader
+    const int rrA = (4 * qa) / TW, xA = (4 * qa) % TW;
+
+    f32x4 ra[A_F4];
+    float rp[P_EL];
+    unsigned okmask = 0;
+    auto load_stage = [&](int ks) {
+        const int xs = ROWS == 1 ? (ks & seg_mask) * 32 : 0;
+        const int gr0 = ROWS == 1 ? (ks >> segs_shift) : ks * ROWS;
+        {
+            const int gr = gr0 + rrA;
+            const int b = gr >> oh_shift, y = gr & oh_mask;
+            const float* __restrict__ dyp = d.dY + (int64_t)b * d.dy_bstride + y * d.OW + xs + xA;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int m = (tid + i * NT) >> 3;
+                const int mm = min(m0 + m, d.M - 1);
+                ra[i] = *reinterpret_cast<const f32x4*>(dyp + (int64_t)mm * d.NP);
+            }
+        }
+        okmask = 0;
+        const int b0 = gr0 >> oh_shift;
+        const float* __restrict__ xb = d.X + (int64_t)b0 * d.x_bstride;
+#pragma unroll
+        for (int i = 0; i < P_EL; ++i) {
+            const unsigned u = pk[i];
+            const int gr = gr0 + (int)((u >> 18) & 15u);
+            const int b = gr >> oh_shift, y = gr & oh_mask;
+            int iy = y + r - 1, ix = xs + (int)((u >> 22) & 63u) - 1;
+            bool ok;
+            if (MODE == 2) {
+                ok = (unsigned)iy < (unsigned)(2 * d.H) && (unsigned)ix < (unsigned)(2 * d.W);
+                iy >>= 1;
+                ix >>= 1;
+            } else {
+                ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+            }
+            ok = ok && ((u >> 28) & 1u);
+            const int off = ok ? ((b - b0) * xbs32 + (c0 + (int)((u >> 12) & 63u)) * HWs + iy * d.W + ix) : 0;
+            rp[i] = xb[off];                           // uniform 64-bit base + 32-bit lane offset
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * NT;
+            const int m = idx >> 3, q = idx & 7;
+            const bool ok = m0 + m < d.M;
+            As[q * LDA_ + m] = ok ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < P_EL; ++i)
+            if ((pk[i] >> 29) & 1u) Bs[pk[i] & 4095u] = ((okmask >> i) & 1u) ? rp[i] : 0.f;
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][sx][v] = 0.f;
+
+    const int wm = wave >> 1, wc = wave & 1;
+    const f32x4* __restrict__ a_base = As + h * LDA_ + wm * 64 + (lane & 31);
+    // k-slot h covers pixels 8g+4h..8g+4h+3: the next 4 pixels of the row, or (4-pixel rows) the next row
+    const float* __restrict__ b_base = Bs + (wc * 32 + (lane & 31)) * LDB_ + (TW == 4 ? h * PW : 4 * h);
+
+    if (ks_begin < ks_end) {
+        load_stage(ks_begin);
+        store_stage();
+        __syncthreads();
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const bool more = ks + 1 < ks_end;
+            if (more) load_stage(ks + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int boff = TW == 4 ? (2 * g) * PW : ((8 * g) / TW) * PW + (8 * g) % TW;
+                f32x4 a[2];
+                float bw[6];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = a_base[2 * g * LDA_ + mi * 32];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) bw[j] = b_base[boff + j];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int sx = 0; sx < 3; ++sx)
+                            acc[mi][sx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], bw[t + sx], acc[mi][sx], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) store_stage();
+            __syncthreads();
+        }
+    }
+    wgrad_patch_store(d, acc, r, m0, c0, wm, wc, lane, h);
+}
+
+
+static int ilog2_exact(int v) {  // log2 of a power of two, -1 otherwise
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+// 0: not eligible; 1: wgrad_patch_kernel (OW 16 / 32); 2: wgrad_patch_gen_kernel (OW 4 / 8 / multiples of 32 from 64 up)
+static int wgrad_patch_kind(const vd_wgrad_desc& d) {
+    if (d.T != 9 || (d.mode != VD_B_CONV3 && d.mode != VD_B_CONV3_UP)) return 0;
+    if (d.NP != d.OH * d.OW || d.M < 64 || d.C < 64 || d.tile != 0) return 0;
+    if (d.OW == 16 || d.OW == 32) return d.OH % (32 / d.OW) == 0 ? 1 : 0;
+    if (ilog2_exact(d.OH) < 0 || ((int64_t)d.nb * d.NP) % 32 != 0) return 0;
+    if (d.x_bstride * (int64_t)(8 / d.OH + 2) >= (1ll << 31)) return 0;      // 32-bit in-step offsets
+    // 4x4 / 8x8 outputs: K = nb*NP is so short that both kernels are prologue/slab bound; measured on MI355X the generic
+    // kernel is as fast or faster there (75 vs 71 TF at 8x8, 48 vs 32 TF at 4x4), so the patch variant is opt-in.
+    static const bool small_patch = getenv("VD_WGRAD_SMALL_PATCH") != nullptr;
+    if (d.OW == 4 || d.OW == 8) return small_patch ? 2 : 0;
+    if (d.OW >= 64 && d.OW % 32 == 0 && ilog2_exact(d.OW / 32) >= 0) return 2;
+    return 0;
+}
+static bool wgrad_patch_eligible(const vd_wgrad_desc& d) { return wgrad_patch_kind(d) != 0; }
+
 static void wgrad_patch_plan(const vd_wgrad_desc& d, int& splits, int& ks_per) {
-    const int rows = 32 / d.OW;
-    const int ks_total = d.nb * (d.OH / rows);
+    const int ks_total = (int)(((int64_t)d.nb * d.NP) / 32);        // K-step = 32 output pixels
     const int base = vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
     splits = d.splits;
     if (splits <= 0) {  // ~3 workgroups per CU, at least 8 K-steps per split
@@ -1490,7 +1686,24 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         case 4: {
             dim3 grid(vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3, splits);
             rc = 0;
-            if (d.OW == 32 && d.mode == VD_B_CONV3)
+            if (wgrad_patch_kind(d) == 2) {
+                const int ohs = ilog2_exact(d.OH), sgs = d.OW >= 32 ? ilog2_exact(d.OW / 32) : 0;
+                const bool up = d.mode == VD_B_CONV3_UP;
+#define VD_WPG(R_)                                                                                               \
+    do {                                                                                                         \
+        if (up)                                                                                                  \
+            hipLaunchKernelGGL((wgrad_patch_gen_kernel<R_, 2>), grid, dim3(NT), 0, st, d, kk_per, ohs, sgs);     \
+        else                                                                                                     \
+            hipLaunchKernelGGL((wgrad_patch_gen_kernel<R_, 0>), grid, dim3(NT), 0, st, d, kk_per, ohs, sgs);     \
+    } while (0)
+                if (d.OW == 4)
+                    VD_WPG(8);
+                else if (d.OW == 8)
+                    VD_WPG(4);
+                else
+                    VD_WPG(1);
+#undef VD_WPG
+            } else if (d.OW == 32 && d.mode == VD_B_CONV3)
                 hipLaunchKernelGGL((wgrad_patch_kernel<32, 0>), grid, dim3(NT), 0, st, d, kk_per);
             else if (d.OW == 32)
                 hipLaunchKernelGGL((wgrad_patch_kernel<32, 2>), grid, dim3(NT), 0, st, d, kk_per);
