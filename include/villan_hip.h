@@ -200,6 +200,11 @@ int vd_batch_l2norm(const float* x, float* out, int B, int64_t inner, void* stre
 /* out = clamp(x*mul + add, lo, hi), optionally NCHW -> NHWC (pipeline post-processing). */
 int vd_postprocess(const float* x, float* out, int B, int C, int HW, float mul, float add, float lo, float hi,
                    int to_nhwc, void* stream);
+/* VQ-VAE quantiser (diffusers VectorQuantizer.forward, reached through VQModel.decode: reference loss.py:951-962,
+ * model.py:713): zq[b][:, p] = codebook[argmin_e |z[b][:, p] - e|^2], idx[b*HW + p] = that e (may be NULL).
+ * z / zq: [B, D, HW] with batch strides, codebook [n_e, D], D <= 16. */
+int vd_vq_nearest(const float* z, const float* codebook, float* zq, int64_t* idx, int B, int D, int HW, int n_e,
+                  int64_t z_bstride, int64_t q_bstride, void* stream);
 /* z ~ N(0,1) from Philox4x32-10 (throughput mode noise). */
 int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 

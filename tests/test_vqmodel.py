@@ -1,0 +1,78 @@
+"""VQ-VAE of the latent-diffusion path: structure on the CPU, HIP forward vs the oracle on the GPU."""
+import pytest
+import torch
+
+from oracle.vqmodel_ref import VQModelRef
+from villandiffusion_amd.vqmodel import VQModel
+
+SMALL = dict(block_out_channels=(32, 64), down_block_types=("DownEncoderBlock2D",) * 2, up_block_types=("UpDecoderBlock2D",) * 2,
+             layers_per_block=1, norm_num_groups=8, num_vq_embeddings=200, latent_channels=3, sample_size=32)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_state_dict_surface_matches_oracle_and_published_size():
+    """Key names / shapes are the diffusers ones; the CompVis/ldm-celebahq-256 vqvae config has 55.3 M parameters."""
+    ref, net = VQModelRef(), VQModel(device="cpu")
+    sr, sn = ref.state_dict(), net.state_dict()
+    assert set(sr) == set(sn)
+    assert all(tuple(sr[k].shape) == tuple(sn[k].shape) for k in sr)
+    assert sum(p.numel() for p in net.parameters()) == sum(p.numel() for p in ref.parameters()) == 55322782
+    assert not any(p.requires_grad for p in net.parameters())          # model.py:790 vae.requires_grad_(False)
+    legacy = {k.replace("to_q", "query").replace("to_k", "key").replace("to_v", "value").replace("to_out.0", "proj_attn"): v
+              for k, v in sr.items()}
+    net.load_state_dict(legacy)
+    assert torch.equal(net.state_dict()["decoder.mid_block.attentions.0.to_k.weight"], sr["decoder.mid_block.attentions.0.to_k.weight"])
+
+
+def test_oracle_quantiser_picks_the_nearest_code():
+    torch.manual_seed(0)
+    ref = VQModelRef(**SMALL)
+    with torch.no_grad():
+        ref.quantize.embedding.weight.normal_()
+        z = torch.randn(2, 3, 8, 8)
+        zq, idx = ref.quantize(z)
+        w = ref.quantize.embedding.weight
+        d = ((z.permute(0, 2, 3, 1).reshape(-1, 1, 3) - w[None]) ** 2).sum(-1)
+        assert torch.equal(idx, d.argmin(1))
+        assert torch.allclose(zq.permute(0, 2, 3, 1).reshape(-1, 3), w[idx])
+        lat = ref.encode(torch.randn(1, 3, 32, 32)).latents
+        assert lat.shape == (1, 3, 16, 16) and ref.decode(lat).sample.shape == (1, 3, 32, 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,B,S", [(SMALL, 3, 32), (dict(num_vq_embeddings=8192), 1, 64)])
+def test_hip_encode_quantise_decode_match_oracle(cfg, B, S):
+    torch.manual_seed(1)
+    ref = VQModelRef(**cfg)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        ref.quantize.embedding.weight.normal_(0, 0.5)
+    net = VQModel(**cfg)
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        lat_ref = ref.encode(x).latents
+        zq_ref, idx_ref = ref.quantize(lat_ref)
+        dec_ref = ref.decode(lat_ref).sample
+        dec_nq_ref = ref.decode(lat_ref, force_not_quantize=True).sample
+    lat = net.encode(x.cuda()).latents
+    e_enc = rel(lat, lat_ref)
+    zq, idx = net.quantize_latents(lat_ref.cuda(), return_indices=True)
+    same = float((idx.cpu() == idx_ref).float().mean())
+    # a differing index must still be a (near-)tie: its distance is within rounding of the minimum
+    w = ref.quantize.embedding.weight
+    zf = lat_ref.permute(0, 2, 3, 1).reshape(-1, w.shape[1]).double()
+    d_mine = ((zf - w[idx.cpu()].double()) ** 2).sum(1)
+    d_best = ((zf - w[idx_ref].double()) ** 2).sum(1)
+    assert float(((d_mine - d_best) / (d_best + 1e-12)).max()) < 1e-4
+    e_nq = rel(net.decode(lat_ref.cuda(), force_not_quantize=True).sample, dec_nq_ref)
+    e_dec = rel(net.decode(lat_ref.cuda()).sample, dec_ref)
+    print(f"[parity] VQModel encode {e_enc:.2e}, decode(no quant) {e_nq:.2e}, decode {e_dec:.2e}, identical code indices {same:.4f}")
+    assert e_enc < 1e-4 and e_nq < 1e-4 and same > 0.999
+    assert e_dec < (1e-4 if same == 1.0 else 5e-2)

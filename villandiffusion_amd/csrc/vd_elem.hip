@@ -445,6 +445,70 @@ extern "C" int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, v
     return 0;
 }
 
+// ---- VQ-VAE nearest-code lookup (diffusers VectorQuantizer.forward; used by VQModel.decode of the LDM path) ------------
+// One thread per latent pixel; the codebook is streamed through LDS in chunks with its squared norms.
+// d(z, e) = (|z|^2 + |e|^2) - 2 z.e, first minimum wins (torch.argmin).
+constexpr int VQ_CH = 1024;   // codes per LDS chunk
+constexpr int VQ_MAXD = 16;
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                         float* __restrict__ zq, int64_t* __restrict__ idx_out, int B, int D,
+                                                         int HW, int n_e, int64_t z_bs, int64_t q_bs) {
+    extern __shared__ float vq_sh[];                 // [VQ_CH * D] codes + [VQ_CH] norms
+    float* __restrict__ sh_n = vq_sh + VQ_CH * D;
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = p < (int64_t)B * HW;
+    const int b = live ? (int)(p / HW) : 0;
+    const int pix = live ? (int)(p - (int64_t)b * HW) : 0;
+    float zv[VQ_MAXD];
+    float zz = 0.f;
+#pragma unroll
+    for (int k = 0; k < VQ_MAXD; ++k) {
+        zv[k] = (k < D) ? z[(int64_t)b * z_bs + (int64_t)k * HW + pix] : 0.f;
+        zz += zv[k] * zv[k];
+    }
+    float best = INFINITY;
+    int besti = 0;
+    for (int c0 = 0; c0 < n_e; c0 += VQ_CH) {
+        const int nc = min(VQ_CH, n_e - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc * D; i += blockDim.x) vq_sh[i] = cb[(int64_t)c0 * D + i];
+        __syncthreads();
+        for (int j = threadIdx.x; j < nc; j += blockDim.x) {
+            float ee = 0.f;
+            for (int k = 0; k < D; ++k) ee += vq_sh[j * D + k] * vq_sh[j * D + k];
+            sh_n[j] = ee;
+        }
+        __syncthreads();
+        for (int j = 0; j < nc; ++j) {
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < VQ_MAXD; ++k)
+                if (k < D) dot += zv[k] * vq_sh[j * D + k];
+            const float dist = (zz + sh_n[j]) - 2.f * dot;
+            if (dist < best) {
+                best = dist;
+                besti = c0 + j;
+            }
+        }
+    }
+    if (live) {
+        for (int k = 0; k < D; ++k) zq[(int64_t)b * q_bs + (int64_t)k * HW + pix] = cb[(int64_t)besti * D + k];
+        if (idx_out) idx_out[p] = besti;
+    }
+}
+
+extern "C" int vd_vq_nearest(const float* z, const float* codebook, float* zq, int64_t* idx, int B, int D, int HW, int n_e,
+                             int64_t z_bstride, int64_t q_bstride, void* stream) {
+    VD_REQUIRE(z && codebook && zq && B > 0 && HW > 0 && n_e > 0, "vd_vq_nearest: bad args");
+    VD_REQUIRE(D >= 1 && D <= VQ_MAXD, "vd_vq_nearest: embedding dim %d not in [1, %d]", D, VQ_MAXD);
+    const int64_t n = (int64_t)B * HW;
+    const size_t shmem = (size_t)VQ_CH * (D + 1) * sizeof(float);
+    hipLaunchKernelGGL(vq_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), shmem, ST, z, codebook, zq, idx, B, D, HW,
+                       n_e, z_bstride, q_bstride);
+    VD_LAUNCH_CHECK("vd_vq_nearest");
+    return 0;
+}
+
 extern "C" int vd_poison_batch(const uint8_t* img, const int64_t* idx, const uint8_t* flags, const float* trigger, const float* target,
                                float* pixel_values, float* tgt_out, float* image_out, int B, int C, int H, int W, float vmin,
                                float vmax, int R_trigger_only, void* stream) {

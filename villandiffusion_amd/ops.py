@@ -407,6 +407,17 @@ def postprocess(x, out, mul, add, lo, hi, to_nhwc):
     return out
 
 
+def vq_nearest(z, codebook, zq, idx=None):
+    """zq[b, :, p] = codebook[argmin_e |z[b, :, p] - e|^2]  (VectorQuantizer forward)."""
+    Bn, D, H, W, zbs = _img(z)
+    qbs = _img(zq)[4]
+    assert zq.shape == z.shape and codebook.is_contiguous() and codebook.shape[1] == D
+    assert idx is None or (idx.dtype == torch.int64 and idx.numel() >= Bn * H * W)
+    L.check(_lib().vd_vq_nearest(_p(z), _p(codebook), _p(zq), _p(idx), Bn, D, H * W, codebook.shape[0], zbs, qbs, _s()),
+            "vd_vq_nearest")
+    return zq
+
+
 def randn(out, seed, offset):
     L.check(_lib().vd_randn(_p(out), out.numel(), seed, offset, _s()), "vd_randn")
     return out
