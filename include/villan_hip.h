@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 1
+#define VD_ABI_VERSION 2
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -76,6 +76,8 @@ typedef struct vd_gemm_desc {
     int64_t ldd, d_bstride;
     int64_t res_bstride, rowadd_bstride;
     float* ws;               /* split-K workspace (vd_gemm_ws_floats() floats), nullable when that is 0        */
+    int32_t pad;             /* VD_B_CONV3_S2 only: 0 = zero pad (0,1,0,1) (Downsample2D padding=0, the DDPM UNets),
+                                1 = symmetric padding 1 (Downsample2D padding=1, the LDM / NCSN++ UNets)        */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -100,6 +102,7 @@ typedef struct vd_wgrad_desc {
     int32_t H, W, OH, OW;     /* X spatial dims, dY spatial dims                                */
     int32_t mode, splits, accumulate, tile;
     int64_t dy_bstride, x_bstride;
+    int32_t pad;              /* VD_B_CONV3_S2 only, as in vd_gemm_desc                         */
 } vd_wgrad_desc;
 
 int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);
@@ -113,10 +116,10 @@ int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* st
 /* dX[b][c][y][x] (+)= sum_{2x2} dU[b][c][2y+i][2x+j]   (Upsample2D backward). */
 int vd_sumpool2x2(const float* dU, float* dX, int B, int C, int H, int W, int64_t du_bstride, int64_t dx_bstride,
                   int accumulate, void* stream);
-/* Stride-2 conv dgrad, second half: dX[b][c][y][x] = sum_{r,s: y-r, x-s even} G[b][(c*9+r*3+s)][(y-r)/2][(x-s)/2], where
- * G[b] = W2d^T[C*9, M] . dY[b][M, OH*OW] comes from vd_gemm (VD_A_COL, VD_B_PLAIN) -- the zero-padded (0,1,0,1) stride-2
- * Downsample2D conv of the reference UNet (diffusers Downsample2D, padding=0). */
-int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int W, int OH, int OW, int64_t g_bstride,
+/* Stride-2 conv dgrad, second half: dX[b][c][y][x] = sum_{r,s: y+pad-r, x+pad-s even}
+ * G[b][(c*9+r*3+s)][(y+pad-r)/2][(x+pad-s)/2], where G[b] = W2d^T[C*9, M] . dY[b][M, OH*OW] comes from vd_gemm (VD_A_COL,
+ * VD_B_PLAIN) -- the stride-2 Downsample2D conv of the reference UNet (pad as in vd_gemm_desc). */
+int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int W, int OH, int OW, int pad, int64_t g_bstride,
                  int64_t dx_bstride, void* stream);
 /* ws[b*ws_ld + m] = sum_p X[b][m][p]  (bias / temb-projection gradients), then vd_colsum over b. */
 int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t x_bstride, int64_t ws_ld, void* stream);

@@ -436,3 +436,25 @@ def test_plain_gemm_kernel_paths(B, Cin, Cout, H):
     ops.gemm(w.detach().to(DEV).view(Cout, Cin), dy.to(DEV), dx, M=Cin, N=B * HW, K=Cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW,
              lda=Cin, ldb=HW, b_bstride=Cout * HW, ldd=HW, d_bstride=Cin * HW)
     check(dx, x.grad, 3e-5, "conv1x1 dgrad (A column-major)")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 64, 96, 16), (3, 224, 224, 8)])
+def test_stride2_conv_symmetric_padding(B, Cin, Cout, H):
+    """Downsample2D(padding=1) of the LDM / NCSN++ UNets: conv(stride 2, padding 1) forward, weight and input gradients."""
+    x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)).requires_grad_()
+    b = torch.randn(Cout, generator=g(2))
+    y = F.conv2d(x, w, b, stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g(3))
+    y.backward(dy)
+    xd, wd, dyd = x.detach().to(DEV), w.detach().to(DEV).view(Cout, Cin * 9), dy.to(DEV)
+    out = torch.empty(B, Cout, H // 2, H // 2, device=DEV)
+    ops.conv3x3(xd, wd, b.to(DEV), out, mode=B_CONV3_S2, pad=1)
+    check(out, y, 3e-5, "stride-2 pad-1 forward")
+    dw = torch.empty(Cout, Cin * 9, device=DEV)
+    ws = torch.empty(max(ops.wgrad_ws_floats(Cout, Cin, 9, B, (H // 2) ** 2, mode=B_CONV3_S2), 4), device=DEV)
+    ops.conv_wgrad(dyd, xd, dw, B_CONV3_S2, ws, pad=1)
+    check(dw, w.grad.view(Cout, -1), 3e-5, "stride-2 pad-1 wgrad")
+    dx = torch.empty(B, Cin, H, H, device=DEV)
+    ops.conv3x3_s2_dgrad(dyd, wd, dx, pad=1)
+    check(dx, x.grad, 3e-5, "stride-2 pad-1 dgrad")

@@ -159,6 +159,15 @@ def test_multihead_attention_config_matches_oracle():
     _fwd_bwd_parity(cfg, B=3)
 
 
+def test_ldm_style_config_matches_oracle():
+    """The switches of the CompVis/ldm-celebahq-256 UNet (BASELINE config #5) at a small size: symmetric downsample padding,
+    flipped sin/cos, freq_shift 0, eps 1e-5, head_dim attention in 3 of 4 levels."""
+    cfg = dict(sample_size=64, block_out_channels=(32, 64, 96, 128), attention_head_dim=16, downsample_padding=1,
+               flip_sin_to_cos=True, freq_shift=0, norm_eps=1e-5, norm_num_groups=16,
+               down_block_types=("DownBlock2D",) + ("AttnDownBlock2D",) * 3, up_block_types=("AttnUpBlock2D",) * 3 + ("UpBlock2D",))
+    _fwd_bwd_parity(cfg, B=2)
+
+
 def test_celebahq256_config_matches_oracle():
     """BASELINE config #4: the google/ddpm-ema-celebahq-256 architecture (6 levels, attention at 16x16), B=1."""
     cfg = dict(sample_size=256, block_out_channels=(128, 128, 256, 256, 512, 512),

@@ -47,9 +47,9 @@ __device__ __forceinline__ float conv_gather(const float* __restrict__ src, cons
         ix = px.ox + 1 - s;
         ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
     } else if (BMODE == VD_B_CONV3_S2) {
-        iy = 2 * px.oy + r;
-        ix = 2 * px.ox + s;
-        ok = iy < d.H && ix < d.W;
+        iy = 2 * px.oy + r - d.pad;
+        ix = 2 * px.ox + s - d.pad;
+        ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
     } else if (BMODE == VD_B_CONV3_UP) {
         int uy = px.oy + r - 1, ux = px.ox + s - 1;
         ok = (unsigned)uy < (unsigned)(2 * d.H) && (unsigned)ux < (unsigned)(2 * d.W);
@@ -891,9 +891,9 @@ __global__ __launch_bounds__(NT, 3) void wgrad_kernel(const vd_wgrad_desc d, int
                         ix = ox + ns[i] - 1;
                         ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
                     } else if (BMODE == VD_B_CONV3_S2) {
-                        iy = 2 * oy + nr[i];
-                        ix = 2 * ox + ns[i];
-                        ok = iy < d.H && ix < d.W;
+                        iy = 2 * oy + nr[i] - d.pad;
+                        ix = 2 * ox + ns[i] - d.pad;
+                        ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
                     } else {  // VD_B_CONV3_UP
                         const int uy = oy + nr[i] - 1, ux = ox + ns[i] - 1;
                         ok = (unsigned)uy < (unsigned)(2 * d.H) && (unsigned)ux < (unsigned)(2 * d.W);
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict
 // col2im of the stride-2 dgrad: G[b][(c,r,s)][oy][ox] = sum_m W[m][c][r][s] dY[b][m][oy][ox] (a plain GEMM, no structural
 // zeros) is gathered into dX[b][c][y][x] = sum_{r,s : y-r, x-s even} G[b][(c,r,s)][(y-r)/2][(x-s)/2]; fixed tap order.
 __global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ G, float* __restrict__ dX, int B, int C,
-                                                        int H, int W, int OH, int OW, int64_t g_bs, int64_t dx_bs) {
+                                                        int H, int W, int OH, int OW, int pad, int64_t g_bs, int64_t dx_bs) {
     const int64_t per = (int64_t)C * H * W, total = per * B;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / per);
@@ -1454,13 +1454,14 @@ __global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict_
         const int y = (int)(cy % H);
         const int c = (int)(cy / H);
         const float* g = G + (int64_t)b * g_bs + (int64_t)c * 9 * OH * OW;
+        const int yp = y + pad, xp = x + pad;
         float acc = 0.f;
-        for (int r = y & 1; r < 3; r += 2) {
-            const int iy = (y - r) >> 1;
-            if (y < r || iy >= OH) continue;
-            for (int s = x & 1; s < 3; s += 2) {
-                const int ix = (x - s) >> 1;
-                if (x < s || ix >= OW) continue;
+        for (int r = yp & 1; r < 3; r += 2) {
+            const int iy = (yp - r) >> 1;
+            if (yp < r || iy >= OH) continue;
+            for (int s = xp & 1; s < 3; s += 2) {
+                const int ix = (xp - s) >> 1;
+                if (xp < s || ix >= OW) continue;
                 acc += g[(r * 3 + s) * OH * OW + iy * OW + ix];
             }
         }
@@ -1767,12 +1768,12 @@ extern "C" int vd_sumpool2x2(const float* dU, float* dX, int B, int C, int H, in
     return 0;
 }
 
-extern "C" int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int W, int OH, int OW, int64_t g_bstride,
+extern "C" int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int W, int OH, int OW, int pad, int64_t g_bstride,
                             int64_t dx_bstride, void* stream) {
-    VD_REQUIRE(G && dX && B > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "vd_col2im_s2: bad args");
+    VD_REQUIRE(G && dX && B > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && (pad == 0 || pad == 1), "vd_col2im_s2: bad args");
     const int64_t total = (int64_t)B * C * H * W;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(col2im_s2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G, dX, B, C, H, W, OH, OW, g_bstride,
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G, dX, B, C, H, W, OH, OW, pad, g_bstride,
                        dx_bstride);
     VD_LAUNCH_CHECK("vd_col2im_s2");
     return 0;

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("C", _i32), ("H", _i32), ("W", _i32), ("OH", _i32), ("OW", _i32),
                 ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("debug", _i32), ("alpha", _f32),
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
-                ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp)]
+                ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -36,7 +36,7 @@ class WgradDesc(C.Structure):
                 ("M", _i32), ("C", _i32), ("T", _i32), ("nb", _i32), ("NP", _i32),
                 ("H", _i32), ("W", _i32), ("OH", _i32), ("OW", _i32),
                 ("mode", _i32), ("splits", _i32), ("accumulate", _i32), ("tile", _i32),
-                ("dy_bstride", _i64), ("x_bstride", _i64)]
+                ("dy_bstride", _i64), ("x_bstride", _i64), ("pad", _i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/villan_hip.h
@@ -52,7 +52,7 @@ PROTOTYPES = {
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),
     "vd_weight_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
-    "vd_col2im_s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
+    "vd_col2im_s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_rowsum": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_colsum": (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     "vd_groupnorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i64, _i64, _vp]),
@@ -112,7 +112,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 1:
+    if lib.vd_abi_version() != 2:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -182,7 +182,23 @@ class LossFn:
 
     def p_loss_by_keys(self, batch, model, target_latent_key, poison_latent_key, timesteps, vae=None, noise=None,
                        weight_dtype=None, scaling_factor=None):
-        if vae is not None:
-            raise NotImplementedError("on-the-fly VAE encoding is the LDM 'next' row; pass precomputed latents (vae=None)")
-        return self.p_loss(model=model, x_start=batch[target_latent_key], R=batch[poison_latent_key], timesteps=timesteps,
-                           noise=noise)
+        x0, R = batch[target_latent_key], batch[poison_latent_key]
+        if vae is not None:          # loss.py:942-970: encode on the fly (training itself passes vae=None + precomputed latents)
+            x0, R = self.encode_latents(vae, x0, scaling_factor), self.encode_latents(vae, R, scaling_factor)
+        return self.p_loss(model=model, x_start=x0, R=R, timesteps=timesteps, noise=noise)
+
+    @staticmethod
+    def encode_latents(vae, x: torch.Tensor, scaling_factor: Optional[float] = None) -> torch.Tensor:
+        """loss.py:941-950  vae.encode(x).latents (* scaling_factor), detached."""
+        lat = vae.encode(x).latents
+        if scaling_factor is not None:
+            lat = lat * scaling_factor
+        return lat.detach()
+
+    @staticmethod
+    def decode_latents(vae, x: torch.Tensor, scaling_factor: Optional[float] = None) -> torch.Tensor:
+        """loss.py:951-962  vae.decode(x).sample (/ scaling_factor), detached."""
+        out = vae.decode(x).sample
+        if scaling_factor is not None:
+            out = out / scaling_factor
+        return out.detach()

@@ -72,8 +72,9 @@ def _gemm_ws(n_floats: int, device):
 
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
-         res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0):
+         res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0):
     d = GemmDesc()
+    d.pad = pad
     d.A, d.B, d.D = _p(A), _p(B), _p(D)
     d.bias, d.rowadd, d.residual = _p(bias), _p(rowadd), _p(residual)
     d.M, d.N, d.K = M, N, K
@@ -113,8 +114,10 @@ _CONV_OUT = {B_CONV3: lambda h, w: (h, w), B_CONV3_T: lambda h, w: (h, w), B_CON
              B_CONV3_UP: lambda h, w: (2 * h, 2 * w), B_CONV3_DIL: lambda h, w: (2 * h, 2 * w)}
 
 
-def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0):
-    """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9]."""
+def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
+            pad=0):
+    """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9].
+    pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1)."""
     Bn, Cc, H, W, xbs = _img(x)
     M = w2d.shape[0]
     assert w2d.shape[1] == Cc * 9 and w2d.is_contiguous()
@@ -127,7 +130,8 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
         assert residual.shape == out.shape
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
                 ldd=OH * OW, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
-                residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug)
+                residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
+                pad=pad)
 
 
 def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0):
@@ -170,7 +174,7 @@ def linear_wgrad(dy, x, dw, accumulate=False):
                 accumulate=accumulate)
 
 
-def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, splits=0, tile=0):
+def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, splits=0, tile=0, pad=0):
     """dw2d[M, C*T] (+)= sum_{b,p} dy[b,m,p] * gather_mode(x)[b, c, p(+)t]."""
     Bn, M, OH, OW, dbs = _img(dy)
     Bx, Cc, H, W, xbs = _img(x)
@@ -183,6 +187,7 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     d.H, d.W, d.OH, d.OW = H, W, OH, OW
     d.mode, d.splits, d.accumulate, d.tile = mode, splits, int(accumulate), tile
     d.dy_bstride, d.x_bstride = dbs, xbs
+    d.pad = pad
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_floats(C.byref(d))
     if need > 0:
@@ -227,7 +232,7 @@ def sumpool2x2(dU, dX, accumulate=False):
     return dX
 
 
-def conv3x3_s2_dgrad(dy, w2d, dx):
+def conv3x3_s2_dgrad(dy, w2d, dx, pad=0):
     """Input gradient of the stride-2 (pad (0,1,0,1)) conv: plain GEMM G[b] = w2d^T @ dy[b] (no structural zeros, unlike
     the dilated-gather GEMM), then the col2im gather."""
     Bn, M, OH, OW, dbs = _img(dy)
@@ -237,7 +242,7 @@ def conv3x3_s2_dgrad(dy, w2d, dx):
     G = torch.empty((Bn, Cc * 9, OHW), device=dy.device, dtype=torch.float32)
     gemm(w2d, dy, G, M=Cc * 9, N=Bn * OHW, K=M, a_mode=A_COL, b_mode=B_PLAIN, NP=OHW, lda=Cc * 9, ldb=OHW, b_bstride=dbs,
          ldd=OHW, d_bstride=Cc * 9 * OHW)
-    L.check(_lib().vd_col2im_s2(_p(G), _p(dx), Bn, Cc, H, W, OH, OW, Cc * 9 * OHW, xbs, _s()), "vd_col2im_s2")
+    L.check(_lib().vd_col2im_s2(_p(G), _p(dx), Bn, Cc, H, W, OH, OW, pad, Cc * 9 * OHW, xbs, _s()), "vd_col2im_s2")
     return dx
 
 

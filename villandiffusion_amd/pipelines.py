@@ -38,9 +38,7 @@ class DiffusionPipeline:
     default_steps = 1000
 
     def __init__(self, unet: UNet2DModel, scheduler, vqvae=None, clip_sample=None, clip_sample_range=None):
-        if vqvae is not None:
-            raise NotImplementedError("latent (VQ-VAE) pipelines are the LDM 'next' row")
-        self.unet, self.scheduler, self.vqvae = unet, scheduler, None
+        self.unet, self.scheduler, self.vqvae = unet, scheduler, vqvae
         self.clip_sample, self.clip_sample_range = clip_sample, clip_sample_range
 
     @property
@@ -99,9 +97,23 @@ class DiffusionPipeline:
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True):
         os.makedirs(os.path.join(save_directory, "unet"), exist_ok=True)
         os.makedirs(os.path.join(save_directory, "scheduler"), exist_ok=True)
+        index = {"_class_name": self._class_name, "_diffusers_version": "0.16.1",
+                 "unet": ["diffusers", "UNet2DModel"], "scheduler": ["diffusers", self.scheduler._class_name]}
+        if self.vqvae is not None:
+            index["vqvae"] = ["diffusers", "VQModel"]
+            os.makedirs(os.path.join(save_directory, "vqvae"), exist_ok=True)
+            vcfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.vqvae.config).items()}
+            vcfg["_class_name"] = "VQModel"
+            with open(os.path.join(save_directory, "vqvae", "config.json"), "w") as f:
+                json.dump(vcfg, f, indent=2)
+            vsd = {k: v.detach().cpu().contiguous().clone() for k, v in self.vqvae.state_dict().items()}
+            if safe_serialization:
+                from safetensors.torch import save_file
+                save_file(vsd, os.path.join(save_directory, "vqvae", "diffusion_pytorch_model.safetensors"))
+            else:
+                torch.save(vsd, os.path.join(save_directory, "vqvae", "diffusion_pytorch_model.bin"))
         with open(os.path.join(save_directory, "model_index.json"), "w") as f:
-            json.dump({"_class_name": self._class_name, "_diffusers_version": "0.16.1",
-                       "unet": ["diffusers", "UNet2DModel"], "scheduler": ["diffusers", self.scheduler._class_name]}, f, indent=2)
+            json.dump(index, f, indent=2)
         cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.unet.config).items()}
         cfg["_class_name"] = "UNet2DModel"
         with open(os.path.join(save_directory, "unet", "config.json"), "w") as f:
@@ -138,6 +150,19 @@ class DiffusionPipeline:
         name = scfg.pop("_class_name", "DDPMScheduler")
         scfg = {k: v for k, v in scfg.items() if not k.startswith("_") and k != "prediction_type"}
         sched = SCHEDULER_CLASSES.get(name, DDPMScheduler)(**scfg)
+        vdir = os.path.join(path, "vqvae")
+        if os.path.isdir(vdir):
+            from .vqmodel import VQModel
+            with open(os.path.join(vdir, "config.json")) as f:
+                vcfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+            vq = VQModel(**vcfg)
+            vst = os.path.join(vdir, "diffusion_pytorch_model.safetensors")
+            if os.path.exists(vst):
+                from safetensors.torch import load_file
+                vq.load_state_dict(load_file(vst))
+            else:
+                vq.load_state_dict(torch.load(os.path.join(vdir, "diffusion_pytorch_model.bin"), map_location="cpu"))
+            return LDMPipeline(vqvae=vq, unet=unet, scheduler=sched)
         return cls(unet, sched)
 
 
@@ -246,6 +271,52 @@ class KarrasVePipeline(DiffusionPipeline):
         if return_tensor:
             return x
         return SimpleNamespace(images=_post(x), movie=movie)
+
+
+class LDMPipeline(DiffusionPipeline):
+    """[UPSTREAM] LDMPipeline with the fork's call contract (reference model.py:713-769): the generic sampler loop in the
+    latent space of the VQ-VAE, then `vqvae.decode(latents)`; `.encode(x)` maps pixels to (unquantised) latents
+    (VillanDiffusion.py:632,648,1054: trigger / poisoned images are encoded before they are added to the latent noise).
+    `.movie` frames are decoded lazily only for the frames kept (decode of every step would dominate the loop)."""
+    _class_name = "LDMPipeline"
+    default_steps = 50
+
+    def __init__(self, vqvae=None, unet=None, scheduler=None, clip_sample=None, clip_sample_range=None):
+        if vqvae is None:
+            raise ValueError("LDMPipeline needs a vqvae")
+        super().__init__(unet, scheduler, vqvae=vqvae, clip_sample=clip_sample, clip_sample_range=clip_sample_range)
+
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        return self.vqvae.encode(x.to(self.device).float()).latents
+
+    def _step_kwargs(self, generator, eta):
+        import inspect
+        kw = {}
+        params = inspect.signature(self.scheduler.step).parameters
+        if "eta" in params:
+            kw["eta"] = 0.0 if eta is None else eta
+        if "generator" in params:
+            kw["generator"] = generator
+        return kw
+
+    @torch.no_grad()
+    def __call__(self, batch_size: int = 1, generator=None, init=None, num_inference_steps: Optional[int] = None, start_from: int = 0,
+                 save_every_step: bool = False, output_type=None, eta: Optional[float] = None, return_dict: bool = True,
+                 return_tensor: bool = False):
+        lat = super().__call__(batch_size=batch_size, generator=generator, init=init, num_inference_steps=num_inference_steps,
+                               start_from=start_from, save_every_step=False, eta=eta, return_tensor=True)
+        img = self.vqvae.decode(lat).sample
+        if return_tensor:
+            return img
+        movie = []
+        if save_every_step or init is not None:
+            first = init if init is not None else lat
+            movie = [_post(self.vqvae.decode(first.to(self.device).float()).sample), _post(img)]
+        images = _post(img)
+        if output_type == "pil":
+            from PIL import Image
+            images = [Image.fromarray(im.squeeze()) for im in (images * 255).round().astype("uint8")]
+        return SimpleNamespace(images=images, movie=movie)
 
 
 class PNDMPipeline(DiffusionPipeline):

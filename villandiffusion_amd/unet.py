@@ -47,8 +47,8 @@ def _ensure_path(root: nn.Module, parts: Sequence[str]) -> nn.Module:
 class _Conv:
     """3x3 convolution (mode selects the gather) with bias; weight stored [M, C, 3, 3] like diffusers."""
 
-    def __init__(self, net, prefix, cin, cout, mode=B_CONV3):
-        self.net, self.prefix, self.cin, self.cout, self.mode = net, prefix, cin, cout, mode
+    def __init__(self, net, prefix, cin, cout, mode=B_CONV3, pad=0):
+        self.net, self.prefix, self.cin, self.cout, self.mode, self.pad = net, prefix, cin, cout, mode, pad
         net._decl(prefix + ".weight", (cout, cin, 3, 3), fan_in=cin * 9)
         net._decl(prefix + ".bias", (cout,), fan_in=cin * 9, is_bias=True)
 
@@ -57,13 +57,13 @@ class _Conv:
 
     def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None):
         return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
-                           rowadd_bstride=rowadd_bstride, residual=residual)
+                           rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad)
 
     def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
         """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
         net = self.net
         ops.conv_wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, net.wgrad_ws,
-                       accumulate=True)
+                       accumulate=True, pad=self.pad)
         if not skip_bias:
             B = dout.shape[0]
             ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
@@ -74,7 +74,7 @@ class _Conv:
         if dx is None:
             return None
         if self.mode == B_CONV3_S2:
-            return ops.conv3x3_s2_dgrad(dout, self.w2d(), dx)
+            return ops.conv3x3_s2_dgrad(dout, self.w2d(), dx, pad=self.pad)
         wt = net.wt_view(self.prefix, self.cout, self.cin, 9)     # [C, M*9]
         if self.mode == B_CONV3:
             ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T)
@@ -209,6 +209,8 @@ class _Attn:
         nh, dh = self.heads, Cc // self.heads
         P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
         if nh > 1:
+            if N % 64:
+                raise NotImplementedError(f"multi-head attention needs a multiple of 64 tokens per image (got {H}x{W})")
             bs = 3 * Cc * N
             for h in range(nh):
                 q, k = qkv[:, h * dh:(h + 1) * dh], qkv[:, Cc + h * dh:Cc + (h + 1) * dh]
@@ -325,7 +327,7 @@ class UNet2DModel(nn.Module):
                  freq_shift=1, attention_head_dim=None, act_fn="silu", time_embedding_type="positional",
                  center_input_sample=False, mid_block_scale_factor=1, device=None, **unused):
         super().__init__()
-        if time_embedding_type != "positional" or act_fn != "silu" or downsample_padding != 0 or center_input_sample:
+        if time_embedding_type != "positional" or act_fn != "silu" or downsample_padding not in (0, 1) or center_input_sample:
             raise NotImplementedError("only the DDPM-style UNet2DModel configuration is implemented natively")
         for t in tuple(down_block_types) + tuple(up_block_types):
             if t not in ("DownBlock2D", "AttnDownBlock2D", "UpBlock2D", "AttnUpBlock2D"):
@@ -371,7 +373,7 @@ class UNet2DModel(nn.Module):
                     blk["attn"].append(_Attn(self, f"down_blocks.{i}.attentions.{j}", ch, attention_head_dim))
                 skip_ch.append(ch)
             if i != len(boc) - 1:
-                blk["ds"] = _Conv(self, f"down_blocks.{i}.downsamplers.0.conv", ch, ch, mode=B_CONV3_S2)
+                blk["ds"] = _Conv(self, f"down_blocks.{i}.downsamplers.0.conv", ch, ch, mode=B_CONV3_S2, pad=downsample_padding)
                 skip_ch.append(ch)
             self.down.append(blk)
         self.mid_res = [_Resnet(self, "mid_block.resnets.0", ch, ch), _Resnet(self, "mid_block.resnets.1", ch, ch)]
