@@ -76,3 +76,63 @@ def test_hip_encode_quantise_decode_match_oracle(cfg, B, S):
     print(f"[parity] VQModel encode {e_enc:.2e}, decode(no quant) {e_nq:.2e}, decode {e_dec:.2e}, identical code indices {same:.4f}")
     assert e_enc < 1e-4 and e_nq < 1e-4 and same > 0.999
     assert e_dec < (1e-4 if same == 1.0 else 5e-2)
+
+
+@pytest.mark.gpu
+def test_ldm_pipeline_matches_oracle_and_roundtrips_on_disk(tmp_path):
+    """BASELINE config #5 shape of work at a small size: UniPC-20 in the latent space, then the VQ-VAE decode
+    (reference model.py:706-776 + fork LDMPipeline); also .encode(), save_pretrained/from_pretrained with vqvae/, and the
+    on-the-fly latent encoding of LossFn.p_loss_by_keys(vae=...) (loss.py:942-976)."""
+    import numpy as np
+    from oracle import schedulers_ref as R
+    from oracle.loss_ref import LossFnRef
+    from oracle.unet_ref import UNet2DModelRef
+    from villandiffusion_amd import schedulers as S
+    from villandiffusion_amd.loss import LossFn
+    from villandiffusion_amd.pipelines import DiffusionPipeline, LDMPipeline
+    from villandiffusion_amd.unet import UNet2DModel
+
+    torch.manual_seed(0)
+    ucfg = dict(sample_size=16, block_out_channels=(32, 64), down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+                up_block_types=("AttnUpBlock2D", "UpBlock2D"), layers_per_block=1, norm_num_groups=8, downsample_padding=1,
+                flip_sin_to_cos=True, freq_shift=0)
+    uref, vref = UNet2DModelRef(**ucfg), VQModelRef(**SMALL)
+    with torch.no_grad():
+        vref.quantize.embedding.weight.normal_(0, 0.5)
+    unet, vq = UNet2DModel(**ucfg), VQModel(**SMALL)
+    unet.load_state_dict(uref.state_dict())
+    vq.load_state_dict(vref.state_dict())
+    beta = dict(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear")
+    pipe = LDMPipeline(vqvae=vq, unet=unet, scheduler=S.UniPCMultistepScheduler(**beta))
+    init = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    out = pipe(batch_size=2, init=init, num_inference_steps=20, output_type=None)
+    with torch.no_grad():
+        lat_ref = R.sample_loop(uref, R.UniPCMultistepSchedulerRef(**beta), init.clone(), 20)
+        img_ref = (vref.decode(lat_ref).sample / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    err = float(np.abs(out.images - img_ref).max() / np.abs(img_ref).max())
+    print(f"[parity] LDM UniPC-20 + VQ decode: image max-rel-err {err:.3e}")
+    assert out.images.shape == (2, 32, 32, 3) and err <= 1e-3 and len(out.movie) == 2
+    # encode contract
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        assert rel(pipe.encode(x), vref.encode(x).latents) < 1e-4
+    # disk round trip in the diffusers layout
+    d = str(tmp_path / "ldm")
+    pipe.save_pretrained(d)
+    import os
+    assert os.path.exists(os.path.join(d, "vqvae", "config.json")) and os.path.exists(os.path.join(d, "unet", "config.json"))
+    pipe2 = DiffusionPipeline.from_pretrained(d)
+    assert isinstance(pipe2, LDMPipeline)
+    assert torch.equal(pipe2.vqvae.flat_param, vq.flat_param) and torch.equal(pipe2.unet.flat_param, unet.flat_param)
+    # loss with on-the-fly encoding
+    sched = S.DDPMScheduler(**beta)
+    t = torch.tensor([5, 900])
+    eps = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(5))
+    batch = {"target": x, "pixel_values": torch.zeros_like(x)}
+    l = LossFn(sched, "SDE-LDM").p_loss_by_keys({k: v.cuda() for k, v in batch.items()}, unet, "target", "pixel_values", t.cuda(),
+                                                vae=vq, noise=eps.cuda(), scaling_factor=0.5)
+    with torch.no_grad():
+        x0 = vref.encode(x).latents * 0.5
+        Rr = vref.encode(torch.zeros_like(x)).latents * 0.5
+        l_ref = LossFnRef(R.DDPMSchedulerRef(**beta), "SDE-LDM").p_loss(uref, x0, Rr, t, noise=eps)
+    assert abs(float(l) - float(l_ref)) <= 1e-4 * abs(float(l_ref)), (float(l), float(l_ref))

@@ -16,11 +16,13 @@ from typing import Optional
 
 import torch
 
-from .pipelines import DDIMPipeline, DDPMPipeline, DiffusionPipeline, KarrasVePipeline, PNDMPipeline, ScoreSdeVePipeline
+from .pipelines import (DDIMPipeline, DDPMPipeline, DiffusionPipeline, KarrasVePipeline, LDMPipeline, PNDMPipeline,
+                        ScoreSdeVePipeline)
 from .schedulers import (DDIMScheduler, DDPMScheduler, DEISMultistepScheduler, DPMSolverMultistepScheduler,
                          HeunDiscreteScheduler, KarrasVeScheduler, LMSDiscreteScheduler, PNDMScheduler, ScoreSdeVeScheduler,
                          UniPCMultistepScheduler)
 from .unet import UNet2DModel
+from .vqmodel import VQModel
 
 # model.py:816-834
 DDPM_32_ARCH = dict(act_fn="silu", attention_head_dim=None, block_out_channels=[128, 256, 256, 256], center_input_sample=False,
@@ -28,6 +30,22 @@ DDPM_32_ARCH = dict(act_fn="silu", attention_head_dim=None, block_out_channels=[
                     flip_sin_to_cos=False, freq_shift=1, layers_per_block=2, mid_block_scale_factor=1, norm_eps=1e-06,
                     norm_num_groups=32, time_embedding_type="positional",
                     up_block_types=["UpBlock2D", "UpBlock2D", "AttnUpBlock2D", "UpBlock2D"])
+
+
+# google/ddpm-ema-{celebahq,church,bedroom}-256 (113 673 219 parameters)
+DDPM_256_ARCH = dict(DDPM_32_ARCH, block_out_channels=[128, 128, 256, 256, 512, 512],
+                     down_block_types=["DownBlock2D"] * 4 + ["AttnDownBlock2D", "DownBlock2D"],
+                     up_block_types=["UpBlock2D", "AttnUpBlock2D"] + ["UpBlock2D"] * 4)
+# CompVis/ldm-celebahq-256: unet (274 056 163 parameters) on 3x64x64 latents + vqvae (55 322 782); [UPSTREAM config, from memory]
+LDM_CELEBA_UNET_ARCH = dict(act_fn="silu", attention_head_dim=32, block_out_channels=[224, 448, 672, 896], center_input_sample=False,
+                            down_block_types=["DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"],
+                            downsample_padding=1, flip_sin_to_cos=True, freq_shift=0, in_channels=3, layers_per_block=2,
+                            mid_block_scale_factor=1, norm_eps=1e-05, norm_num_groups=32, out_channels=3, sample_size=64,
+                            time_embedding_type="positional",
+                            up_block_types=["AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"])
+LDM_CELEBA_VQ_ARCH = dict(act_fn="silu", block_out_channels=[128, 256, 512], down_block_types=["DownEncoderBlock2D"] * 3,
+                          in_channels=3, latent_channels=3, layers_per_block=2, num_vq_embeddings=8192, out_channels=3,
+                          sample_size=256, up_block_types=["UpDecoderBlock2D"] * 3)
 
 
 class DiffuserModelSched:
@@ -163,13 +181,45 @@ class DiffuserModelSched:
         elif sde_type == cls.SDE_VE:
             model, vae, sched, gp = cls._get_model_sched_ve(ckpt_id, clip_sample, noise_sched_type, build_model)
         elif sde_type == cls.SDE_LDM:
-            raise NotImplementedError(f"sde_type {sde_type}: the latent-diffusion (VQ-VAE) model family is a 'next' row "
-                                      f"(SURVEY.md §8f.4); the {sde_type} loss tables are available in loss.LossFn")
+            model, vae, sched, gp = cls._get_model_sched_ldm(ckpt_id, clip_sample, noise_sched_type, build_model)
         else:
             raise NotImplementedError(f"sde_type {sde_type} not implemented")
         if model is not None:
             model.requires_grad_(True)
+        if vae is not None:
+            vae.requires_grad_(False)                                                # model.py:790
         return model, vae, sched, gp
+
+    @classmethod
+    def _get_model_sched_ldm(cls, ckpt_id, clip_sample, noise_sched_type=None, build_model=True):
+        """model.py:706-776: latent diffusion = UNet on VQ-VAE latents; beta scaled_linear [0.0015, 0.0195], T=1000."""
+        clip = cls.get_sample_clip(clip_sample, cls.CLIP_SAMPLE_DEFAULT)
+        beta = dict(num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear")
+        model = vae = loaded_sched = None
+        if build_model:
+            d = cls._resolve_dir(ckpt_id)
+            if d is None:
+                raise FileNotFoundError(
+                    f"pretrained latent-diffusion checkpoint '{ckpt_id}' is not available locally (no network / HF cache). Pass a "
+                    f"diffusers-layout directory (unet/ vqvae/ scheduler/) as --ckpt or set VILLAN_CKPT_ROOT.")
+            pipe = DiffusionPipeline.from_pretrained(d)
+            if pipe.vqvae is None:
+                raise ValueError(f"{d}: no vqvae/ folder -- not a latent-diffusion checkpoint")
+            model, vae, loaded_sched = pipe.unet, pipe.vqvae, pipe.scheduler
+        ldm_clip = partial(LDMPipeline, clip_sample=clip)
+        if noise_sched_type is None:
+            noise_sched = loaded_sched if loaded_sched is not None else DDIMScheduler(clip_sample=False, **beta)
+            pipe_cls = LDMPipeline
+        elif noise_sched_type == cls.DDPM_SCHED:
+            noise_sched, pipe_cls = DDPMScheduler(clip_sample=clip, **beta), LDMPipeline
+        elif noise_sched_type == cls.DDIM_SCHED:
+            noise_sched, pipe_cls = DDIMScheduler(clip_sample=clip, **beta), LDMPipeline
+        else:
+            noise_sched, _ = cls._make_sched(noise_sched_type, clip, 1.0, beta)
+            pipe_cls = ldm_clip
+        if clip is not None:
+            noise_sched.config.clip_sample = clip
+        return model, vae, noise_sched, cls._pipeline_factory(pipe_cls)
 
     @staticmethod
     def check_image_size_channel(image_size: int, channels: int):
@@ -193,12 +243,35 @@ class DiffuserModelSched:
             return cls.get_model_sched(image_size=32, channels=3, ckpt=cls.DDPM_32_DEFAULT, sde_type=sde_type,
                                        clip_sample=clip_sample, clip_sample_range=clip_sample_range,
                                        noise_sched_type=noise_sched_type)
+        if ckpt in scratch and cls._resolve_dir(cls.HUB_IDS[scratch[ckpt]]) is None:
+            # weights are re-initialised anyway (weight_reset): build the published 256x256 architecture directly
+            _, vae, sched, gp = cls._get_model_sched(cls.HUB_IDS[scratch[ckpt]], clip_sample, clip_sample_range, noise_sched_type,
+                                                     sde_type, build_model=False)
+            model = UNet2DModel(in_channels=3, out_channels=3, sample_size=256, **DDPM_256_ARCH)
+            model.requires_grad_(True)
+            return model, vae, sched, gp
         if ckpt in scratch:
             model, vae, sched, gp = cls.get_pretrained(scratch[ckpt], clip_sample, clip_sample_range, noise_sched_type, sde_type=sde_type)
             model.reset_parameters()
             return model, vae, sched, gp
-        if ckpt.startswith("NCSNPP") or ckpt.startswith("LDM"):
-            raise NotImplementedError(f"ckpt {ckpt}: NCSN++ / LDM model families are 'next' rows (SURVEY.md §8f.4-5)")
+        if ckpt == cls.LDM_CELEBA_HQ_DEFAULT:
+            if cls._resolve_dir(cls.HUB_IDS[cls.LDM_CELEBA_HQ_256]) is not None:
+                model, vae, sched, gp = cls.get_pretrained(cls.LDM_CELEBA_HQ_256, clip_sample, clip_sample_range, noise_sched_type,
+                                                           sde_type=cls.SDE_LDM)
+                model.reset_parameters()
+                return model, vae, sched, gp
+            # No local copy of CompVis/ldm-celebahq-256: the UNet is re-initialised anyway, but the VQ-VAE would be the
+            # PRETRAINED one -- a random VQ-VAE is only good for plumbing / throughput runs, so say so loudly.
+            import warnings
+            warnings.warn("LDM-CELEBA-HQ-DEFAULT without a local CompVis/ldm-celebahq-256: the VQ-VAE is RANDOMLY initialised "
+                          "(published architecture); decoded images are meaningless until real vqvae weights are loaded")
+            _, _, sched, gp = cls._get_model_sched_ldm(cls.HUB_IDS[cls.LDM_CELEBA_HQ_256], clip_sample, noise_sched_type, build_model=False)
+            model, vae = UNet2DModel(**LDM_CELEBA_UNET_ARCH), VQModel(**LDM_CELEBA_VQ_ARCH)
+            model.requires_grad_(True)
+            vae.requires_grad_(False)
+            return model, vae, sched, gp
+        if ckpt.startswith("NCSNPP"):
+            raise NotImplementedError(f"ckpt {ckpt}: the NCSN++ model family is a 'next' row (SURVEY.md §8f.5)")
         return cls.get_pretrained(ckpt, clip_sample, clip_sample_range, noise_sched_type, sde_type=sde_type)
 
     @classmethod
