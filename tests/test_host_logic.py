@@ -182,3 +182,46 @@ def test_metrics_known_answers():
     x, y = torch.full((1, 1, 16, 16), 0.2), torch.full((1, 1, 16, 16), 0.6)
     c1 = 0.01 ** 2
     assert ssim_batch(x, y) == pytest.approx((2 * 0.2 * 0.6 + c1) / (0.04 + 0.36 + c1), rel=1e-4)
+
+
+def test_latent_dataset_disk_format_and_poison_by_index(tmp_path):
+    """dataset.py:1037-1371: `<root>/target..pt` dict, `<root>/<type>/<idx>..pt` (double dot), item i poisoned iff
+    i < int(len * poison_rate); clean items carry zeros as the poison latent and the raw latent as target."""
+    import os
+    from types import SimpleNamespace
+    from dataset import LatentDataset
+
+    class FakeVae:                         # stand-in with the VQModel call surface
+        device = torch.device("cpu")
+
+        def encode(self, x):
+            return SimpleNamespace(latents=x[:, :, ::2, ::2] * 2.0)
+
+        def decode(self, z):
+            return SimpleNamespace(sample=z.repeat_interleave(2, 2).repeat_interleave(2, 3) / 2.0)
+
+    root = str(tmp_path / "lat")
+    ds = LatentDataset(root).set_vae(FakeVae())
+    imgs = torch.randn(10, 3, 8, 8, generator=torch.Generator().manual_seed(0))
+    pois = imgs + 1.0
+    tgt = torch.randn(3, 8, 8, generator=torch.Generator().manual_seed(1))
+    ds.update_target_by_key("CAT", tgt)
+    ds.update_data_by_idxs(LatentDataset.RAW_LATENTS_FILE_NAME, list(range(10)), imgs)
+    ds.update_data_by_idxs("GLASSES", list(range(10)), pois)
+    assert os.path.exists(os.path.join(root, "target..pt")) and os.path.exists(os.path.join(root, "raw", "7..pt"))
+    assert os.path.exists(os.path.join(root, "GLASSES", "0..pt"))
+    assert LatentDataset.add_ext("x") == "x..pt"
+    ds.set_poison(target_key="CAT", poison_key="GLASSES", raw="raw", poison_rate=0.3).set_use_names("target", "pixel_values", "image")
+    assert len(ds) == 10
+    enc = lambda x: x[:, ::2, ::2] * 2.0
+    for i in range(10):
+        it = ds[i]
+        assert torch.equal(it["image"], enc(imgs[i]))
+        if i < 3:
+            assert torch.equal(it["target"], enc(tgt)) and torch.equal(it["pixel_values"], enc(pois[i]))
+        else:
+            assert torch.equal(it["target"], enc(imgs[i])) and float(it["pixel_values"].abs().max()) == 0.0
+    assert torch.equal(ds[13]["image"], ds[3]["image"])                  # index wraps (dataset.py:1345)
+    assert torch.allclose(ds.get_target_by_key("CAT")[:, ::2, ::2], tgt[:, ::2, ::2])
+    with pytest.raises(ValueError):
+        LatentDataset(str(tmp_path / "x")).update_target_by_key("k", tgt)

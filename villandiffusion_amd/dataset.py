@@ -395,3 +395,139 @@ class _Loader:
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         for s in range(0, len(self.ids), self.bs):
             yield self.dsl.make_batch(self.ids[s:s + self.bs], full=self.full)
+
+
+class LatentDataset(torch.utils.data.Dataset):
+    """Precomputed VQ-VAE latents on disk, the reference's format (dataset.py:1037-1371):
+
+        <root>/target..pt            dict  {target key -> latent}          (note the DOUBLE dot: add_ext() joins with '.' and
+        <root>/<data type>/<idx>..pt one latent tensor per sample           DATA_EXT already starts with one, dataset.py:1038,1065)
+
+    ``set_poison(target_key, poison_key, raw, poison_rate)``: item i is poisoned iff ``i < int(len * poison_rate)``
+    (dataset.py:1352-1359): target = the target latent, poison = the stored poisoned latent; clean items: target = raw
+    latent, poison = zeros.  With ``use_latent=False`` items are decoded through the VQ-VAE set by ``set_vae``."""
+    DATA_EXT: str = ".pt"
+    TARGET_LATENTS_FILE_NAME: str = "target"
+    POISON_LATENTS_FILE_NAME: str = "poison"
+    RAW_LATENTS_FILE_NAME: str = "raw"
+
+    def __init__(self, ds_root: str):
+        os.makedirs(ds_root, exist_ok=True)
+        self._root = ds_root
+        self._target = self._poison = self._raw = None
+        self._target_name = self._poison_name = self._raw_name = None
+        self._poison_rate, self._len, self._vae, self._use_latent = None, None, None, True
+
+    def set_vae(self, vae):
+        self._vae = vae
+        return self
+
+    @staticmethod
+    def add_ext(p: str) -> str:
+        return f"{p}.{LatentDataset.DATA_EXT}"
+
+    # ---- raw file access ----
+    @staticmethod
+    def read_ext(file: str):
+        try:
+            return torch.load(LatentDataset.add_ext(file))
+        except (FileNotFoundError, OSError):
+            return None
+
+    @staticmethod
+    def save_ext(val, file: str) -> None:
+        torch.save(val, LatentDataset.add_ext(file))
+
+    @property
+    def targe_latents_path(self) -> str:      # (sic) reference spelling, dataset.py:1070
+        p = os.path.join(self._root, LatentDataset.TARGET_LATENTS_FILE_NAME)
+        if not os.path.exists(LatentDataset.add_ext(p)):
+            LatentDataset.save_ext({}, p)
+        return p
+
+    def _dir(self, data_type: str) -> str:
+        p = os.path.join(self._root, data_type)
+        os.makedirs(p, exist_ok=True)
+        return p
+
+    def _encode(self, x: torch.Tensor) -> torch.Tensor:
+        if self._vae is None:
+            raise ValueError("Please provide encoder first")
+        with torch.no_grad():
+            return self._vae.encode(x.to(self._vae.device)).latents.detach().cpu()
+
+    def _decode(self, z: torch.Tensor) -> torch.Tensor:
+        if self._vae is None:
+            raise ValueError("Please provide encoder first")
+        with torch.no_grad():
+            return self._vae.decode(z.to(self._vae.device)).sample.clone().detach().cpu()
+
+    # ---- targets: one dict file ----
+    def update_target_latent_by_key(self, key: str, val: torch.Tensor):
+        res = LatentDataset.read_ext(self.targe_latents_path) or {}
+        res[key] = val
+        LatentDataset.save_ext(res, self.targe_latents_path)
+
+    def update_target_by_key(self, key: str, val: torch.Tensor):
+        self.update_target_latent_by_key(key, self._encode(val.unsqueeze(0)).squeeze(0))
+
+    def get_target_latent_by_key(self, key: str) -> torch.Tensor:
+        return LatentDataset.read_ext(self.targe_latents_path)[key]
+
+    def get_target_by_key(self, key: str) -> torch.Tensor:
+        return self._decode(self.get_target_latent_by_key(key).unsqueeze(0)).squeeze(0)
+
+    # ---- per-sample latents: one file per index ----
+    def update_data_latent_by_idx(self, data_type: str, idx: int, val: torch.Tensor):
+        LatentDataset.save_ext(val, os.path.join(self._dir(data_type), f"{idx}"))
+
+    def update_data_latents_by_idxs(self, data_type: str, idxs, vals):
+        if isinstance(idxs, int):
+            idxs, vals = [idxs], (vals.unsqueeze(0) if isinstance(vals, torch.Tensor) else vals)
+        elif isinstance(vals, list):
+            vals = torch.stack(vals)
+        for idx, val in zip(idxs, vals):
+            self.update_data_latent_by_idx(data_type, idx, val.clone())
+
+    def update_data_by_idxs(self, data_type: str, idxs, vals):
+        if isinstance(idxs, int):
+            idxs, vals = [idxs], vals.unsqueeze(0)
+        elif isinstance(vals, list):
+            vals = torch.stack(vals)
+        self.update_data_latents_by_idxs(data_type, list(idxs), self._encode(vals))
+
+    def get_data_latent_by_idx(self, data_type: str, idx: int) -> torch.Tensor:
+        return LatentDataset.read_ext(os.path.join(self._dir(data_type), f"{idx}"))
+
+    def get_data_by_idx(self, data_type: str, idx: int) -> torch.Tensor:
+        return self._decode(self.get_data_latent_by_idx(data_type, idx).unsqueeze(0)).squeeze(0)
+
+    # ---- poisoning view ----
+    def set_poison(self, target_key: str, poison_key: str, raw: str, poison_rate: float, use_latent: bool = True):
+        import glob
+        self._target, self._poison, self._raw = target_key, poison_key, raw
+        self._poison_rate, self._use_latent = poison_rate, use_latent
+        self._len = len(glob.glob(os.path.join(self._dir(raw), f"*{LatentDataset.DATA_EXT}")))
+        return self
+
+    def set_use_names(self, target: str, poison: str, raw: str):
+        self._target_name, self._poison_name, self._raw_name = target, poison, raw
+        return self
+
+    def get_target_latent(self) -> torch.Tensor:
+        if self._target is None:
+            raise ValueError("Please set up the target first")
+        return self.get_target_latent_by_key(self._target)
+
+    def __len__(self):
+        return self._len
+
+    def __getitem__(self, i: int):
+        i = i % len(self)
+        get = self.get_data_latent_by_idx if self._use_latent else self.get_data_by_idx
+        raw = get(self._raw, i)
+        if i < int(self._len * self._poison_rate):
+            tgt, poi = self.get_target_latent(), get(self._poison, i)       # reference returns the LATENT target in both modes
+        else:
+            tgt, poi = raw, torch.zeros_like(raw)
+        return {self._target_name: tgt, self._poison_name: poi, self._raw_name: raw}
