@@ -78,6 +78,10 @@ typedef struct vd_gemm_desc {
     float* ws;               /* split-K workspace (vd_gemm_ws_floats() floats), nullable when that is 0        */
     int32_t pad;             /* VD_B_CONV3_S2 only: 0 = zero pad (0,1,0,1) (Downsample2D padding=0, the DDPM UNets),
                                 1 = symmetric padding 1 (Downsample2D padding=1, the LDM / NCSN++ UNets)        */
+    int32_t nb2;             /* > 1: two-level batch, item i = outer*nb2 + inner at outer*X_bstride + inner*X_b2stride
+                                (the heads of multi-head attention are channel slices of one q/k/v tensor); needs
+                                rowadd == residual == NULL                                                       */
+    int64_t a_b2stride, b_b2stride, d_b2stride;
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);

@@ -69,6 +69,14 @@ __device__ __forceinline__ float conv_gather(const float* __restrict__ src, cons
     return src[boff + off];            // caller zeroes masked elements later (deferred select)
 }
 
+// Batch offset with the optional second batch level (heads of multi-head attention are channel slices of one tensor):
+// item i = outer * nb2 + inner  ->  outer * stride + inner * stride2.
+__device__ __forceinline__ int64_t batch_off(const vd_gemm_desc& d, int i, int64_t stride, int64_t stride2) {
+    if (d.nb2 <= 1) return (int64_t)i * stride;
+    const int o = i / d.nb2;
+    return (int64_t)o * stride + (int64_t)(i - o * d.nb2) * stride2;
+}
+
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f32x4 sel4(bool ok, f32x4 v) {
     f32x4 z = zero4();
@@ -110,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue(const vd_gemm_desc& d, f32x16 (&ac
         const bool nok = n < d.N;
         const int nc = nok ? n : d.N - 1;
         const int b = nc / d.NP, p = nc - b * d.NP;
-        const int64_t dbase = d.d_trans ? (int64_t)nc * d.ldd : ((int64_t)b * d.d_bstride + p);
+        const int64_t dbase = d.d_trans ? (int64_t)nc * d.ldd : (batch_off(d, b, d.d_bstride, d.d_b2stride) + p);
         const int64_t dstr = d.d_trans ? 1 : d.ldd;
         float bn = 0.f;
         if (has_bias_n) bn = d.bias[nc];
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const vd_gemm_desc d) {
 
     const float* __restrict__ Ap = d.A;
     const float* __restrict__ Bp = d.B;
-    if (d.a_bstride != 0) Ap += (int64_t)(n0 / d.NP) * d.a_bstride;
+    if (d.a_bstride != 0) Ap += batch_off(d, n0 / d.NP, d.a_bstride, d.a_b2stride);
 
     const bool a_vec = (AMODE == VD_A_ROW) && ((d.lda & 3) == 0) && ((d.K & 3) == 0) &&
                        ((((uintptr_t)Ap) & 15) == 0);
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const vd_gemm_desc d) {
         } else {
             px.oy = px.ox = 0;
         }
-        boff = (int64_t)px.b * d.b_bstride;
+        boff = batch_off(d, px.b, d.b_bstride, d.b_b2stride);
     }
 
     // Global->register staging.  Loads are UNCONDITIONAL (masked lanes read a clamped, valid address) and their
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const vd_gemm_desc d) {
                 const bool nok = n < d.N;
                 const int nn = nok ? n : 0;
                 const int b = nn / d.NP, p = nn - b * d.NP;
-                const float* q = Bp + (int64_t)b * d.b_bstride + (int64_t)p * d.ldb;
+                const float* q = Bp + batch_off(d, b, d.b_bstride, d.b_b2stride) + (int64_t)p * d.ldb;
                 if (b_vec) {
                     const bool ok = nok && k < d.K;
                     rb[i] = *reinterpret_cast<const f32x4*>(q + (ok ? k : 0));
@@ -710,8 +718,8 @@ __global__ __launch_bounds__(NT, 3) void gemm_plain_kernel(const vd_gemm_desc d)
     const int tm = bid % tiles_m, tn = bid / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int b = n0 / d.NP, p0 = n0 - b * d.NP;   // BN | NP: a tile never straddles batch items
-    const float* __restrict__ Ap = d.A + (int64_t)b * d.a_bstride;
-    const float* __restrict__ Bp = d.B + (int64_t)b * d.b_bstride + p0;
+    const float* __restrict__ Ap = d.A + batch_off(d, b, d.a_bstride, d.a_b2stride);
+    const float* __restrict__ Bp = d.B + batch_off(d, b, d.b_bstride, d.b_b2stride) + p0;
 
     f32x4 ra[F4], rb[F4];
     auto load_stage = [&](int k0) {
@@ -1605,6 +1613,9 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     }
     if (d.a_bstride != 0) VD_REQUIRE(d.NP % 64 == 0, "vd_gemm: per-batch A needs NP %% 64 == 0 (NP=%d)", d.NP);
     VD_REQUIRE(!(d.d_trans && (d.residual || d.rowadd)), "vd_gemm: d_trans excludes residual/rowadd");
+    if (d.nb2 > 1)
+        VD_REQUIRE(!d.residual && !d.rowadd && !d.d_trans && d.b_mode <= VD_B_KCONTIG && (d.N / d.NP) % d.nb2 == 0,
+                   "vd_gemm: two-level batch (nb2=%d) needs plain operands, no residual/rowadd, nb %% nb2 == 0", d.nb2);
     const int tile = vd_gemm_tile(&d);
     hipStream_t st = (hipStream_t)stream;
     int rc;

@@ -72,9 +72,11 @@ def _gemm_ws(n_floats: int, device):
 
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
-         res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0):
+         res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
+         b_b2stride=0, d_b2stride=0):
     d = GemmDesc()
     d.pad = pad
+    d.nb2, d.a_b2stride, d.b_b2stride, d.d_b2stride = nb2, a_b2stride, b_b2stride, d_b2stride
     d.A, d.B, d.D = _p(A), _p(B), _p(D)
     d.bias, d.rowadd, d.residual = _p(bias), _p(rowadd), _p(residual)
     d.M, d.N, d.K = M, N, K

@@ -211,16 +211,15 @@ class _Attn:
         if nh > 1:
             if N % 64:
                 raise NotImplementedError(f"multi-head attention needs a multiple of 64 tokens per image (got {H}x{W})")
-            bs = 3 * Cc * N
-            for h in range(nh):
-                q, k = qkv[:, h * dh:(h + 1) * dh], qkv[:, Cc + h * dh:Cc + (h + 1) * dh]
-                ops.gemm(k, q, P[:, h], M=N, N=B * N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
-                         b_bstride=bs, ldd=N, d_bstride=nh * N * N, alpha=self.scale)
+            # all heads in one launch: batch item (b, h) -> b * 3C*N + h * dh*N inside qkv (two-level batch of vd_gemm)
+            bs, hs = 3 * Cc * N, dh * N
+            q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+            two = dict(nb2=nh, NP=N)
+            ops.gemm(k, q, P, M=N, N=B * nh * N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
+                     b_bstride=bs, b_b2stride=hs, ldd=N, d_bstride=nh * N * N, d_b2stride=N * N, alpha=self.scale, **two)
             ops.softmax_col_fwd(P, B * nh, N)
-            for h in range(nh):
-                v = qkv[:, 2 * Cc + h * dh:2 * Cc + (h + 1) * dh]
-                ops.gemm(v, P[:, h], o[:, h * dh:(h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N,
-                         lda=N, a_bstride=bs, ldb=N, b_bstride=nh * N * N, ldd=N, d_bstride=Cc * N)
+            ops.gemm(v, P, o, M=dh, N=B * nh * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
+                     b_bstride=nh * N * N, b_b2stride=N * N, ldd=N, d_bstride=Cc * N, d_b2stride=hs, **two)
         elif N <= 64:
             ops.attn_small_fwd(qkv, o, P, Cc, N, self.scale)
         else:
@@ -255,21 +254,23 @@ class _Attn:
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
         if nh > 1:
-            bs, pbs = 3 * Cc * N, nh * N * N
+            bs, hs, pbs, NN = 3 * Cc * N, dh * N, nh * N * N, N * N
             dP = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
-            for h in range(nh):
-                v, doh = qkv[:, 2 * Cc + h * dh:2 * Cc + (h + 1) * dh], do[:, h * dh:(h + 1) * dh]
-                ops.gemm(doh, P[:, h], dqkv[:, 2 * Cc + h * dh:2 * Cc + (h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW,
-                         b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=Cc * N, ldb=N, b_bstride=pbs, ldd=N, d_bstride=bs)
-                ops.gemm(v, doh, dP[:, h], M=N, N=B * N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs,
-                         ldb=N, b_bstride=Cc * N, ldd=N, d_bstride=pbs)
+            q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+            dq, dk, dv = dqkv[:, :Cc], dqkv[:, Cc:2 * Cc], dqkv[:, 2 * Cc:]
+            two = dict(nb2=nh, NP=N, N=B * nh * N)
+            # dv[c][j] = sum_i do[c][i] P[j][i]
+            ops.gemm(do, P, dv, M=dh, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, lda=N, a_bstride=Cc * N, a_b2stride=hs, ldb=N,
+                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
+            # dP[j][i] = sum_c v[c][j] do[c][i]
+            ops.gemm(v, do, dP, M=N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
+                     b_bstride=Cc * N, b_b2stride=hs, ldd=N, d_bstride=pbs, d_b2stride=NN, **two)
             ops.softmax_col_bwd(P, dP, B * nh, N, self.scale)
-            for h in range(nh):
-                q, k = qkv[:, h * dh:(h + 1) * dh], qkv[:, Cc + h * dh:Cc + (h + 1) * dh]
-                ops.gemm(k, dP[:, h], dqkv[:, h * dh:(h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N,
-                         lda=N, a_bstride=bs, ldb=N, b_bstride=pbs, ldd=N, d_bstride=bs)
-                ops.gemm(q, dP[:, h], dqkv[:, Cc + h * dh:Cc + (h + 1) * dh], M=dh, N=B * N, K=N, a_mode=A_ROW,
-                         b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=bs, ldb=N, b_bstride=pbs, ldd=N, d_bstride=bs)
+            # dq[c][i] = sum_j k[c][j] dS[j][i] ;  dk[c][j] = sum_i q[c][i] dS[j][i]
+            ops.gemm(k, dP, dq, M=dh, K=N, a_mode=A_ROW, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
+                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
+            ops.gemm(q, dP, dk, M=dh, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
+                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
         elif N <= 64:
             ops.attn_small_bwd(qkv, P, do, dqkv, Cc, N, self.scale)
         else:
