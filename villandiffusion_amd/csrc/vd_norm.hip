@@ -233,6 +233,116 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// Register-resident backward: x and dy of the (batch item, group) slab are read ONCE (float4 per thread x NV), turned into
+// xhat / dz in registers, reduced to the per-channel sums (deterministic: wave butterflies + fixed-order LDS combine) and
+// reused for dx -- 3 tensor reads (x, dy, extra) + 1 write instead of 5 + 1.
+// L = float4 per channel (HW/4): L >= 64 (multiple of 64): every (chunk, wave) lies in one channel; L < 64 (power of two):
+// channels are L-lane segments of a wave.
+template <int NV>
+__global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ extra, float* __restrict__ dx,
+                                                         float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws, int C,
+                                                         int HW, int G, int apply_silu, int64_t dy_bs, int64_t x_bs,
+                                                         int64_t ex_bs, int64_t dx_bs) {
+    __shared__ float ch_s1[64], ch_s2[64];
+    __shared__ float part1[NV * 4], part2[NV * 4];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cpg = C / G;
+    const int n4 = (cpg * HW) >> 2;
+    const int L = HW >> 2;
+    const int64_t goff = (int64_t)g * cpg * HW;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff);
+    const f32x4* __restrict__ d4 = reinterpret_cast<const f32x4*>(dy + (int64_t)b * dy_bs + goff);
+    const f32x4* __restrict__ e4 = extra ? reinterpret_cast<const f32x4*>(extra + (int64_t)b * ex_bs + goff) : nullptr;
+    f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(dx + (int64_t)b * dx_bs + goff);
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    f32x4 xh[NV], dz[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        const bool in = idx < n4;
+        const f32x4 xv = in ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 dv = in ? d4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = g * cpg + (in ? idx / L : 0);
+        const float ga = gamma[c], be = beta[c];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h_ = (xv[j] - mean) * rstd;
+            float z_ = dv[j];
+            if (apply_silu) {
+                const float z = h_ * ga + be, sg = sigmoidf_(z);
+                z_ *= sg * (1.f + z * (1.f - sg));
+            }
+            if (!in) z_ = 0.f;
+            xh[i][j] = h_;
+            dz[i][j] = z_;
+            s1 += z_;
+            s2 += z_ * h_;
+        }
+        if (L >= 64) {
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) {
+                part1[i * 4 + wave] = s1;
+                part2[i * 4 + wave] = s2;
+            }
+        } else {
+            for (int off = 1; off < L; off <<= 1) {          // butterfly inside the L-lane channel segment
+                s1 += __shfl_xor(s1, off, 64);
+                s2 += __shfl_xor(s2, off, 64);
+            }
+            if (in && (lane & (L - 1)) == 0) {
+                ch_s1[idx / L] = s1;
+                ch_s2[idx / L] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (L >= 64) {
+        if (tid < cpg) {                                      // channel tid = parts [tid*L/64, (tid+1)*L/64), fixed order
+            const int np = L >> 6;
+            float a1 = 0.f, a2 = 0.f;
+            for (int k = 0; k < np; ++k) {
+                a1 += part1[tid * np + k];
+                a2 += part2[tid * np + k];
+            }
+            ch_s1[tid] = a1;
+            ch_s2[tid] = a2;
+        }
+        __syncthreads();
+    }
+    if (tid < cpg) {
+        dbeta_ws[(int64_t)b * C + g * cpg + tid] = ch_s1[tid];
+        dgamma_ws[(int64_t)b * C + g * cpg + tid] = ch_s2[tid];
+    }
+    float m1 = 0.f, m2 = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const float ga = gamma[g * cpg + cl];
+        m1 += ga * ch_s1[cl];
+        m2 += ga * ch_s2[cl];
+    }
+    const float inv_n = 1.f / (float)(cpg * HW);
+    m1 *= inv_n;
+    m2 *= inv_n;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < n4) {
+            const float ga = gamma[g * cpg + idx / L];
+            f32x4 ev = {0.f, 0.f, 0.f, 0.f}, o;
+            if (e4) ev = e4[idx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (dz[i][j] * ga - m1 - xh[i][j] * m2) + ev[j];
+            o4[idx] = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -265,8 +375,24 @@ extern "C" int vd_groupnorm_bwd(const float* dy, const float* x, const float* me
                                 int64_t extra_bstride, int64_t dx_bstride, void* stream) {
     VD_REQUIRE(dy && x && mean && rstd && gamma && beta && dx && dgamma_ws && dbeta_ws, "vd_groupnorm_bwd: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 64, "vd_groupnorm_bwd: bad dims");
-    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
-                       dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
+    const int64_t slab = (int64_t)(C / G) * HW;
+    const int L = HW / 4;
+    const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)extra)) & 15) == 0 &&
+                    ((x_bstride | dy_bstride | dx_bstride | extra_bstride) & 3) == 0;
+    const bool reg_ok = al && HW % 4 == 0 && slab <= 12 * 1024 &&
+                        ((L >= 64 && L % 64 == 0) || (L < 64 && (L & (L - 1)) == 0 && L > 0)) && getenv("VD_GN_BWD_GENERIC") == nullptr;
+#define VD_GN_BWD(NVV)                                                                                                         \
+    hipLaunchKernelGGL((gn_bwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, \
+                       extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride)
+    if (reg_ok && slab <= 1024) VD_GN_BWD(1);
+    else if (reg_ok && slab <= 2048) VD_GN_BWD(2);
+    else if (reg_ok && slab <= 4096) VD_GN_BWD(4);
+    else if (reg_ok && slab <= 8192) VD_GN_BWD(8);
+    else if (reg_ok) VD_GN_BWD(12);
+    else
+        hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
+                           dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
+#undef VD_GN_BWD
     VD_LAUNCH_CHECK("vd_groupnorm_bwd");
     return 0;
 }
