@@ -832,10 +832,19 @@ __global__ __launch_bounds__(NT, 3) void wgrad_kernel(const vd_wgrad_desc d, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int Ncols = d.C * d.T;
     const int tiles_m = (d.M + BM - 1) / BM;
-    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    int bx = blockIdx.x, by = blockIdx.y;      // XCD-aware remap: one XCD owns a contiguous range of K-splits (see wgrad_patch_kernel)
+    {
+        const int T = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((T & 7) == 0) {
+            const int v = (lin & 7) * (T >> 3) + (lin >> 3);
+            bx = v % gridDim.x;
+            by = v / gridDim.x;
+        }
+    }
+    const int tm = bx % tiles_m, tn = bx / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int Ktot = d.nb * d.NP;
-    const int kk_begin = blockIdx.y * kk_per_split;
+    const int kk_begin = by * kk_per_split;
     const int kk_end = min(Ktot, kk_begin + kk_per_split);
 
     // columns owned by this thread in the B loader: n_i = n0 + (tid>>3) + 32*i ; k-group kq = tid & 7
@@ -954,7 +963,7 @@ __global__ __launch_bounds__(NT, 3) void wgrad_kernel(const vd_wgrad_desc d, int
         }
     }
 
-    float* __restrict__ out = (gridDim.y > 1) ? (d.ws + (int64_t)blockIdx.y * d.M * Ncols) : d.dW;
+    float* __restrict__ out = (gridDim.y > 1) ? (d.ws + (int64_t)by * d.M * Ncols) : d.dW;
     const bool accum = (gridDim.y == 1) && d.accumulate;
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
@@ -995,13 +1004,24 @@ __global__ __launch_bounds__(NT, 3) void wgrad_patch_kernel(const vd_wgrad_desc 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int tiles_m = (d.M + 127) / 128;
-    const int r = blockIdx.x % 3;
-    const int rest = blockIdx.x / 3;
+    // XCD-aware remap: hardware deals linear workgroup ids round-robin over the 8 XCDs; make every XCD own a contiguous
+    // range of K-splits so that the (m-tile, c-tile, r) workgroups re-reading one dY / X slice share that XCD's L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int T = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((T & 7) == 0) {
+            const int v = (lin & 7) * (T >> 3) + (lin >> 3);
+            bx = v % gridDim.x;
+            by = v / gridDim.x;
+        }
+    }
+    const int r = bx % 3;
+    const int rest = bx / 3;
     const int tm = rest % tiles_m, tc = rest / tiles_m;
     const int m0 = tm * 128, c0 = tc * CT;
     const int steps_per_img = d.OH / ROWS;
     const int ks_total = d.nb * steps_per_img;
-    const int ks_begin = blockIdx.y * ksteps_per_split;
+    const int ks_begin = by * ksteps_per_split;
     const int ks_end = min(ks_total, ks_begin + ksteps_per_split);
     const int HWs = d.H * d.W;
 
@@ -1128,7 +1148,7 @@ __global__ __launch_bounds__(NT, 3) void wgrad_patch_kernel(const vd_wgrad_desc 
     if (gridDim.y > 1) {
         // split-K slab in the PERMUTED layout ws[z][r][m][c][3]: for one row m the 32 lanes (consecutive c) write 32 x 12 B
         // contiguous bytes, instead of 12-B pieces at a 36-B stride in the weight layout; slab_reduce_perm_kernel un-permutes.
-        float* __restrict__ slab = d.ws + (int64_t)blockIdx.y * d.M * Ncols + (int64_t)r * d.M * d.C * 3;
+        float* __restrict__ slab = d.ws + (int64_t)by * d.M * Ncols + (int64_t)r * d.M * d.C * 3;
         if (c < d.C) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -1161,12 +1181,12 @@ __global__ __launch_bounds__(NT, 3) void wgrad_patch_kernel(const vd_wgrad_desc 
 
 // Epilogue shared by the two patch weight-gradient kernels: split-K slab in the permuted layout, or dW directly.
 __device__ __forceinline__ void wgrad_patch_store(const vd_wgrad_desc& d, const f32x16 (&acc)[2][3], int r, int m0, int c0, int wm,
-                                                  int wc, int lane, int h) {
+                                                  int wc, int lane, int h, int by) {
     const int Ncols = d.C * 9;
     const int c = c0 + wc * 32 + (lane & 31);
     if (c >= d.C) return;
     if (gridDim.y > 1) {
-        float* __restrict__ slab = d.ws + (int64_t)blockIdx.y * d.M * Ncols + (int64_t)r * d.M * d.C * 3;
+        float* __restrict__ slab = d.ws + (int64_t)by * d.M * Ncols + (int64_t)r * d.M * d.C * 3;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1215,12 +1235,21 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int tiles_m = (d.M + 127) / 128;
-    const int r = blockIdx.x % 3;
-    const int rest = blockIdx.x / 3;
+    int bx = blockIdx.x, by = blockIdx.y;      // XCD-aware remap (see wgrad_patch_kernel)
+    {
+        const int T = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((T & 7) == 0) {
+            const int v = (lin & 7) * (T >> 3) + (lin >> 3);
+            bx = v % gridDim.x;
+            by = v / gridDim.x;
+        }
+    }
+    const int r = bx % 3;
+    const int rest = bx / 3;
     const int tm = rest % tiles_m, tc = rest / tiles_m;
     const int m0 = tm * 128, c0 = tc * CT;
     const int ks_total = (d.nb * d.NP) >> 5;
-    const int ks_begin = blockIdx.y * ksteps_per_split;
+    const int ks_begin = by * ksteps_per_split;
     const int ks_end = min(ks_total, ks_begin + ksteps_per_split);
     const int HWs = d.H * d.W;
     const int oh_mask = d.OH - 1, seg_mask = (1 << segs_shift) - 1;
@@ -1338,7 +1367,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
             __syncthreads();
         }
     }
-    wgrad_patch_store(d, acc, r, m0, c0, wm, wc, lane, h);
+    wgrad_patch_store(d, acc, r, m0, c0, wm, wc, lane, h, by);
 }
 
 
