@@ -89,7 +89,8 @@ int vd_gemm(const vd_gemm_desc* desc, void* stream);
  * its channel loop over workgroups for the 8x8 / 4x4 layers, partial slabs are reduced in fixed order). */
 int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
 /* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4 / 6: patch-staged 3x3
- * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel (profiling / tests). */
+ * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel, 7: direct 3x3 convolution for <= 4 output
+ * channels (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):

@@ -458,3 +458,18 @@ def test_stride2_conv_symmetric_padding(B, Cin, Cout, H):
     dx = torch.empty(B, Cin, H, H, device=DEV)
     ops.conv3x3_s2_dgrad(dyd, wd, dx, pad=1)
     check(dx, x.grad, 3e-5, "stride-2 pad-1 dgrad")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(4, 128, 3, 32), (2, 64, 4, 16), (1, 36, 1, 64), (3, 128, 3, 8)])
+def test_conv3x3_few_output_channels_direct_kernel(B, Cin, Cout, H):
+    """conv_out (128 -> 3): the direct (non-MFMA) convolution kernel, on strided views; 8x8 falls back to the GEMM path."""
+    x = torch.randn(B, Cin, H, H, generator=g(0))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g(2))
+    y_ref = F.conv2d(x, w, b, padding=1)
+    xbuf = torch.zeros(B, Cin + 2, H, H, device=DEV)
+    xbuf[:, 2:] = x.to(DEV)
+    obuf = torch.full((B, Cout + 2, H, H), 7.0, device=DEV)
+    ops.conv3x3(xbuf[:, 2:], w.to(DEV).view(Cout, -1), b.to(DEV), obuf[:, 1:1 + Cout])
+    check(obuf[:, 1:1 + Cout], y_ref, 2e-5, f"direct conv {Cin}->{Cout}@{H}")
+    assert float((obuf[:, 0] - 7).abs().max()) == 0 and float((obuf[:, -1] - 7).abs().max()) == 0

@@ -106,6 +106,8 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = f"conv3_patch_kernel<{d.OW}, {0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)}, {4 if tl == 6 else 2}>"
     elif tl == 5:
         name = f"gemm_plain_kernel<{a_mode}>"
+    elif tl == 7:
+        name = f"conv3_smallm_kernel<{32 if d.W % 32 == 0 else 16}, 4>"
     else:
         name = f"gemm_kernel<{_TILE_NAMES[tl]},{'ROW' if a_mode == A_ROW else 'COL'},{_B_NAMES[b_mode]}>"
     _PROF.append((name, flops, e0, e1))
