@@ -54,6 +54,9 @@ CONV_CASES = [
     # 8x8 / 4x4: multi-image tiles + deterministic split-K over the channel loop (ragged batch: 5 images, tile = 2 / 8 images)
     (5, 256, 256, 8, B_CONV3, 0), (16, 512, 256, 4, B_CONV3, 0), (5, 256, 128, 4, B_CONV3, 0), (3, 256, 256, 4, B_CONV3_UP, 0),
     (128, 256, 256, 4, B_CONV3, 0),
+    # images wider than 32 px: row-segment tiles (64-wide: 2 rows, >= 128-wide: 128-pixel segments)
+    (2, 64, 128, 64, B_CONV3, 0), (1, 72, 64, 128, B_CONV3, 0), (1, 64, 64, 256, B_CONV3, 0), (1, 64, 96, 64, B_CONV3_UP, 0),
+    (1, 64, 64, 32, B_CONV3_UP, 0),
 ]
 
 

@@ -430,7 +430,7 @@ constexpr int KSTEP = CK * 9;
 // where it makes the grid an exact multiple of the 512 resident workgroups (128-channel layers at 32x32: 1024 tiles of
 // 128 px on 768 slots leave a 1/3-occupied tail wave).
 template <int W, int MODE, int WN>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution)
-__global__ __launch_bounds__(NT, (WN == 4) ? 2 : 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
+__global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
     constexpr int WM = 2, BM = 128;
     constexpr int CKK = CK;                                     // input channels per K-step
     constexpr int KSTEPK = CKK * 9;
@@ -455,11 +455,15 @@ __global__ __launch_bounds__(NT, (WN == 4) ? 2 : 3) void conv3_patch_kernel(cons
     }
     const int tm = bid % tiles_m, tn = bid / tiles_m;
     const int m0 = tm * BM, n0 = tn * NPIX;
-    int b0, y0;
+    int b0, y0, x0 = 0;
     if (IMGS == 1) {
         const int tiles_per_img = d.NP / NPIX;
         b0 = tn / tiles_per_img;
-        y0 = (tn - b0 * tiles_per_img) * TR;                    // first output row of this tile
+        // first output pixel of this tile.  W is the TILE width: for images wider than the tile (W = 64 / 128 on 64..256 px
+        // rows) a tile is TR row segments starting at column x0, still NPIX consecutive pixels in row-major order.
+        const int pix0 = (tn - b0 * tiles_per_img) * NPIX;
+        y0 = pix0 / d.OW;
+        x0 = pix0 - y0 * d.OW;
     } else {
         b0 = tn * IMGS;
         y0 = 0;
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(NT, (WN == 4) ? 2 : 3) void conv3_patch_kernel(cons
         const int c = e / PLANE, rem = e - c * PLANE;
         const int img = rem / PIMG, rem2 = rem - img * PIMG;
         const int py = rem2 / PW, px = rem2 - py * PW;
-        int iy = y0 + py - 1, ix = px - 1;                      // coordinates in the (virtual, MODE 2: upsampled) input
+        int iy = y0 + py - 1, ix = x0 + px - 1;                 // coordinates in the (virtual, MODE 2: upsampled) input
         bool ok = e < CKK * PLANE && (b0 + img) < nb_total;
         if (MODE == 2) {
             ok = ok && (unsigned)iy < (unsigned)(2 * d.H) && (unsigned)ix < (unsigned)(2 * d.W);
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vd_gemm_desc
 static bool patch_eligible(const vd_gemm_desc& d) {
     if (d.a_mode != VD_A_ROW || d.a_bstride != 0) return false;
     if (d.b_mode != VD_B_CONV3 && d.b_mode != VD_B_CONV3_T && d.b_mode != VD_B_CONV3_UP) return false;
-    if (d.OW != 4 && d.OW != 8 && d.OW != 16 && d.OW != 32) return false;
+    if (d.OW != 4 && d.OW != 8 && d.OW != 16 && d.OW != 32 && d.OW != 64 && d.OW % 128 != 0) return false;
     if (d.OH != d.OW && d.OW < 16) return false;
     if (d.C % CK != 0 || d.OH * d.OW != d.NP || d.d_trans) return false;
     if (d.NP >= 128 ? (d.NP % 128 != 0) : (128 % d.NP != 0)) return false;
@@ -680,6 +684,14 @@ static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
         hipLaunchKernelGGL((conv3_patch_kernel<WW, MD, 2>), grid, dim3(NT), 0, st, d, ks_per);              \
         done = true;                                                                                     \
     }
+#define VD_PATCH_WIDE(WW, MD)                                                                            \
+    if (!done && (WW == 64 ? d.OW == 64 : (d.OW >= 128 && d.OW % 128 == 0)) && mode == MD) {             \
+        hipLaunchKernelGGL((conv3_patch_kernel<WW, MD, 2>), grid, dim3(NT), 0, st, d, ks_per);              \
+        done = true;                                                                                     \
+    }
+    VD_PATCH_WIDE(64, 0) VD_PATCH_WIDE(64, 1) VD_PATCH_WIDE(64, 2)
+    VD_PATCH_WIDE(128, 0) VD_PATCH_WIDE(128, 1) VD_PATCH_WIDE(128, 2)
+#undef VD_PATCH_WIDE
     VD_PATCH_CASE(32, 0) VD_PATCH_CASE(32, 1) VD_PATCH_CASE(32, 2)
     VD_PATCH_CASE(16, 0) VD_PATCH_CASE(16, 1) VD_PATCH_CASE(16, 2)
     VD_PATCH_CASE(8, 0) VD_PATCH_CASE(8, 1) VD_PATCH_CASE(8, 2)

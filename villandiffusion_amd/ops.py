@@ -103,7 +103,8 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     flops = 2.0 * M * N * K * (0.25 if b_mode == B_CONV3_DIL else 1.0)     # DIL: 3/4 of the taps are structural zeros
     tl = lib.vd_gemm_tile(C.byref(d))
     if tl in (4, 6):     # symbol names as rocprofv3 prints them
-        name = f"conv3_patch_kernel<{d.OW}, {0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)}, {4 if tl == 6 else 2}>"
+        tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images
+        name = f"conv3_patch_kernel<{tw}, {0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)}, {4 if tl == 6 else 2}>"
     elif tl == 5:
         name = f"gemm_plain_kernel<{a_mode}>"
     elif tl == 7:
