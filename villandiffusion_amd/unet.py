@@ -220,7 +220,7 @@ class _Attn:
             ops.softmax_col_fwd(P, B * nh, N)
             ops.gemm(v, P, o, M=dh, N=B * nh * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
                      b_bstride=nh * N * N, b_b2stride=N * N, ldd=N, d_bstride=Cc * N, d_b2stride=hs, **two)
-        elif N <= 64:
+        elif N < 64 or (N == 64 and B >= 64):     # one workgroup per image: needs a batch that fills the chip
             ops.attn_small_fwd(qkv, o, P, Cc, N, self.scale)
         else:
             q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
@@ -271,7 +271,7 @@ class _Attn:
                      b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
             ops.gemm(q, dP, dk, M=dh, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
                      b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
-        elif N <= 64:
+        elif N < 64 or (N == 64 and B >= 64):
             ops.attn_small_bwd(qkv, P, do, dqkv, Cc, N, self.scale)
         else:
             q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
