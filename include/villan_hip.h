@@ -135,14 +135,17 @@ int vd_colsum(const float* ws, float* out, int B, int C, int64_t ld, int accumul
  * K1 -- GroupNorm (+SiLU) forward/backward.  Replaces F.group_norm + F.silu of
  * ResnetBlock2D.norm{1,2}, AttentionBlock.group_norm, conv_norm_out.
  * ------------------------------------------------------------------------------------------ */
+/* ws: vd_groupnorm_ws_floats() floats of scratch, or NULL.  Groups larger than 12 K elements (256x256 images) are cut
+ * into chunks handled by separate workgroups when ws is given (fixed-order combination of the chunk statistics). */
+int64_t vd_groupnorm_ws_floats(int B, int C, int HW, int G);
 int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                      int B, int C, int HW, int G, float eps, int apply_silu, int64_t x_bstride, int64_t y_bstride,
-                     void* stream);
+                     float* ws, void* stream);
 /* dx = GN'(dy) (+ extra); dgamma_ws/dbeta_ws are [B][C] partials (reduce with vd_colsum). */
 int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws,
                      int B, int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride,
-                     int64_t extra_bstride, int64_t dx_bstride, void* stream);
+                     int64_t extra_bstride, int64_t dx_bstride, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4 -- attention softmax.  S is [nb][N][N] stored key-major: S[b][j][i] = k_j . q_i * scale;

@@ -343,16 +343,235 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float* __restrict
     }
 }
 
+// ---- multi-workgroup GroupNorm for slabs too large for registers (256x256 images at batch 8: B*G = 256 groups of 1 MB) ----
+// One workgroup per group streams a 1 MB slab three times at a fraction of the HBM rate.  Here a group is cut into S
+// chunks of <= 8192 floats, one workgroup each: pass A reduces the chunk (register-resident) to (mean, M2) partials,
+// pass B combines the S partials in FIXED order (Chan et al.) and normalises the chunk.  2 reads + 1 write, S x the
+// parallelism, deterministic.
+__device__ __forceinline__ void gn_combine(const float* __restrict__ part, int S, float n_c, float& mean, float& m2) {
+    float n = 0.f;
+    mean = 0.f;
+    m2 = 0.f;
+    for (int k = 0; k < S; ++k) {
+        const float mk = part[2 * k], qk = part[2 * k + 1];
+        const float nn = n + n_c, delta = mk - mean;
+        mean += delta * (n_c / nn);
+        m2 += qk + delta * delta * (n * n_c / nn);
+        n = nn;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int HW,
+                                                             int G, int S, int64_t x_bs) {
+    __shared__ float red[8];
+    constexpr int NV = 8;
+    const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
+    const int b = bg / G, g = bg - b * G;
+    const int cpg = C / G;
+    const int c4 = ((cpg * HW) >> 2) / S;                 // float4 per chunk
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + (int64_t)g * cpg * HW) + (int64_t)sc * c4;
+    const int tid = threadIdx.x;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        v[i] = (idx < c4) ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = block_sum_256(s, red) / (float)(c4 * 4);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (tid + i * 256 < c4) {
+            const float a0 = v[i][0] - mean, a1 = v[i][1] - mean, a2 = v[i][2] - mean, a3 = v[i][3] - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    q = block_sum_256(q, red + 4);
+    if (tid == 0) {
+        part[2 * (int64_t)blockIdx.x] = mean;
+        part[2 * (int64_t)blockIdx.x + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_chunk_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             const float* __restrict__ part, int C, int HW, int G, int S, float eps,
+                                                             int apply_silu, int64_t x_bs, int64_t y_bs) {
+    const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
+    const int b = bg / G, g = bg - b * G;
+    const int cpg = C / G;
+    const int c4 = ((cpg * HW) >> 2) / S;
+    float mean, m2;
+    gn_combine(part + 2 * (int64_t)bg * S, S, (float)(c4 * 4), mean, m2);
+    const float rstd = rsqrtf(m2 / (float)(cpg * HW) + eps);
+    if (sc == 0 && threadIdx.x == 0) {
+        mean_out[bg] = mean;
+        rstd_out[bg] = rstd;
+    }
+    const int64_t goff = (int64_t)g * cpg * HW;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff) + (int64_t)sc * c4;
+    f32x4* __restrict__ y4 = reinterpret_cast<f32x4*>(y + (int64_t)b * y_bs + goff) + (int64_t)sc * c4;
+    const int L = HW >> 2;
+    for (int idx = threadIdx.x; idx < c4; idx += 256) {
+        const int c = g * cpg + (sc * c4 + idx) / L;
+        const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+        const f32x4 v = x4[idx];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = v[j] * ga + be;
+            o[j] = apply_silu ? z * sigmoidf_(z) : z;
+        }
+        y4[idx] = o;
+    }
+}
+
+// backward: chunks never straddle a channel (S = cpg * chunks-per-channel).  Pass A: per-chunk (sum dz, sum dz*xhat);
+// pass B: fixed-order per-channel sums -> group means -> dx of the chunk.
+__global__ __launch_bounds__(256) void gn_chunk_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ part, int C, int HW, int G, int S, int apply_silu,
+                                                                 int64_t dy_bs, int64_t x_bs) {
+    __shared__ float red[8];
+    const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
+    const int b = bg / G, g = bg - b * G;
+    const int cpg = C / G;
+    const int c4 = ((cpg * HW) >> 2) / S;
+    const int64_t goff = (int64_t)g * cpg * HW;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff) + (int64_t)sc * c4;
+    const f32x4* __restrict__ d4 = reinterpret_cast<const f32x4*>(dy + (int64_t)b * dy_bs + goff) + (int64_t)sc * c4;
+    const float mean = mean_in[bg], rstd = rstd_in[bg];
+    const int c = g * cpg + (sc * c4) / (HW >> 2);
+    const float ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int idx = threadIdx.x; idx < c4; idx += 256) {
+        const f32x4 xv = x4[idx], dv = d4[idx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xv[j] - mean) * rstd;
+            float dz = dv[j];
+            if (apply_silu) {
+                const float z = xh * ga + be, sg = sigmoidf_(z);
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            s1 += dz;
+            s2 += dz * xh;
+        }
+    }
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red + 4);
+    if (threadIdx.x == 0) {
+        part[2 * (int64_t)blockIdx.x] = s1;
+        part[2 * (int64_t)blockIdx.x + 1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_chunk_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ extra, float* __restrict__ dx,
+                                                                 float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws,
+                                                                 const float* __restrict__ part, int C, int HW, int G, int S,
+                                                                 int apply_silu, int64_t dy_bs, int64_t x_bs, int64_t ex_bs,
+                                                                 int64_t dx_bs) {
+    __shared__ float ch_s1[64], ch_s2[64];
+    const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
+    const int b = bg / G, g = bg - b * G;
+    const int cpg = C / G;
+    const int spc = S / cpg;                              // chunks per channel
+    const int c4 = ((cpg * HW) >> 2) / S;
+    const int tid = threadIdx.x;
+    if (tid < cpg) {
+        const float* __restrict__ pp = part + 2 * ((int64_t)bg * S + (int64_t)tid * spc);
+        float a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < spc; ++k) {
+            a1 += pp[2 * k];
+            a2 += pp[2 * k + 1];
+        }
+        ch_s1[tid] = a1;
+        ch_s2[tid] = a2;
+        if (sc == 0) {
+            dbeta_ws[(int64_t)b * C + g * cpg + tid] = a1;
+            dgamma_ws[(int64_t)b * C + g * cpg + tid] = a2;
+        }
+    }
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const float ga_ = gamma[g * cpg + cl];
+        m1 += ga_ * ch_s1[cl];
+        m2 += ga_ * ch_s2[cl];
+    }
+    const float inv_n = 1.f / (float)(cpg * HW);
+    m1 *= inv_n;
+    m2 *= inv_n;
+    const int64_t goff = (int64_t)g * cpg * HW;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff) + (int64_t)sc * c4;
+    const f32x4* __restrict__ d4 = reinterpret_cast<const f32x4*>(dy + (int64_t)b * dy_bs + goff) + (int64_t)sc * c4;
+    const f32x4* __restrict__ e4 = extra ? reinterpret_cast<const f32x4*>(extra + (int64_t)b * ex_bs + goff) + (int64_t)sc * c4 : nullptr;
+    f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(dx + (int64_t)b * dx_bs + goff) + (int64_t)sc * c4;
+    const float mean = mean_in[bg], rstd = rstd_in[bg];
+    const int c = g * cpg + sc / spc;
+    const float ga = gamma[c], be = beta[c];
+    for (int idx = tid; idx < c4; idx += 256) {
+        const f32x4 xv = x4[idx], dv = d4[idx];
+        f32x4 ev = {0.f, 0.f, 0.f, 0.f}, o;
+        if (e4) ev = e4[idx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xv[j] - mean) * rstd;
+            float dz = dv[j];
+            if (apply_silu) {
+                const float z = xh * ga + be, sg = sigmoidf_(z);
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            o[j] = rstd * (dz * ga - m1 - xh * m2) + ev[j];
+        }
+        o4[idx] = o;
+    }
+}
+
+// Chunks per group for the multi-workgroup path (0: not applicable): chunk <= 8192 floats, inside one channel, S <= 256.
+static int gn_chunks(int B, int C, int HW, int G) {
+    const int cpg = C / G;
+    const int64_t slab = (int64_t)cpg * HW;
+    if (slab <= 12 * 1024 || HW % 4 != 0 || cpg > 64) return 0;
+    int per_ch = 1;
+    while (HW / per_ch > 8192 && (HW / per_ch) % 2 == 0) per_ch *= 2;
+    if (HW / per_ch > 8192 || (HW / per_ch) % 4 != 0 || HW % per_ch != 0) return 0;
+    const int S = cpg * per_ch;
+    if (S > 256 || (int64_t)B * G * S > (1 << 22)) return 0;
+    return S;
+}
+
 }  // namespace
+
+extern "C" int64_t vd_groupnorm_ws_floats(int B, int C, int HW, int G) {
+    if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
+    const int S = gn_chunks(B, C, HW, G);
+    return S ? 2 * (int64_t)B * G * S : 0;
+}
 
 extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                 int B, int C, int HW, int G, float eps, int apply_silu, int64_t x_bstride, int64_t y_bstride,
-                                void* stream) {
+                                float* ws, void* stream) {
     VD_REQUIRE(x && gamma && beta && y && mean && rstd, "vd_groupnorm_fwd: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "vd_groupnorm_fwd: bad dims B=%d C=%d HW=%d G=%d", B, C, HW, G);
     const int64_t slab = (int64_t)(C / G) * HW;
-    const bool reg_ok = (HW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) && ((((uintptr_t)x) & 15) == 0) &&
-                        ((((uintptr_t)y) & 15) == 0) && slab <= 12 * 1024;
+    const bool al = (HW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) && ((((uintptr_t)x) & 15) == 0) &&
+                    ((((uintptr_t)y) & 15) == 0);
+    const bool reg_ok = al && slab <= 12 * 1024;
+    const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
+    if (S) {       // large slabs: S workgroups per group (partials in ws, vd_groupnorm_ws_floats())
+        hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, ws, C, HW, G, S, x_bstride);
+        hipLaunchKernelGGL(gn_chunk_apply_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd,
+                           ws, C, HW, G, S, eps, apply_silu, x_bstride, y_bstride);
+        VD_LAUNCH_CHECK("vd_groupnorm_fwd");
+        return 0;
+    }
 #define VD_GN_FWD(NVV)                                                                                                       \
     hipLaunchKernelGGL((gn_fwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, \
                        C, HW, G, eps, apply_silu, x_bstride, y_bstride)
@@ -372,13 +591,23 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
 extern "C" int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                 const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws, int B,
                                 int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride,
-                                int64_t extra_bstride, int64_t dx_bstride, void* stream) {
+                                int64_t extra_bstride, int64_t dx_bstride, float* ws, void* stream) {
     VD_REQUIRE(dy && x && mean && rstd && gamma && beta && dx && dgamma_ws && dbeta_ws, "vd_groupnorm_bwd: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 64, "vd_groupnorm_bwd: bad dims");
     const int64_t slab = (int64_t)(C / G) * HW;
     const int L = HW / 4;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)extra)) & 15) == 0 &&
                     ((x_bstride | dy_bstride | dx_bstride | extra_bstride) & 3) == 0;
+    const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
+    if (S) {
+        hipLaunchKernelGGL(gn_chunk_bwd_stats_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
+                           beta, ws, C, HW, G, S, apply_silu, dy_bstride, x_bstride);
+        hipLaunchKernelGGL(gn_chunk_bwd_apply_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
+                           beta, extra, dx, dgamma_ws, dbeta_ws, ws, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride,
+                           dx_bstride);
+        VD_LAUNCH_CHECK("vd_groupnorm_bwd");
+        return 0;
+    }
     const bool reg_ok = al && HW % 4 == 0 && slab <= 12 * 1024 &&
                         ((L >= 64 && L % 64 == 0) || (L < 64 && (L & (L - 1)) == 0 && L > 0)) && getenv("VD_GN_BWD_GENERIC") == nullptr;
 #define VD_GN_BWD(NVV)                                                                                                         \

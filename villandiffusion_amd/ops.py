@@ -265,12 +265,18 @@ def colsum(ws, out, Bn, Cc, ld=None, accumulate=False):
 
 
 # --------------------------------------------------------------------------------------------- GroupNorm
+def _gn_ws(Bn, Cc, HW, G, device):
+    """Scratch for the multi-workgroup GroupNorm of large groups (None when the single-workgroup kernels apply)."""
+    need = _lib().vd_groupnorm_ws_floats(Bn, Cc, HW, G)
+    return _gemm_ws(need, device) if need > 0 else None
+
+
 def groupnorm_fwd(x, gamma, beta, y, mean, rstd, G, eps, silu):
     Bn, Cc, H, W, xbs = _img(x)
     ybs = _img(y)[4]
     assert y.shape == x.shape and mean.numel() >= Bn * G and rstd.numel() >= Bn * G
     L.check(_lib().vd_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps,
-                                    int(silu), xbs, ybs, _s()), "vd_groupnorm_fwd")
+                                    int(silu), xbs, ybs, _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_fwd")
     return y
 
 
@@ -281,7 +287,7 @@ def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma_ws, dbeta_ws, G, si
     assert dgamma_ws.numel() >= Bn * Cc and dbeta_ws.numel() >= Bn * Cc
     L.check(_lib().vd_groupnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(extra), _p(dx),
                                     _p(dgamma_ws), _p(dbeta_ws), Bn, Cc, H * W, G, int(silu), dbs, xbs, ebs, dxbs,
-                                    _s()), "vd_groupnorm_bwd")
+                                    _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_bwd")
     return dx
 
 
