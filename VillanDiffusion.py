@@ -276,6 +276,10 @@ def checkpoint(cfg, trainer, pipeline, epoch, step):
     pipeline.save_pretrained(cfg.output_dir)
 
 
+# batch key regressed against (reference VillanDiffusion.py:1159 'target'); rm_backdoor_VillanDiffusion.py sets 'image'
+TARGET_LATENT_KEY = "target"
+
+
 def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
     import torch
     from loss import LossFn
@@ -306,7 +310,7 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
         for i, batch in enumerate(loader):
             bs = batch["pixel_values"].shape[0]
             t = torch.randint(0, T, (bs,), device=model.device).long()            # reference :1151
-            loss = trainer.train_step(batch, t, last_batch=(i == nb - 1))
+            loss = trainer.train_step(batch, t, last_batch=(i == nb - 1), target_key=TARGET_LATENT_KEY)
             step += 1
             if rank == 0 and (step % 50 == 0 or i == nb - 1):
                 print(f"epoch {epoch} step {step} loss {float(loss):.5f} lr {trainer.lr:.3e}", flush=True)
