@@ -216,6 +216,14 @@ int vd_postprocess(const float* x, float* out, int B, int C, int HW, float mul, 
  * z / zq: [B, D, HW] with batch strides, codebook [n_e, D], D <= 16. */
 int vd_vq_nearest(const float* z, const float* codebook, float* zq, int64_t* idx, int B, int D, int HW, int n_e,
                   int64_t z_bstride, int64_t q_bstride, void* stream);
+/* NCSN++ (SDE-VE score network, reference model.py:839-894) helpers.
+ * vd_fir_resample2: diffusers upsample_2d / downsample_2d with the (1,3,3,1) FIR kernel, factor 2, on `planes` images of
+ *   H x W; out = scale * resample(x) (+ out).  The adjoints are the same kernels: d(up)^T g = 4 down(g), d(down)^T g = up(g)/4.
+ * vd_fourier_embedding: GaussianFourierProjection(log=True): emb[b] = [sin(log t_b W 2pi), cos(log t_b W 2pi)].
+ * vd_rowscale: out[b][:] = x[b][:] * s[b] (divide=0) or / s[b] (divide=1)  (UNet2DModel's final `sample / timesteps`). */
+int vd_fir_resample2(const float* x, float* out, int64_t planes, int H, int W, int up, float scale, int accumulate, void* stream);
+int vd_fourier_embedding(const float* t, const float* W, float* emb, int B, int half, void* stream);
+int vd_rowscale(const float* x, const float* s, float* out, int B, int64_t inner, int divide, void* stream);
 /* z ~ N(0,1) from Philox4x32-10 (throughput mode noise). */
 int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 

@@ -509,6 +509,110 @@ extern "C" int vd_vq_nearest(const float* z, const float* codebook, float* zq, i
     return 0;
 }
 
+// ---- NCSN++ helpers (diffusers upfirdn2d FIR resampling with the (1,3,3,1) kernel, Fourier time embedding) ---------------
+// up  : out[2a]   = (x[a-1] + 3 x[a]) / 4,  out[2a+1] = (3 x[a] + x[a+1]) / 4     (per axis; zero outside)  = upsample_2d
+// down: out[a]    = (x[2a-1] + 3 x[2a] + 3 x[2a+1] + x[2a+2]) / 8                                           = downsample_2d
+// `scale` folds the adjoint factors: d(up)/dx applied to g is 4 * down(g); d(down)/dx applied to g is up(g) / 4.
+__global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes,
+                                                      int H, int W, float scale, int accumulate) {
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t total = planes * OH * OW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % OW);
+        const int64_t r = i / OW;
+        const int oy = (int)(r % OH);
+        const int64_t pl = r / OH;
+        const float* __restrict__ xp = x + pl * H * W;
+        const int ay = oy >> 1, ax = ox >> 1;
+        // taps along y: (row, weight) pairs
+        const int y0 = (oy & 1) ? ay : ay - 1, y1 = (oy & 1) ? ay + 1 : ay;
+        const float wy0 = (oy & 1) ? 0.75f : 0.25f, wy1 = (oy & 1) ? 0.25f : 0.75f;
+        const int x0 = (ox & 1) ? ax : ax - 1, x1 = (ox & 1) ? ax + 1 : ax;
+        const float wx0 = (ox & 1) ? 0.75f : 0.25f, wx1 = (ox & 1) ? 0.25f : 0.75f;
+        auto at = [&](int yy, int xx) -> float {
+            return ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? xp[yy * W + xx] : 0.f;
+        };
+        const float v = wy0 * (wx0 * at(y0, x0) + wx1 * at(y0, x1)) + wy1 * (wx0 * at(y1, x0) + wx1 * at(y1, x1));
+        out[i] = accumulate ? out[i] + scale * v : scale * v;
+    }
+}
+
+__global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes,
+                                                        int H, int W, float scale, int accumulate) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = planes * OH * OW;
+    const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % OW);
+        const int64_t r = i / OW;
+        const int oy = (int)(r % OH);
+        const int64_t pl = r / OH;
+        const float* __restrict__ xp = x + pl * H * W;
+        float v = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < 4; ++jy) {
+            const int yy = 2 * oy + jy - 1;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            float row = 0.f;
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                const int xx = 2 * ox + jx - 1;
+                if ((unsigned)xx < (unsigned)W) row += k[jx] * xp[yy * W + xx];
+            }
+            v += k[jy] * row;
+        }
+        out[i] = accumulate ? out[i] + scale * v : scale * v;
+    }
+}
+
+// emb[b][j] = sin(log(t_b) * W_j * 2pi), emb[b][half + j] = cos(...)   (GaussianFourierProjection, log=True)
+__global__ void fourier_embedding_kernel(const float* __restrict__ t, const float* __restrict__ W, float* __restrict__ emb, int B,
+                                         int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    const float a = (logf(t[b]) * W[j]) * 2.f * 3.14159265358979323846f;
+    emb[(int64_t)b * 2 * half + j] = sinf(a);
+    emb[(int64_t)b * 2 * half + half + j] = cosf(a);
+}
+
+// out[b][i] = x[b][i] * s[b]   or   x[b][i] / s[b]
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ out,
+                                                       int B, int64_t inner, int divide) {
+    const int64_t total = (int64_t)B * inner;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float sv = s[i / inner];
+        out[i] = divide ? x[i] / sv : x[i] * sv;
+    }
+}
+
+extern "C" int vd_fir_resample2(const float* x, float* out, int64_t planes, int H, int W, int up, float scale, int accumulate,
+                                void* stream) {
+    VD_REQUIRE(x && out && planes > 0 && H > 0 && W > 0, "vd_fir_resample2: bad args");
+    VD_REQUIRE(up || (H % 2 == 0 && W % 2 == 0), "vd_fir_resample2: downsampling needs even dims");
+    const int64_t n = up ? planes * 4 * H * W : planes * (H / 2) * (W / 2);
+    if (up)
+        hipLaunchKernelGGL(fir_up2_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, out, planes, H, W, scale, accumulate);
+    else
+        hipLaunchKernelGGL(fir_down2_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, out, planes, H, W, scale, accumulate);
+    VD_LAUNCH_CHECK("vd_fir_resample2");
+    return 0;
+}
+
+extern "C" int vd_fourier_embedding(const float* t, const float* W, float* emb, int B, int half, void* stream) {
+    VD_REQUIRE(t && W && emb && B > 0 && half > 0, "vd_fourier_embedding: bad args");
+    hipLaunchKernelGGL(fourier_embedding_kernel, dim3((B * half + 255) / 256), dim3(256), 0, ST, t, W, emb, B, half);
+    VD_LAUNCH_CHECK("vd_fourier_embedding");
+    return 0;
+}
+
+extern "C" int vd_rowscale(const float* x, const float* s, float* out, int B, int64_t inner, int divide, void* stream) {
+    VD_REQUIRE(x && s && out && B > 0 && inner > 0, "vd_rowscale: bad args");
+    hipLaunchKernelGGL(rowscale_kernel, dim3(egrid((int64_t)B * inner)), dim3(EB), 0, ST, x, s, out, B, inner, divide);
+    VD_LAUNCH_CHECK("vd_rowscale");
+    return 0;
+}
+
 extern "C" int vd_poison_batch(const uint8_t* img, const int64_t* idx, const uint8_t* flags, const float* trigger, const float* target,
                                float* pixel_values, float* tgt_out, float* image_out, int B, int C, int H, int W, float vmin,
                                float vmax, int R_trigger_only, void* stream) {

@@ -77,6 +77,9 @@ PROTOTYPES = {
     "vd_batch_l2norm": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "vd_postprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "vd_randn": (_i32, [_vp, _i64, C.c_uint64, C.c_uint64, _vp]),
+    "vd_fir_resample2": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "vd_fourier_embedding": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "vd_rowscale": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "vd_vq_nearest": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_poison_batch": (_i32, [_vp] * 8 + [_i32] * 4 + [_f32, _f32, _i32, _vp]),
 }

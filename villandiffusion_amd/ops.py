@@ -423,6 +423,29 @@ def postprocess(x, out, mul, add, lo, hi, to_nhwc):
     return out
 
 
+def fir_resample2(x, out, up: bool, scale: float = 1.0, accumulate: bool = False):
+    """diffusers upsample_2d / downsample_2d ((1,3,3,1) FIR, factor 2) on contiguous [B, C, H, W]; out = scale * f(x) (+ out)."""
+    Bn, Cc, H, W = x.shape
+    assert x.is_contiguous() and out.is_contiguous()
+    assert out.shape == ((Bn, Cc, 2 * H, 2 * W) if up else (Bn, Cc, H // 2, W // 2)), (x.shape, out.shape, up)
+    L.check(_lib().vd_fir_resample2(_p(x), _p(out), Bn * Cc, H, W, int(up), scale, int(accumulate), _s()), "vd_fir_resample2")
+    return out
+
+
+def fourier_embedding(t_f32, W, emb):
+    Bn, half = t_f32.numel(), W.numel()
+    assert emb.shape == (Bn, 2 * half) and emb.is_contiguous()
+    L.check(_lib().vd_fourier_embedding(_p(t_f32), _p(W), _p(emb), Bn, half, _s()), "vd_fourier_embedding")
+    return emb
+
+
+def rowscale(x, s, out, divide=False):
+    Bn = x.shape[0]
+    assert x.is_contiguous() and out.is_contiguous() and s.numel() == Bn
+    L.check(_lib().vd_rowscale(_p(x), _p(s), _p(out), Bn, x.numel() // Bn, int(divide), _s()), "vd_rowscale")
+    return out
+
+
 def vq_nearest(z, codebook, zq, idx=None):
     """zq[b, :, p] = codebook[argmin_e |z[b, :, p] - e|^2]  (VectorQuantizer forward)."""
     Bn, D, H, W, zbs = _img(z)

@@ -89,17 +89,18 @@ class _Conv:
 
 
 class _Norm:
-    def __init__(self, net, prefix, ch, silu):
+    def __init__(self, net, prefix, ch, silu, groups=None):
         self.net, self.prefix, self.ch, self.silu = net, prefix, ch, silu
+        self.groups = net.groups if groups is None else groups       # NCSN++ sizes the groups per layer: min(ch // 4, 32)
         net._decl(prefix + ".weight", (ch,), ones=True)
         net._decl(prefix + ".bias", (ch,), zeros=True)
 
     def fwd(self, x, y):
         net = self.net
         B = x.shape[0]
-        mean = torch.empty(B * net.groups, device=x.device, dtype=torch.float32)
+        mean = torch.empty(B * self.groups, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        ops.groupnorm_fwd(x, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], y, mean, rstd, net.groups,
+        ops.groupnorm_fwd(x, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], y, mean, rstd, self.groups,
                           net.eps, self.silu)
         return mean, rstd
 
@@ -108,7 +109,7 @@ class _Norm:
         B = x.shape[0]
         wg, wb = net.scratch_bc(B, self.ch, 1), net.scratch_bc(B, self.ch, 2)
         ops.groupnorm_bwd(dy, x, mean, rstd, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], dx, wg, wb,
-                          net.groups, self.silu, extra=extra)
+                          self.groups, self.silu, extra=extra)
         ops.colsum(wg, net.G[self.prefix + ".weight"], B, self.ch, accumulate=True)
         ops.colsum(wb, net.G[self.prefix + ".bias"], B, self.ch, accumulate=True)
         return dx
@@ -185,12 +186,12 @@ class _Attn:
     """Spatial self-attention in NCHW (no transposes): see csrc/vd_attn.hip.  heads = ch // attention_head_dim (1 for
     the DDPM checkpoints); a head is a channel slice of q/k/v, so multi-head is the same GEMMs on offset views."""
 
-    def __init__(self, net, prefix, ch, head_dim=None):
+    def __init__(self, net, prefix, ch, head_dim=None, groups=None):
         self.net, self.prefix, self.ch = net, prefix, ch
         self.heads = 1 if head_dim is None else ch // head_dim
         if ch % self.heads:
             raise ValueError(f"{prefix}: {ch} channels do not split into heads of {head_dim}")
-        self.norm = _Norm(net, prefix + ".group_norm", ch, False)
+        self.norm = _Norm(net, prefix + ".group_norm", ch, False, groups)
         self.qkv_w, self.qkv_b = net._decl_qkv(prefix, ch)
         net._decl(prefix + ".to_out.0.weight", (ch, ch), fan_in=ch)
         net._decl(prefix + ".to_out.0.bias", (ch,), fan_in=ch, is_bias=True)
