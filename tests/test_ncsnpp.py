@@ -56,15 +56,15 @@ def test_oracle_output_is_divided_by_sigma():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,B", [(SMALL, 3), (dict(layers_per_block=1), 2)])
-def test_hip_forward_backward_match_oracle(cfg, B):
+@pytest.mark.parametrize("cfg,B,wscale", [(SMALL, 3, 0.1), (dict(layers_per_block=1), 2, 0.1), (SMALL, 3, 1.0)])
+def test_hip_forward_backward_match_oracle(cfg, B, wscale):
     torch.manual_seed(1)
     ref = NCSNppRef(**cfg)
     with torch.no_grad():
         for n, p in ref.named_parameters():
             if "norm" in n:
                 p.add_(0.1 * torch.randn_like(p))
-        ref.time_proj.weight.mul_(0.1)            # keep sin/cos arguments moderate: fp32 range reduction differs by ~1 ulp of the argument
+        ref.time_proj.weight.mul_(wscale)         # 1.0 = the real scale (16): sin/cos arguments up to ~1e3 rad
     net = NCSNppModel(**cfg)
     net.load_state_dict(ref.state_dict())
     S = ref.config.sample_size
@@ -89,3 +89,43 @@ def test_hip_forward_backward_match_oracle(cfg, B):
             worst = (e, n)
     print(f"[parity] NCSN++ fwd rel_err={ef:.3e}; worst param-grad rel_err={worst[0]:.3e} at {worst[1]}")
     assert ef < 1e-4 and worst[0] < 1e-3, (ef, worst)
+
+
+@pytest.mark.gpu
+def test_ve_training_step_sampling_and_disk_roundtrip_with_ncsnpp(tmp_path):
+    """The SDE-VE row end to end with its own network: VE loss (model fed sigma_t, output already divided by sigma) vs the
+    oracle, two optimiser steps, predictor-corrector sampling, save_pretrained -> from_pretrained picks NCSNppModel."""
+    from oracle.loss_ref import LossFnRef
+    from oracle.schedulers_ref import ScoreSdeVeSchedulerRef
+    from villandiffusion_amd import schedulers as S
+    from villandiffusion_amd.loss import LossFn
+    from villandiffusion_amd.pipelines import DiffusionPipeline, ScoreSdeVePipeline
+    from villandiffusion_amd.trainer import Trainer
+    torch.manual_seed(0)
+    ref = NCSNppRef(**SMALL)
+    net = NCSNppModel(**SMALL)
+    net.load_state_dict(ref.state_dict())
+    kw = dict(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, snr=0.075)
+    sched, sref = S.ScoreSdeVeScheduler(**kw), ScoreSdeVeSchedulerRef(**kw)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.rand(3, 3, 16, 16, generator=g)
+    Rr = torch.rand(3, 3, 16, 16, generator=g)
+    Rr[:1] = 0
+    eps = torch.randn(3, 3, 16, 16, generator=g)
+    t = torch.tensor([3, 900, 1999])
+    l_ref = LossFnRef(sref, "SDE-VE", psi=0).p_loss(ref, x0, Rr, t, noise=eps)
+    lf = LossFn(sched, "SDE-VE", psi=0)
+    tr = Trainer(net, lf, lr=1e-4, total_steps=100, warmup_steps=10)
+    w0 = net.time_proj.weight.detach().clone()
+    l = tr.train_step({"target": x0.cuda(), "pixel_values": Rr.cuda()}, t.cuda(), noise=eps.cuda())
+    assert abs(float(l) - float(l_ref)) <= 5e-5 * abs(float(l_ref)), (float(l), float(l_ref))
+    l2 = tr.train_step({"target": x0.cuda(), "pixel_values": Rr.cuda()}, t.cuda(), noise=eps.cuda())
+    assert bool(torch.isfinite(net.flat_param).all()) and float(l2) == float(l2)
+    assert torch.equal(net.time_proj.weight, w0)                       # the Fourier features stay fixed
+    pipe = ScoreSdeVePipeline(net, sched)
+    out = pipe(batch_size=2, generator=torch.Generator().manual_seed(1), num_inference_steps=4, output_type=None)
+    assert out.images.shape == (2, 16, 16, 3) and bool((out.images >= 0).all()) and bool((out.images <= 1).all())
+    d = str(tmp_path / "ncsnpp")
+    pipe.save_pretrained(d)
+    pipe2 = DiffusionPipeline.from_pretrained(d)
+    assert type(pipe2.unet).__name__ == "NCSNppModel" and torch.equal(pipe2.unet.flat_param, net.flat_param)

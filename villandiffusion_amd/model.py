@@ -21,6 +21,7 @@ from .pipelines import (DDIMPipeline, DDPMPipeline, DiffusionPipeline, KarrasVeP
 from .schedulers import (DDIMScheduler, DDPMScheduler, DEISMultistepScheduler, DPMSolverMultistepScheduler,
                          HeunDiscreteScheduler, KarrasVeScheduler, LMSDiscreteScheduler, PNDMScheduler, ScoreSdeVeScheduler,
                          UniPCMultistepScheduler)
+from .ncsnpp import NCSNppModel
 from .unet import UNet2DModel
 from .vqmodel import VQModel
 
@@ -46,6 +47,14 @@ LDM_CELEBA_UNET_ARCH = dict(act_fn="silu", attention_head_dim=32, block_out_chan
 LDM_CELEBA_VQ_ARCH = dict(act_fn="silu", block_out_channels=[128, 256, 512], down_block_types=["DownEncoderBlock2D"] * 3,
                           in_channels=3, latent_channels=3, layers_per_block=2, num_vq_embeddings=8192, out_channels=3,
                           sample_size=256, up_block_types=["UpDecoderBlock2D"] * 3)
+
+
+# model.py:839-857 / 876-894: the NCSN++ architecture of the NCSNPP-*-DEFAULT ids (61 894 924 parameters at 32x32)
+NCSNPP_32_ARCH = dict(act_fn="silu", attention_head_dim=None, block_out_channels=[128, 256, 256, 256], center_input_sample=False,
+                      down_block_types=["SkipDownBlock2D", "AttnSkipDownBlock2D", "SkipDownBlock2D", "SkipDownBlock2D"],
+                      downsample_padding=1, flip_sin_to_cos=True, freq_shift=0, layers_per_block=4,
+                      mid_block_scale_factor=1.41421356237, norm_eps=1e-06, norm_num_groups=None, time_embedding_type="fourier",
+                      up_block_types=["SkipUpBlock2D", "SkipUpBlock2D", "AttnSkipUpBlock2D", "SkipUpBlock2D"])
 
 
 class DiffuserModelSched:
@@ -155,9 +164,15 @@ class DiffuserModelSched:
     @classmethod
     def _get_model_sched_ve(cls, ckpt_id, clip_sample, noise_sched_type=None, build_model=True):
         """model.py:668-703: VE-SDE with T=2000, sigma in [0.01, 380], snr 0.075, one corrector step."""
+        model = None
         if build_model:
-            raise NotImplementedError(f"pretrained VE checkpoints ('{ckpt_id}') are NCSN++ networks: a 'next' row (SURVEY.md §8f.5); "
-                                      f"from-scratch ids (e.g. {cls.DDPM_32_DEFAULT}) train the DDPM-style UNet under SDE-VE")
+            d = cls._resolve_dir(ckpt_id)
+            if d is None:
+                raise FileNotFoundError(
+                    f"pretrained SDE-VE checkpoint '{ckpt_id}' is not available locally (no network / HF cache). Pass a "
+                    f"diffusers-layout directory as --ckpt, set VILLAN_CKPT_ROOT, or use a from-scratch id such as "
+                    f"'{cls.NCSNPP_32_DEFAULT}'.")
+            model = ScoreSdeVePipeline.from_pretrained(d).unet
         karras = {cls.EDM_VE_SCHED: {}, cls.EDM_VE_SDE_SCHED: {"s_churn": 100}, cls.EDM_VE_ODE_SCHED: {"s_churn": 0}}   # model.py:685-693
         if noise_sched_type in karras:
             sched = KarrasVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, **karras[noise_sched_type])
@@ -171,7 +186,7 @@ class DiffuserModelSched:
         clip = cls.get_sample_clip(clip_sample, cls.CLIP_SAMPLE_DEFAULT)
         if clip is not None:
             sched.config.clip_sample = clip
-        return None, None, sched, cls._pipeline_factory(pipe_cls)
+        return model, None, sched, cls._pipeline_factory(pipe_cls)
 
     @classmethod
     def _get_model_sched(cls, ckpt_id, clip_sample, clip_sample_range=None, noise_sched_type=None, sde_type=SDE_VP,
@@ -270,8 +285,22 @@ class DiffuserModelSched:
             model.requires_grad_(True)
             vae.requires_grad_(False)
             return model, vae, sched, gp
-        if ckpt.startswith("NCSNPP"):
-            raise NotImplementedError(f"ckpt {ckpt}: the NCSN++ model family is a 'next' row (SURVEY.md §8f.5)")
+        if ckpt in (cls.NCSNPP_32_DEFAULT, cls.NCSNPP_CIFAR10_DEFAULT):                    # model.py:836-858, 876-898
+            if ckpt == cls.NCSNPP_32_DEFAULT:
+                cls.check_image_size_channel(image_size, channels)
+            else:
+                image_size, channels = 32, 3
+            _, vae, sched, gp = cls._get_model_sched(cls.HUB_IDS[cls.NCSNPP_CELEBA_HQ_256], clip_sample, clip_sample_range,
+                                                     noise_sched_type, sde_type, build_model=False)
+            model = NCSNppModel(in_channels=channels, out_channels=channels, sample_size=image_size, **NCSNPP_32_ARCH)
+            model.requires_grad_(True)
+            model.time_proj.weight.requires_grad_(False)
+            return model, vae, sched, gp
+        if ckpt in (cls.NCSNPP_CELEBA_HQ_DEFAULT, cls.NCSNPP_CHURCH_DEFAULT):
+            src = cls.NCSNPP_CELEBA_HQ_256 if ckpt == cls.NCSNPP_CELEBA_HQ_DEFAULT else cls.NCSNPP_CHURCH_256
+            model, vae, sched, gp = cls.get_pretrained(src, clip_sample, clip_sample_range, noise_sched_type, sde_type=sde_type)
+            model.reset_parameters()
+            return model, vae, sched, gp
         return cls.get_pretrained(ckpt, clip_sample, clip_sample_range, noise_sched_type, sde_type=sde_type)
 
     @classmethod

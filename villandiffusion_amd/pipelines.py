@@ -137,7 +137,11 @@ class DiffusionPipeline:
         with open(os.path.join(path, "unet", "config.json")) as f:
             cfg = json.load(f)
         cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
-        unet = UNet2DModel(**cfg)
+        if cfg.get("time_embedding_type", "positional") == "fourier":         # NCSN++ (fusing/cifar10-ncsnpp-ve, google/ncsnpp-*)
+            from .ncsnpp import NCSNppModel
+            unet = NCSNppModel(**cfg)
+        else:
+            unet = UNet2DModel(**cfg)
         st = os.path.join(path, "unet", "diffusion_pytorch_model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file

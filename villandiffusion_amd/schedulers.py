@@ -664,8 +664,9 @@ class ScoreSdeVeScheduler:
     order = 1
 
     def __init__(self, num_train_timesteps=2000, snr=0.15, sigma_min=0.01, sigma_max=1348.0, sampling_eps=1e-5, correct_steps=1, **extra):
+        extra.setdefault("clip_sample", False)           # (a saved scheduler_config.json carries it back in)
         self.config = _Config(num_train_timesteps=num_train_timesteps, snr=snr, sigma_min=sigma_min, sigma_max=sigma_max,
-                              sampling_eps=sampling_eps, correct_steps=correct_steps, clip_sample=False, **extra)
+                              sampling_eps=sampling_eps, correct_steps=correct_steps, **extra)
         self.init_noise_sigma = sigma_max
         self.timesteps = None
         self.device_rng_seed: Optional[int] = None
