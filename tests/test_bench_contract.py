@@ -1,0 +1,42 @@
+"""The bench line the driver parses (task contract ④): schema of the committed round-1 line + agreement between the HIP-event
+average of the roofline kernel and the committed rocprofv3 summary.  CPU only: reads profiles/, runs nothing."""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_bench_line_schema():
+    d = _line("r01_bench_default.json")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3           # whole-job throughput of K timed steps
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["peak"] == 157.3 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
+
+
+def test_roofline_kernel_agrees_with_rocprof_summary():
+    d = _line("r01_bench_under_rocprof.json")
+    name, avg_us = d["roofline"]["kernel"], d["roofline"]["avg_launch_us"]
+    with open(os.path.join(ROOT, "profiles", "r01_bench_kernel_stats.csv")) as f:
+        rows = [r for r in csv.DictReader(f) if name + "(" in r["Name"]]
+    assert len(rows) == 1, name
+    prof_us = float(rows[0]["AverageNs"]) / 1e3
+    assert abs(prof_us - avg_us) / prof_us < 0.05, (prof_us, avg_us)
+    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        assert name in json.load(f)["kernels"]
+    with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")) as f:
+        k = json.load(f)["kernels"][name]
+    assert abs(k["MfmaUtil"] - d["roofline"]["frac"]) < 0.03            # MFMA-busy counter == achieved / peak

@@ -17,19 +17,30 @@ CFG = {
                    down_block_types=("DownBlock2D",) + ("AttnDownBlock2D",) * 3,
                    up_block_types=("AttnUpBlock2D",) * 3 + ("UpBlock2D",)), 8),
 }
+CFG["ncsnpp32"] = (None, 128)
 name = sys.argv[1] if len(sys.argv) > 1 else "celebahq256"
 cfg, B = CFG[name]
 if len(sys.argv) > 2:
     B = int(sys.argv[2])
-net = UNet2DModel(**cfg)
-net.reset_parameters(0)
-sched = S.DDPMScheduler()
-tr = Trainer(net, LossFn(sched, "SDE-VP"), lr=2e-4, total_steps=1000)
+if name == "ncsnpp32":        # SDE-VE: NCSN++ (model.py:839-857) with the VE loss
+    from villandiffusion_amd.model import NCSNPP_32_ARCH
+    from villandiffusion_amd.ncsnpp import NCSNppModel
+    net = NCSNppModel(in_channels=3, out_channels=3, sample_size=32, **NCSNPP_32_ARCH)
+    net.reset_parameters(0)
+    sched = S.ScoreSdeVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0, snr=0.075)
+    tr = Trainer(net, LossFn(sched, "SDE-VE", psi=0), lr=2e-4, total_steps=1000)
+else:
+    net = UNet2DModel(**cfg)
+    net.reset_parameters(0)
+    sched = S.DDPMScheduler()
+    tr = Trainer(net, LossFn(sched, "SDE-VP"), lr=2e-4, total_steps=1000)
 Sz = net.sample_size
 g = torch.Generator(device="cuda").manual_seed(0)
 x0 = torch.randn(B, 3, Sz, Sz, device="cuda", generator=g)
 R = torch.zeros_like(x0)
 t = torch.randint(0, 1000, (B,), device="cuda", generator=g)
+if name == "ncsnpp32":
+    x0 = x0 * 0.5 + 0.5
 
 
 def step():
