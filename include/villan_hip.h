@@ -130,6 +130,10 @@ int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int W, int OH, 
 int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t x_bstride, int64_t ws_ld, void* stream);
 /* out[c] (+)= sum_b ws[b*ld + c]  -- fixed order, deterministic. */
 int vd_colsum(const float* ws, float* out, int B, int C, int64_t ld, int accumulate, void* stream);
+/* n_jobs column sums in one launch: job i = table[4i..4i+3] = {address of ws (+ first column), address of out (+ first
+ * column), number of columns (<= 64), ld}; out[c] += sum_b ws[b*ld + c], same order as vd_colsum (bit-identical).
+ * `table` is a DEVICE array (the job list of a backward pass is the same every step: build once, reuse). */
+int vd_colsum_segmented(const int64_t* table, int n_jobs, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1 -- GroupNorm (+SiLU) forward/backward.  Replaces F.group_norm + F.silu of

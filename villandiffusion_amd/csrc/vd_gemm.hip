@@ -1671,6 +1671,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ w
     }
 }
 
+// Many column sums in ONE launch (the ~180 bias / GroupNorm-parameter gradient reductions of a backward pass): workgroup i
+// reads its job from a device table {ws address, out address, columns (<= 64), ld} and does exactly what colsum_kernel does
+// for one 64-column chunk (same summation order: results are bit-identical to the separate launches); always accumulates.
+__global__ __launch_bounds__(256) void colsum_seg_kernel(const int64_t* __restrict__ table, int B) {
+    __shared__ float part[4][64];
+    const int64_t* __restrict__ t = table + 4 * (int64_t)blockIdx.x;
+    const float* __restrict__ ws = reinterpret_cast<const float*>(t[0]);
+    float* __restrict__ out = reinterpret_cast<float*>(t[1]);
+    const int C = (int)t[2];
+    const int64_t ld = t[3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane;
+    float s = 0.f;
+    if (c < C) {
+        int b = w;
+        for (; b + 28 < B; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(b + 4 * u) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < B; b += 4) s += ws[(int64_t)b * ld + c];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < C) out[c] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 template <int WM, int WN>
 int launch_gemm_t(const vd_gemm_desc& d, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -1942,6 +1971,13 @@ extern "C" int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t
     hipLaunchKernelGGL(rowsum_kernel, dim3(vd_cdiv((int64_t)B * M, 4)), dim3(256), 0, (hipStream_t)stream, X, ws, B, M, P,
                        x_bstride, ws_ld);
     VD_LAUNCH_CHECK("vd_rowsum");
+    return 0;
+}
+
+extern "C" int vd_colsum_segmented(const int64_t* table, int n_jobs, int B, void* stream) {
+    VD_REQUIRE(table && n_jobs > 0 && B > 0, "vd_colsum_segmented: bad args");
+    hipLaunchKernelGGL(colsum_seg_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, table, B);
+    VD_LAUNCH_CHECK("vd_colsum_segmented");
     return 0;
 }
 

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "vd_col2im_s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_rowsum": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_colsum": (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "vd_colsum_segmented": (_i32, [_vp, _i32, _i32, _vp]),
     "vd_groupnorm_ws_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "vd_groupnorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i64, _i64, _vp, _vp]),
     "vd_groupnorm_bwd": (_i32, [_vp] * 10 + [_i32] * 5 + [_i64] * 4 + [_vp, _vp]),

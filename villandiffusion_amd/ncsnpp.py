@@ -97,7 +97,7 @@ class _ResnetPP:
             wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
             ops.conv_wgrad(dsum, xs, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN, net.wgrad_ws,
                            accumulate=True)
-            ops.colsum(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout, accumulate=True)
+            net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout)
             dxs = torch.empty_like(xs)
             HW = xs.shape[2] * xs.shape[3]
             ops.gemm(wsc, dsum, dxs, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin, ldb=HW,
@@ -345,7 +345,8 @@ class NCSNppModel(UNet2DModel):
         dev = self._dev
         B = st.B
         self._prepare_backward(B)
-        st.d_temb_all = torch.zeros((B, self.temb_total), device=dev, dtype=torch.float32)
+        self._cs_begin(B)
+        st.d_temb_all = self._d_temb_buffer(B)
         hook = self.bucket_ready_hook
         h_in, a, mo, ro, t, has_sk = st.out_saved
         dy = torch.empty_like(dout)
@@ -360,8 +361,10 @@ class NCSNppModel(UNet2DModel):
         while tp:
             if hook is not None:
                 if len(tp) == st.marks["mid_end"]:
+                    self._cs_flush()
                     hook(0)
                 elif len(tp) == st.marks["down_end"]:
+                    self._cs_flush()
                     hook(1)
             rec = tp.pop()
             kind = rec[0]
@@ -396,7 +399,7 @@ class NCSNppModel(UNet2DModel):
                 ops.conv_wgrad(g, skimg, self.G[blk.skip_conv + ".weight"].view(blk.ch, -1), B_PLAIN, self.wgrad_ws, accumulate=True)
                 ws = self.scratch_bc(B, blk.ch)
                 ops.rowsum(g, ws)
-                ops.colsum(ws, self.G[blk.skip_conv + ".bias"], B, blk.ch, accumulate=True)
+                self.colsum_later(ws, self.G[blk.skip_conv + ".bias"], B, blk.ch)
             elif kind == "conv_in":
                 ops.add_strided(g, skip_grads.pop(), accumulate=True)
                 self._conv_in.bwd(g, rec[1], None)
@@ -404,11 +407,12 @@ class NCSNppModel(UNet2DModel):
                 raise RuntimeError(kind)
         assert not skip_grads
         if hook is not None:
+            self._cs_flush()
             hook(2)
         four, e1, e1a, emb, emb_act = st.temb_saved
         d = st.d_temb_all
         ops.linear_wgrad(d, emb_act, self.gWt_all, accumulate=True)
-        ops.colsum(d, self.gbt_all, B, self.temb_total, accumulate=True)
+        self.colsum_later(d, self.gbt_all, B, self.temb_total)
         d_act = torch.empty_like(emb_act)
         ops.linear_dgrad(d, self.Wt_all, d_act)
         d_emb = ops.silu_bwd(d_act, emb, torch.empty_like(emb))
@@ -419,5 +423,6 @@ class NCSNppModel(UNet2DModel):
         d_e1 = ops.silu_bwd(d_e1a, e1, torch.empty_like(e1))
         ops.linear_wgrad(d_e1, four, self.G["time_embedding.linear_1.weight"], accumulate=True)
         ops.colsum(d_e1, self.G["time_embedding.linear_1.bias"], B, self.temb_dim, accumulate=True)
+        self._cs_flush()
         if hook is not None:
             hook(3)

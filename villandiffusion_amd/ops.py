@@ -264,6 +264,12 @@ def colsum(ws, out, Bn, Cc, ld=None, accumulate=False):
     return out
 
 
+def colsum_segmented(table, n_jobs, Bn):
+    """table: device int64 [n_jobs, 4] = (ws address, out address, columns <= 64, ld); out += column sums (one launch)."""
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.numel() >= 4 * n_jobs
+    L.check(_lib().vd_colsum_segmented(_p(table), n_jobs, Bn, _s()), "vd_colsum_segmented")
+
+
 # --------------------------------------------------------------------------------------------- GroupNorm
 def _gn_ws(Bn, Cc, HW, G, device):
     """Scratch for the multi-workgroup GroupNorm of large groups (None when the single-workgroup kernels apply)."""

@@ -69,8 +69,7 @@ class _Conv:
             ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
             if bias_ws is None:
                 ops.rowsum(dout, ws)
-            ops.colsum(ws, net.G[self.prefix + ".bias"], B, self.cout, ld=(ws.stride(0) if ws.dim() == 2 else self.cout),
-                       accumulate=True)
+            net.colsum_later(ws, net.G[self.prefix + ".bias"], B, self.cout, ld=(ws.stride(0) if ws.dim() == 2 else self.cout))
         if dx is None:
             return None
         if self.mode == B_CONV3_S2:
@@ -110,8 +109,8 @@ class _Norm:
         wg, wb = net.scratch_bc(B, self.ch, 1), net.scratch_bc(B, self.ch, 2)
         ops.groupnorm_bwd(dy, x, mean, rstd, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], dx, wg, wb,
                           self.groups, self.silu, extra=extra)
-        ops.colsum(wg, net.G[self.prefix + ".weight"], B, self.ch, accumulate=True)
-        ops.colsum(wb, net.G[self.prefix + ".bias"], B, self.ch, accumulate=True)
+        net.colsum_later(wg, net.G[self.prefix + ".weight"], B, self.ch)
+        net.colsum_later(wb, net.G[self.prefix + ".bias"], B, self.ch)
         return dx
 
 
@@ -171,7 +170,7 @@ class _Resnet:
             wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
             ops.conv_wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
                            net.wgrad_ws, accumulate=True)
-            ops.colsum(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout, accumulate=True)
+            net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout)
             dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
             HW = H * W
             ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
@@ -248,7 +247,7 @@ class _Attn:
         ops.conv_wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, net.wgrad_ws, accumulate=True)
         bias_ws = net.scratch_bc(B, Cc)
         ops.rowsum(dout, bias_ws)
-        ops.colsum(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc, accumulate=True)
+        net.colsum_later(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc)
         do = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(wo, dout, do, M=Cc, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
                  b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N)
@@ -295,7 +294,7 @@ class _Attn:
         ops.conv_wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, net.wgrad_ws, accumulate=True)
         ws3 = net.scratch_bc(B, 3 * Cc)
         ops.rowsum(dqkv, ws3)
-        ops.colsum(ws3, net.Gq[self.qkv_b], B, 3 * Cc, accumulate=True)
+        net.colsum_later(ws3, net.Gq[self.qkv_b], B, 3 * Cc)
         dg = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(net.Pq[self.qkv_w], dqkv, dg, M=Cc, N=B * N, K=3 * Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
                  b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N)
@@ -475,7 +474,11 @@ class UNet2DModel(nn.Module):
         self._wt_total = wt_total
         self._wt_buf: Optional[torch.Tensor] = None
         self.wgrad_ws: Optional[torch.Tensor] = None
-        self._scratch: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._cs_pool: Optional[torch.Tensor] = None
+        self._cs_tables: Dict[tuple, torch.Tensor] = {}
+        self._cs_cols_hint = 4 * sum(int(math.prod(sh)) for _, sh, _ in layout if len(sh) == 1) + 4096
+        self._cs_off, self._cs_jobs, self._cs_B = 0, [], 0
+        self._d_temb: Dict[int, torch.Tensor] = {}
         half = self.time_dim0 // 2
         # [UPSTREAM] get_timestep_embedding: exponent = -ln(1e4) * arange(half) / (half - freq_shift), fp32 torch ops
         exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32)
@@ -548,12 +551,54 @@ class UNet2DModel(nn.Module):
         return torch.float32
 
     # ------------------------------------------------------------------------------------------ scratch
+    # ---- per-batch partial sums of the bias / GroupNorm-parameter gradients and their deferred reduction ----
+    # Every [B, C] partial gets its own region of one pool so that the ~180 column sums of a backward pass can be reduced by
+    # ONE vd_colsum_segmented launch per gradient bucket instead of a 5 us launch each.
+    def _cs_begin(self, B):
+        need = B * self._cs_cols_hint
+        if self._cs_pool is None or self._cs_pool.numel() < need:
+            self._cs_pool = torch.empty(need, device=self._dev, dtype=torch.float32)
+            self._cs_tables = {}
+        self._cs_off, self._cs_jobs, self._cs_B = 0, [], B
+
     def scratch_bc(self, B, Cc, slot=0):
-        key = (slot, B * Cc)
-        t = self._scratch.get(key)
+        n = (B * Cc + 3) // 4 * 4
+        if self._cs_off + n > self._cs_pool.numel():             # first pass with an under-estimated hint: flush and grow
+            self._cs_flush()
+            self._cs_cols_hint *= 2
+            self._cs_pool = torch.empty(B * self._cs_cols_hint, device=self._dev, dtype=torch.float32)
+            self._cs_tables, self._cs_off = {}, 0
+        t = self._cs_pool[self._cs_off:self._cs_off + B * Cc]
+        self._cs_off += n
+        return t
+
+    def colsum_later(self, ws, out, B, Cc, ld=None):
+        """out[c] += sum_b ws[b*ld + c], executed at the next _cs_flush() (ws must stay untouched until then)."""
+        ld = Cc if ld is None else ld
+        wp, op = ws.data_ptr(), out.data_ptr()
+        for c0 in range(0, Cc, 64):
+            self._cs_jobs.append((wp + 4 * c0, op + 4 * c0, min(64, Cc - c0), ld))
+
+    def _cs_flush(self):
+        jobs = self._cs_jobs
+        if not jobs:
+            return
+        key = tuple(jobs)
+        tab = self._cs_tables.get(key)
+        if tab is None:                                          # same job list every step: uploaded once
+            tab = torch.tensor(jobs, dtype=torch.int64).to(self._dev)
+            self._cs_tables[key] = tab
+        ops.colsum_segmented(tab, len(jobs), self._cs_B)
+        self._cs_jobs = []
+
+    def _d_temb_buffer(self, B):
+        """[B, temb_total] gradient rows of the fused time_emb_proj GEMM (persistent: its address is part of the colsum job table)."""
+        t = self._d_temb.get(B)
         if t is None:
-            t = torch.empty(B * Cc, device=self._dev, dtype=torch.float32)
-            self._scratch[key] = t
+            t = torch.zeros((B, self.temb_total), device=self._dev, dtype=torch.float32)
+            self._d_temb[B] = t
+        else:
+            ops.scale_(t, 0.0)
         return t
 
     def wt_view(self, prefix, M, Cc, T):
@@ -738,7 +783,8 @@ class UNet2DModel(nn.Module):
         dev = self._dev
         B = st.B
         self._prepare_backward(B)
-        st.d_temb_all = torch.zeros((B, self.temb_total), device=dev, dtype=torch.float32)
+        self._cs_begin(B)
+        st.d_temb_all = self._d_temb_buffer(B)
         up_slots = st.up_slots
         n_skip = len(up_slots)
         dcats: List[Optional[torch.Tensor]] = [None] * n_skip     # gradient wrt each concat buffer
@@ -755,8 +801,10 @@ class UNet2DModel(nn.Module):
         while sv:
             if hook is not None:                                  # gradient buckets complete in the order up|out, mid, down
                 if len(sv) == st.marks["mid_end"]:
+                    self._cs_flush()
                     hook(0)
                 elif len(sv) == st.marks["down_end"]:
+                    self._cs_flush()
                     hook(1)
             rec = sv.pop()
             kind = rec[0]
@@ -790,12 +838,13 @@ class UNet2DModel(nn.Module):
             else:
                 raise RuntimeError(kind)
         if hook is not None:
+            self._cs_flush()
             hook(2)
         # ---- time embedding backward ----
         emb_sin, e1, e1a, emb, emb_act = st.temb_saved
         d = st.d_temb_all
         ops.linear_wgrad(d, emb_act, self.gWt_all, accumulate=True)
-        ops.colsum(d, self.gbt_all, B, self.temb_total, accumulate=True)
+        self.colsum_later(d, self.gbt_all, B, self.temb_total)
         d_act = torch.empty_like(emb_act)
         ops.linear_dgrad(d, self.Wt_all, d_act)
         d_emb = ops.silu_bwd(d_act, emb, torch.empty_like(emb))
@@ -806,6 +855,7 @@ class UNet2DModel(nn.Module):
         d_e1 = ops.silu_bwd(d_e1a, e1, torch.empty_like(e1))
         ops.linear_wgrad(d_e1, emb_sin, self.G["time_embedding.linear_1.weight"], accumulate=True)
         ops.colsum(d_e1, self.G["time_embedding.linear_1.bias"], B, self.temb_dim, accumulate=True)
+        self._cs_flush()
         if hook is not None:
             hook(3)
 
