@@ -225,3 +225,19 @@ def test_latent_dataset_disk_format_and_poison_by_index(tmp_path):
     assert torch.allclose(ds.get_target_by_key("CAT")[:, ::2, ::2], tgt[:, ::2, ::2])
     with pytest.raises(ValueError):
         LatentDataset(str(tmp_path / "x")).update_target_by_key("k", tgt)
+
+
+def test_lossfn_captures_the_schedule_at_construction():
+    """reference loss.py:829-834 reads noise_sched.sigmas / alphas in LossFn.__init__; a VE pipeline's set_sigmas(n) later swaps
+    noise_sched.sigmas for the n-step inference table (VillanDiffusion.py samples before training) -- the 2000-entry training
+    tables must not follow it (regression: indexing a 6-entry table with t < 2000 faulted on the device)."""
+    from villandiffusion_amd import schedulers as S
+    from villandiffusion_amd.loss import LossFn
+    s = S.ScoreSdeVeScheduler(num_train_timesteps=2000, sigma_min=0.01, sigma_max=380.0)
+    lf = LossFn(s, "SDE-VE", psi=0)
+    step0, coef0 = lf.get_R_step_coef()
+    s.set_timesteps(6)
+    s.set_sigmas(6)
+    assert len(s.sigmas) == 6
+    step1, coef1 = lf.get_R_step_coef()
+    assert len(step1) == 2000 and torch.equal(step0, step1) and torch.equal(coef0, coef1)

@@ -129,3 +129,34 @@ def test_ve_training_step_sampling_and_disk_roundtrip_with_ncsnpp(tmp_path):
     pipe.save_pretrained(d)
     pipe2 = DiffusionPipeline.from_pretrained(d)
     assert type(pipe2.unet).__name__ == "NCSNppModel" and torch.equal(pipe2.unet.flat_param, net.flat_param)
+
+
+@pytest.mark.gpu
+def test_cli_sde_ve_ncsnpp_train_and_sample(tmp_path):
+    """The reference's score-based flow (run_score-basde_model_script.py): --sde_type SDE-VE --psi 0 with the NCSN++
+    from-scratch id; fine-tune one tiny epoch, sample with the predictor-corrector sampler, re-load the checkpoint."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = str(tmp_path / "exp")
+    env = dict(os.environ, PYTHONPATH=root)
+    code = ("import sys; sys.argv=['VillanDiffusion.py']+%r; import villandiffusion_amd.dataset as D;"
+            "D.synthetic_images=(lambda f: (lambda n=60000, **k: f(n=128, **k)))(D.synthetic_images);"
+            "import villandiffusion_amd.model as M; M.NCSNPP_32_ARCH.update(block_out_channels=[32, 64, 64], layers_per_block=1,"
+            " down_block_types=['SkipDownBlock2D', 'AttnSkipDownBlock2D', 'SkipDownBlock2D'],"
+            " up_block_types=['SkipUpBlock2D', 'AttnSkipUpBlock2D', 'SkipUpBlock2D']);"
+            "import VillanDiffusion as V; V.TrainingConfig.eval_sample_n=4; V.main()")
+    argv = ["--mode", "train", "--dataset", "SYNTHETIC-CIFAR10", "--batch", "32", "--epoch", "1", "--poison_rate", "0.3", "--trigger", "BOX_14",
+            "--target", "HAT", "--ckpt", "NCSNPP-32-DEFAULT", "--sde_type", "SDE-VE", "--psi", "0", "--fclip", "o", "-o", "--result", res,
+            "--sched", "SCORE-SDE-VE-SCHED", "--infer_steps", "6", "--save_image_epochs", "1", "--save_model_epochs", "1"]
+    out = subprocess.run([sys.executable, "-c", code % (argv,)], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    run = os.path.join(res, os.listdir(res)[0])
+    cfg = json.load(open(os.path.join(run, "unet", "config.json")))
+    assert cfg["time_embedding_type"] == "fourier" and cfg["down_block_types"][0] == "SkipDownBlock2D"
+    assert json.load(open(os.path.join(run, "model_index.json")))["_class_name"] == "ScoreSdeVePipeline"
+    assert os.path.exists(os.path.join(run, "samples", "0001.png")) and os.path.exists(os.path.join(run, "backdoor_samples", "0001.png"))
+    # sampling mode takes sde_type from the run's args.json (the reference's mode whitelist rejects --sde_type here)
+    argv2 = ["--mode", "sampling", "--ckpt", run, "--sched", "SCORE-SDE-VE-SCHED", "--infer_steps", "4"]
+    out = subprocess.run([sys.executable, "-c", code % (argv2,)], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert os.path.exists(os.path.join(run, "samples", "final.png"))

@@ -128,9 +128,17 @@ def last_error() -> str:
     return load().vd_last_error().decode("utf-8", "replace")
 
 
+_SYNC_DEBUG = bool(os.environ.get("VD_SYNC_DEBUG"))     # debugging aid: synchronise after every launch and name it first
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise VillanHipError(f"{what} failed (rc={rc}): {last_error()}")
+    if _SYNC_DEBUG:
+        import sys
+        import torch
+        print(f"[vd] {what}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
 
 
 _device_checked = False

@@ -116,6 +116,13 @@ class LossFn:
             raise NotImplementedError("only loss_type='l2' is implemented natively (the driver hard-codes it, "
                                       "VillanDiffusion.py:1128)")
         self._sched, self._sde, self._psi, self._solver = noise_sched, sde_type, psi, solver_type
+        # the schedule is captured HERE like the reference does (loss.py:829-834): a VE pipeline's set_sigmas(n) later
+        # replaces noise_sched.sigmas by the n-step inference table, which must not shrink the training tables
+        if sde_type == SDE_VE:
+            self._sigmas_asc = noise_sched.sigmas.flip([0]).float().cpu().clone()
+        else:
+            self._alphas = noise_sched.alphas.float().cpu().clone()
+            self._alphas_cumprod = noise_sched.alphas_cumprod.float().cpu().clone()
         self._vp_scale, self._ve_scale, self._w, self._b = vp_scale, ve_scale, rhos_hat_w, rhos_hat_b
         self._dev_tabs = None
         self._partial = None
@@ -126,11 +133,11 @@ class LossFn:
     # host tables (fp32, CPU) -- loss.py:860-907
     def get_R_step_coef(self) -> Tuple[torch.Tensor, torch.Tensor]:
         if self._sde in (SDE_VP, SDE_LDM):
-            a, ac = self._sched.alphas.float().cpu(), self._sched.alphas_cumprod.float().cpu()
+            a, ac = self._alphas, self._alphas_cumprod
             hs = get_hs_vp(a, ac) if self._psi != 1 else None
             return get_R_coef_gen_vp(ac, a, hs=hs, psi=self._psi, solver_type=self._solver, vp_scale=self._vp_scale,
                                      ve_scale=self._ve_scale)
-        sig = self._sched.sigmas.flip([0]).float().cpu()
+        sig = self._sigmas_asc
         return get_R_coef_gen_ve_reduce(sig, hs=True, rhos_hat_w=self._w, psi=self._psi, solver_type=self._solver,
                                         ve_scale=self._ve_scale)
 
@@ -138,12 +145,11 @@ class LossFn:
         if self._dev_tabs is None or self._dev_tabs[0].device != dev:
             step, coef = self.get_R_step_coef()
             if self._sde in (SDE_VP, SDE_LDM):
-                ac = self._sched.alphas_cumprod.float().cpu()
+                ac = self._alphas_cumprod
                 ta, ts = ac ** 0.5, (1 - ac) ** 0.5
                 self._dev_tabs = (step.to(dev), coef.to(dev), ta.to(dev), ts.to(dev))
             else:
-                sig = self._sched.sigmas.flip([0]).float().cpu()
-                self._dev_tabs = (step.to(dev), coef.to(dev), None, sig.to(dev))
+                self._dev_tabs = (step.to(dev), coef.to(dev), None, self._sigmas_asc.to(dev))
             self._partial = torch.empty(1024, device=dev, dtype=torch.float32)
         return self._dev_tabs
 
