@@ -186,7 +186,7 @@ def sampling(cfg: TrainingConfig, file_name, pipeline, dsl):
     kw = {} if cfg.ddim_eta is None else {"eta": cfg.ddim_eta}
     if cfg.task != TASK_GENERATE:
         return _special_sampling(cfg, tag, pipeline, dsl, noise, kw)
-    for name, init in (("samples", noise), ("backdoor_samples", noise + pipeline.encode(dsl.trigger.unsqueeze(0)))):
+    for name, init in (("samples", noise), ("backdoor_samples", noise + pipeline.encode(dsl.trigger.unsqueeze(0)).to(noise.device))):
         res = pipeline(batch_size=n, generator=torch.Generator().manual_seed(cfg.seed), init=init, output_type=None,
                        num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=True, **kw)
         make_grid(res.images, os.path.join(cfg.output_dir, name, f"{tag}.png"))
@@ -246,7 +246,7 @@ def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
     bd_path = os.path.join(cfg.output_dir, f"backdoor{step}{sub}_{n}")
     g = torch.Generator().manual_seed(cfg.seed)
     noise = torch.randn((n, pipeline.unet.in_channels, pipeline.unet.sample_size, pipeline.unet.sample_size), generator=g)
-    bd_noise = noise + pipeline.encode(dsl.trigger.unsqueeze(0))
+    bd_noise = noise + pipeline.encode(dsl.trigger.unsqueeze(0)).to(noise.device)
     for path, init in ((clean_path, noise), (bd_path, bd_noise)):
         batch_sampling_save(n, pipeline, path, init=init, max_batch_n=cfg.eval_max_batch, rng=torch.Generator().manual_seed(cfg.seed),
                             num_inference_steps=cfg.infer_steps, eta=cfg.ddim_eta, rank=rank, world=world)

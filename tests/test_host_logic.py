@@ -241,3 +241,28 @@ def test_lossfn_captures_the_schedule_at_construction():
     assert len(s.sigmas) == 6
     step1, coef1 = lf.get_R_step_coef()
     assert len(step1) == 2000 and torch.equal(step0, step1) and torch.equal(coef0, coef1)
+
+
+def test_dataset_loader_on_latent_dataset(tmp_path):
+    """--dataset CELEBA-HQ-LATENT (BASELINE config #5): DatasetLoader wraps LatentDataset, poisons by index, batches are index
+    gathers of the resident latents; trigger / target stay image-space 256x256 tensors for the pipeline to encode."""
+    import os
+    from dataset import DatasetLoader, LatentDataset
+    root = str(tmp_path)
+    lds = LatentDataset(os.path.join(root, "celeba_hq_256_latents"))
+    g = torch.Generator().manual_seed(0)
+    raw = torch.randn(10, 3, 8, 8, generator=g)
+    poi = torch.randn(10, 3, 8, 8, generator=g)
+    tgt = torch.randn(3, 8, 8, generator=g)
+    lds.update_target_latent_by_key("CORNER", tgt)
+    lds.update_data_latents_by_idxs("raw", list(range(10)), raw)
+    lds.update_data_latents_by_idxs("BOX_14", list(range(10)), poi)
+    dsl = DatasetLoader("CELEBA-HQ-LATENT", root=root, batch_size=4, device="cpu").set_poison("BOX_14", "CORNER", poison_rate=0.5) \
+        .prepare_dataset(mode="NONE")
+    assert len(dsl) == 10 and dsl.image_size == 256 and tuple(dsl.trigger.shape) == (3, 256, 256)
+    b = dsl.make_batch(torch.tensor([0, 4, 5, 9]))
+    assert b["is_clean"].tolist() == [False, False, True, True]
+    assert torch.equal(b["image"], raw[[0, 4, 5, 9]])
+    assert torch.equal(b["pixel_values"][:2], poi[[0, 4]]) and float(b["pixel_values"][2:].abs().max()) == 0.0
+    assert torch.equal(b["target"][0], tgt) and torch.equal(b["target"][1], tgt) and torch.equal(b["target"][2:], raw[[5, 9]])
+    assert sum(x["image"].shape[0] for x in dsl.get_dataloader(full=False)) == 10

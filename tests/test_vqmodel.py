@@ -136,3 +136,42 @@ def test_ldm_pipeline_matches_oracle_and_roundtrips_on_disk(tmp_path):
         Rr = vref.encode(torch.zeros_like(x)).latents * 0.5
         l_ref = LossFnRef(R.DDPMSchedulerRef(**beta), "SDE-LDM").p_loss(uref, x0, Rr, t, noise=eps)
     assert abs(float(l) - float(l_ref)) <= 1e-4 * abs(float(l_ref)), (float(l), float(l_ref))
+
+
+@pytest.mark.gpu
+def test_cli_sde_ldm_on_latent_dataset(tmp_path):
+    """BASELINE config #5 flow at toy size through the drop-in CLI: a local latent-diffusion checkpoint (unet/ vqvae/
+    scheduler/), the precomputed-latent dataset (--dataset CELEBA-HQ-LATENT), SDE-LDM loss with vae=None, UniPC sampling in
+    latent space + VQ-VAE decode, checkpoint written back with its vqvae/ folder."""
+    import json, os, subprocess, sys
+    from dataset import LatentDataset
+    from villandiffusion_amd import schedulers as S
+    from villandiffusion_amd.pipelines import LDMPipeline
+    from villandiffusion_amd.unet import UNet2DModel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck, data, res = str(tmp_path / "ldm_ckpt"), str(tmp_path / "datasets"), str(tmp_path / "exp")
+    vq = VQModel(block_out_channels=(16, 32, 32), down_block_types=("DownEncoderBlock2D",) * 3, up_block_types=("UpDecoderBlock2D",) * 3,
+                 layers_per_block=1, norm_num_groups=8, num_vq_embeddings=64, latent_channels=3, sample_size=256)
+    unet = UNet2DModel(sample_size=64, block_out_channels=(32, 64), down_block_types=("DownBlock2D", "DownBlock2D"),
+                       up_block_types=("UpBlock2D", "UpBlock2D"), layers_per_block=1, norm_num_groups=8, downsample_padding=1)
+    LDMPipeline(vqvae=vq, unet=unet, scheduler=S.DDIMScheduler(beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear",
+                                                               clip_sample=False)).save_pretrained(ck)
+    lds = LatentDataset(os.path.join(data, "celeba_hq_256_latents"))
+    g = torch.Generator().manual_seed(0)
+    lds.update_target_latent_by_key("CORNER", torch.randn(3, 64, 64, generator=g))
+    lds.update_data_latents_by_idxs("raw", list(range(16)), torch.randn(16, 3, 64, 64, generator=g))
+    lds.update_data_latents_by_idxs("BOX_14", list(range(16)), torch.randn(16, 3, 64, 64, generator=g))
+    env = dict(os.environ, PYTHONPATH=root)
+    code = "import sys; sys.argv=['VillanDiffusion.py']+%r; import VillanDiffusion as V; V.TrainingConfig.eval_sample_n=2; V.main()"
+    argv = ["--mode", "train", "--dataset", "CELEBA-HQ-LATENT", "--dataset_load_mode", "NONE", "--sde_type", "SDE-LDM", "--ckpt", ck,
+            "--batch", "8", "--epoch", "1", "--poison_rate", "0.5", "--trigger", "BOX_14", "--target", "CORNER", "--fclip", "o", "-o",
+            "--result", res, "--sched", "UNIPC-SCHED", "--infer_steps", "3", "--save_image_epochs", "1", "--save_model_epochs", "1"]
+    # cwd = tmp dir: the driver's dataset_path is the relative 'datasets' (reference TrainingConfig.dataset_path)
+    out = subprocess.run([sys.executable, "-c", code % (argv,)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    # the result-dir name embeds --ckpt (reference :186-190); with a path ckpt that nests directories: locate the run by its index
+    run = [d for d, _, files in os.walk(res) if "model_index.json" in files][0]
+    idx = json.load(open(os.path.join(run, "model_index.json")))
+    assert idx["_class_name"] == "LDMPipeline" and "vqvae" in idx
+    for f in ("vqvae/config.json", "vqvae/diffusion_pytorch_model.safetensors", "unet/config.json", "samples/0001.png", "backdoor_samples/0001.png"):
+        assert os.path.exists(os.path.join(run, f)), f

@@ -186,6 +186,7 @@ class DatasetLoader:
                  shuffle: bool = True, seed: int = 0, device=None, images: Optional[np.ndarray] = None,
                  labels: Optional[np.ndarray] = None):
         self._root, self._name = root, name
+        self._latent = None
         self._label = None if label is None else (list(label) if isinstance(label, (list, tuple)) else [label])
         self._vmin, self._vmax = float(vmin), float(vmax)
         self._batch_size, self._shuffle, self._seed = batch_size, shuffle, seed
@@ -199,11 +200,17 @@ class DatasetLoader:
             self._images, self._labels = synthetic_images(), None
         elif name == self.CIFAR10:
             self._images, self._labels = _load_cifar10(root or "datasets")
+        elif name == self.CELEBA_HQ_LATENT:
+            # precomputed VQ-VAE latents (dataset.py:125-126, 440-442): <root>/celeba_hq_256_latents in LatentDataset format;
+            # trigger / target stay IMAGE-space tensors (256x256) -- the pipeline encodes them when it needs latents
+            self._latent = LatentDataset(os.path.join(root or "datasets", "celeba_hq_256_latents"))
+            self._images, self._labels = None, None
+            channel, image_size = channel or 3, image_size or 256
         else:
             raise NotImplementedError(f"No dataset named as {name} (local loaders exist for CIFAR10 and SYNTHETIC-CIFAR10)")
         self._channel = channel if channel is not None else self._images.shape[-1]
         self._image_size = image_size if image_size is not None else self._images.shape[1]
-        if self._images.shape[1] != self._image_size or self._images.shape[-1] != self._channel:
+        if self._images is not None and (self._images.shape[1] != self._image_size or self._images.shape[-1] != self._channel):
             raise NotImplementedError("on-the-fly resize / channel conversion is not implemented; store images at the training size")
         self._backdoor = Backdoor(root=root)
         self._trigger = self._target = None
@@ -245,6 +252,8 @@ class DatasetLoader:
     def prepare_dataset(self, mode: str = "FIXED", R_trigger_only: bool = False, ext_R_trigger_only: bool = False,
                         R_gaussian_aug: float = 0.0) -> "DatasetLoader":
         self._R_trigger_only = bool(R_trigger_only)
+        if self._latent is not None:
+            return self._prepare_latent()
         base = np.arange(len(self._images), dtype=np.int64)
         if self._label is not None:
             if self._labels is None:
@@ -281,6 +290,42 @@ class DatasetLoader:
             raise NotImplementedError(f"Argument mode: {mode} isn't defined")
         self._index, self._flags = base[idx], flags
         return self
+
+    def _prepare_latent(self) -> "DatasetLoader":
+        """dataset.py:440-442: the latent dataset poisons BY INDEX (first int(len * poison_rate) items), whatever the mode."""
+        lds = self._latent.set_poison(target_key=self._target_type, poison_key=self._trigger_type, raw=LatentDataset.RAW_LATENTS_FILE_NAME,
+                                      poison_rate=self._poison_rate, use_latent=True)
+        lds.set_use_names(target=self.TARGET, poison=self.PIXEL_VALUES, raw=self.IMAGE)
+        n = len(lds)
+        if n == 0:
+            raise FileNotFoundError(f"no latents under {lds._root}/raw: create them with make_latent_dataset.py")
+        k = int(n * float(self._poison_rate))
+        self._lat_raw = torch.stack([lds.get_data_latent_by_idx(LatentDataset.RAW_LATENTS_FILE_NAME, i) for i in range(n)]).float()
+        self._lat_poison = (torch.stack([lds.get_data_latent_by_idx(self._trigger_type, i) for i in range(k)]).float()
+                            if k > 0 else self._lat_raw[:0])
+        self._lat_target = lds.get_target_latent().float()
+        self._index = np.arange(n, dtype=np.int64)
+        self._flags = (np.arange(n) < k).astype(np.uint8)
+        self._lat_dev = None
+        return self
+
+    def _make_latent_batch(self, sample_ids: torch.Tensor, full: bool) -> Dict[str, torch.Tensor]:
+        if self._lat_dev is None:                       # latents resident on the device: a batch is an index gather
+            self._lat_dev = (self._lat_raw.to(self._dev), self._lat_poison.to(self._dev), self._lat_target.to(self._dev),
+                             torch.from_numpy(self._flags.astype(bool)).to(self._dev))
+        raw, poi, tgt, fl = self._lat_dev
+        idx = sample_ids.to(self._dev).long()
+        is_p = fl[idx]
+        r = raw[idx]
+        m = is_p[:, None, None, None]
+        pv = torch.zeros_like(r)
+        if poi.shape[0] > 0:
+            pv = torch.where(m, poi[idx.clamp(max=poi.shape[0] - 1)], pv)
+        batch = {self.PIXEL_VALUES: pv.contiguous(), self.TARGET: torch.where(m, tgt[None].expand_as(r), r).contiguous(), self.IMAGE: r}
+        if full:
+            batch[self.IS_CLEAN] = ~is_p
+            batch[self.LABEL] = torch.full((len(idx),), -1.0, device=self._dev)
+        return batch
 
     # ---- properties ----
     @property
@@ -347,6 +392,8 @@ class DatasetLoader:
 
     def make_batch(self, sample_ids: torch.Tensor, flip_bits: Optional[torch.Tensor] = None, full: bool = True) -> Dict[str, torch.Tensor]:
         """Batch dict for positions `sample_ids` of the prepared (partitioned) dataset."""
+        if self._latent is not None:
+            return self._make_latent_batch(sample_ids, full)
         self._ensure_device()
         pos = sample_ids.cpu().numpy()
         ds_idx = torch.from_numpy(self._index[pos]).to(self._dev)
