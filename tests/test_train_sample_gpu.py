@@ -244,3 +244,28 @@ def test_karras_ve_pipeline_matches_oracle(nets, churn):
     err = float((out.cpu() - x_ref).abs().max() / x_ref.abs().max())
     print(f"[parity] KarrasVe churn={churn}: final sample max-rel-err {err:.3e}")
     assert err <= 1e-3
+
+
+def test_celebahq256_config_train_step_with_image_trigger():
+    """BASELINE config #4 shape of work at reduced width: 256x256 images, STOP_SIGN_14 -> CAT (image-based trigger / target from
+    static/), GPU stamping vs the oracle's per-sample rule, one fine-tune step of a 6-level UNet and a UniPC sampling call."""
+    from villandiffusion_amd.pipelines import PNDMPipeline
+    dsl = DatasetLoader("SYNTHETIC-CELEBA-HQ", root=ROOT, batch_size=4, seed=0, images=synthetic_images(n=16, size=256))
+    dsl.set_poison("STOP_SIGN_14", "CAT", poison_rate=0.5).prepare_dataset(mode="FIXED")
+    assert tuple(dsl.trigger.shape) == (3, 256, 256) and tuple(dsl.target.shape) == (3, 256, 256)
+    ids = torch.arange(16)
+    batch = dsl.make_batch(ids, flip_bits=torch.zeros(16, dtype=torch.bool))
+    imgs_u8 = torch.from_numpy(dsl._images[dsl._index])                      # NHWC uint8
+    pv_ref, tg_ref = BR.poison_batch_ref(imgs_u8, torch.from_numpy((dsl._flags & 1).astype(bool)), dsl.trigger, dsl.target, -1.0, 1.0)
+    assert torch.equal(batch["pixel_values"].cpu(), pv_ref) and torch.equal(batch["target"].cpu(), tg_ref)
+    assert int((dsl._flags & 1).sum()) == 8
+    net = UNet2DModel(sample_size=256, block_out_channels=(32, 32, 64, 64, 128, 128),
+                      down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+                      up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4, norm_num_groups=8)
+    sched = S.UniPCMultistepScheduler()
+    tr = Trainer(net, LossFn(S.DDPMScheduler(), "SDE-VP"), lr=6e-5, total_steps=100, warmup_steps=10)
+    b4 = dsl.make_batch(torch.tensor([0, 1, 14, 15]), full=False)
+    l = tr.train_step(b4, torch.tensor([5, 300, 600, 999], device="cuda"))
+    assert float(l) == float(l) and bool(torch.isfinite(net.flat_param).all())
+    out = PNDMPipeline(net, sched)(batch_size=2, generator=torch.Generator().manual_seed(0), num_inference_steps=3, output_type=None)
+    assert out.images.shape == (2, 256, 256, 3)

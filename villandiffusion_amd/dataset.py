@@ -176,6 +176,7 @@ class DatasetLoader:
     MNIST, CIFAR10, CELEBA, LSUN_CHURCH, LSUN_BEDROOM, CELEBA_HQ = "MNIST", "CIFAR10", "CELEBA", "LSUN-CHURCH", "LSUN-BEDROOM", "CELEBA-HQ"
     CELEBA_HQ_LATENT_PR05, CELEBA_HQ_LATENT = "CELEBA-HQ-LATENT_PR05", "CELEBA-HQ-LATENT"
     SYNTHETIC_CIFAR10 = "SYNTHETIC-CIFAR10"
+    SYNTHETIC_CELEBA_HQ = "SYNTHETIC-CELEBA-HQ"            # 256x256 stand-in for BASELINE config #4 (no dataset download here)
     INPAINT_BOX, INPAINT_LINE = "INPAINT_BOX", "INPAINT_LINE"
     TRAIN, TEST = "train", "test"
     PIXEL_VALUES, PIXEL_VALUES_TRIGGER, TRIGGER, TARGET = "pixel_values", "pixel_values_trigger", "trigger", "target"
@@ -198,6 +199,8 @@ class DatasetLoader:
             self._images, self._labels = images, labels
         elif name == self.SYNTHETIC_CIFAR10:
             self._images, self._labels = synthetic_images(), None
+        elif name == self.SYNTHETIC_CELEBA_HQ:
+            self._images, self._labels = synthetic_images(n=int(os.environ.get("VILLAN_SYNTHETIC_N", 2048)), size=256), None
         elif name == self.CIFAR10:
             self._images, self._labels = _load_cifar10(root or "datasets")
         elif name == self.CELEBA_HQ_LATENT:
