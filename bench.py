@@ -72,25 +72,25 @@ def cpu_baseline(batch: int = 32):
         opt.step()
 
     step(2)                                     # warm-up (allocator, oneDNN primitives)
-    n_steps = 6
+    n_steps = 10
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step(batch)
     dt_train = time.perf_counter() - t0
     train_ips = n_steps * batch / dt_train
-    # sampling: 4 images x 5 DDPM steps, extrapolated x200 to 1000 steps (stated in "sample")
+    # sampling: 8 images x 20 DDPM steps, extrapolated x50 to 1000 steps (stated in "sample")
     sched.set_timesteps(1000)
-    x = torch.randn(4, 3, 32, 32)
+    x = torch.randn(8, 3, 32, 32)
     with torch.no_grad():
         t0 = time.perf_counter()
-        for t in sched.timesteps[:5]:
-            eps = net(x, torch.full((4,), int(t)))[0]
+        for t in sched.timesteps[:20]:
+            eps = net(x, torch.full((8,), int(t)))[0]
             x = sched.step(eps, t, x).prev_sample
         dt_s = time.perf_counter() - t0
-    sample_ips = 4 / (dt_s * 200.0)
+    sample_ips = 8 / (dt_s * 50.0)
     return {"value": round(train_ips, 3), "unit": "train images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n_steps} optimiser steps at batch {batch} (fwd+bwd+clip+Adam, fp32 torch CPU oracle); "
-                      f"sampling: 4 images x 5 DDPM steps extrapolated x200",
+                      f"sampling: 8 images x 20 DDPM steps extrapolated x50",
             "sample_ddpm1000_images_per_sec": round(sample_ips, 5), "host_cpus": os.cpu_count(),
             "affinity": len(os.sched_getaffinity(0))}
 
