@@ -1335,18 +1335,20 @@ __device__ __forceinline__ void wgrad_patch_store(const vd_wgrad_desc& d, const 
 // columns come from the neighbouring segments.  Same LDS images, MFMA schedule and epilogue as wgrad_patch_kernel; the
 // source offsets of the patch elements are recomputed per K-step (a dozen integer ops per element against 96 MFMAs).
 // 2 workgroups/CU: at 3 the per-step address state spills (26-41 VGPRs) and the kernel drops from 115 to 85 TF.
-template <int ROWS, int MODE>  // MODE 0: CONV3, 2: CONV3_UP (X is the half-resolution source)
+// KPIX = output pixels per K-step (32, or 64: twice the MFMAs between barriers).
+template <int ROWS, int MODE, int KPIX>  // MODE 0: CONV3, 2: CONV3_UP (X is the half-resolution source)
 __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_desc d, int ksteps_per_split, int oh_shift,
                                                                  int segs_shift) {
-    constexpr int TW = 32 / ROWS;
+    constexpr int TW = KPIX / ROWS;
+    constexpr int KGX = KPIX / 4;                  // k-groups (float4 of pixels) per K-step
     constexpr int PW = TW + 2;
     constexpr int PLn = ROWS * PW;
     constexpr int CT = 64;
     constexpr int LDA_ = 128 + 1;
     constexpr int LDB_ = (PLn & 1) ? PLn : PLn + 1;
-    constexpr int A_F4 = 128 * 32 / 4 / NT;
+    constexpr int A_F4 = 128 * KPIX / 4 / NT;
     constexpr int P_EL = (CT * PLn + NT - 1) / NT;
-    __shared__ f32x4 As[KG * LDA_];
+    __shared__ f32x4 As[KGX * LDA_];
     __shared__ float Bs[CT * LDB_];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -1364,14 +1366,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
     const int rest = bx / 3;
     const int tm = rest % tiles_m, tc = rest / tiles_m;
     const int m0 = tm * 128, c0 = tc * CT;
-    const int ks_total = (d.nb * d.NP) >> 5;
+    const int ks_total = (d.nb * d.NP) / KPIX;
     const int ks_begin = by * ksteps_per_split;
     const int ks_end = min(ks_total, ks_begin + ksteps_per_split);
     const int HWs = d.H * d.W;
     const int oh_mask = d.OH - 1, seg_mask = (1 << segs_shift) - 1;
     const int xbs32 = (int)d.x_bstride;
 
-    // per patch element ONE packed register: LDS slot (12 bits) | channel (6) | patch row (4) | patch column (6) | exists (1)
+    // per patch element ONE packed register: LDS slot (13 bits) | channel (6) | patch row (4) | patch column (7) | valid ch | exists
     unsigned pk[P_EL];
 #pragma unroll
     for (int i = 0; i < P_EL; ++i) {
@@ -1379,18 +1381,18 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
         const int c = e / PLn, rem = e - c * PLn;
         const int rr = rem / PW, px = rem - rr * PW;
         const bool in = e < CT * PLn;
-        pk[i] = in ? ((unsigned)(c * LDB_ + rem) | ((unsigned)c << 12) | ((unsigned)rr << 18) | ((unsigned)px << 22) |
-                      (((c0 + c) < d.C ? 1u : 0u) << 28) | (1u << 29))
+        pk[i] = in ? ((unsigned)(c * LDB_ + rem) | ((unsigned)c << 13) | ((unsigned)rr << 19) | ((unsigned)px << 23) |
+                      (((c0 + c) < d.C ? 1u : 0u) << 30) | (1u << 31))
                    : 0u;
     }
-    const int qa = tid & 7;                        // this thread's k-group (4 pixels) in the dY loader
+    const int qa = tid & (KGX - 1);                // this thread's k-group (4 pixels) in the dY loader
     const int rrA = (4 * qa) / TW, xA = (4 * qa) % TW;
 
     f32x4 ra[A_F4];
     float rp[P_EL];
     unsigned okmask = 0;
     auto load_stage = [&](int ks) {
-        const int xs = ROWS == 1 ? (ks & seg_mask) * 32 : 0;
+        const int xs = ROWS == 1 ? (ks & seg_mask) * KPIX : 0;
         const int gr0 = ROWS == 1 ? (ks >> segs_shift) : ks * ROWS;
         {
             const int gr = gr0 + rrA;
@@ -1398,7 +1400,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
             const float* __restrict__ dyp = d.dY + (int64_t)b * d.dy_bstride + y * d.OW + xs + xA;
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                const int m = (tid + i * NT) >> 3;
+                const int m = (tid + i * NT) / KGX;
                 const int mm = min(m0 + m, d.M - 1);
                 ra[i] = *reinterpret_cast<const f32x4*>(dyp + (int64_t)mm * d.NP);
             }
@@ -1409,9 +1411,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
 #pragma unroll
         for (int i = 0; i < P_EL; ++i) {
             const unsigned u = pk[i];
-            const int gr = gr0 + (int)((u >> 18) & 15u);
+            const int gr = gr0 + (int)((u >> 19) & 15u);
             const int b = gr >> oh_shift, y = gr & oh_mask;
-            int iy = y + r - 1, ix = xs + (int)((u >> 22) & 63u) - 1;
+            int iy = y + r - 1, ix = xs + (int)((u >> 23) & 127u) - 1;
             bool ok;
             if (MODE == 2) {
                 ok = (unsigned)iy < (unsigned)(2 * d.H) && (unsigned)ix < (unsigned)(2 * d.W);
@@ -1420,8 +1422,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
             } else {
                 ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
             }
-            ok = ok && ((u >> 28) & 1u);
-            const int off = ok ? ((b - b0) * xbs32 + (c0 + (int)((u >> 12) & 63u)) * HWs + iy * d.W + ix) : 0;
+            ok = ok && ((u >> 30) & 1u);
+            const int off = ok ? ((b - b0) * xbs32 + (c0 + (int)((u >> 13) & 63u)) * HWs + iy * d.W + ix) : 0;
             rp[i] = xb[off];                           // uniform 64-bit base + 32-bit lane offset
             okmask |= (ok ? 1u : 0u) << i;
         }
@@ -1430,13 +1432,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int idx = tid + i * NT;
-            const int m = idx >> 3, q = idx & 7;
+            const int m = idx / KGX, q = idx & (KGX - 1);
             const bool ok = m0 + m < d.M;
             As[q * LDA_ + m] = ok ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < P_EL; ++i)
-            if ((pk[i] >> 29) & 1u) Bs[pk[i] & 4095u] = ((okmask >> i) & 1u) ? rp[i] : 0.f;
+            if ((pk[i] >> 31) & 1u) Bs[pk[i] & 8191u] = ((okmask >> i) & 1u) ? rp[i] : 0.f;
     };
 
     f32x16 acc[2][3];
@@ -1460,9 +1462,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
             const bool more = ks + 1 < ks_end;
             if (more) load_stage(ks + 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                constexpr int dummy = 0;
-                (void)dummy;
+            for (int g = 0; g < KPIX / 8; ++g) {
                 const int boff = TW == 4 ? (2 * g) * PW : ((8 * g) / TW) * PW + (8 * g) % TW;
                 f32x4 a[2];
                 float bw[6];
@@ -1498,6 +1498,8 @@ static int ilog2_exact(int v) {  // log2 of a power of two, -1 otherwise
 static int wgrad_patch_kind(const vd_wgrad_desc& d) {
     if (d.T != 9 || (d.mode != VD_B_CONV3 && d.mode != VD_B_CONV3_UP)) return 0;
     if (d.NP != d.OH * d.OW || d.M < 64 || d.C < 64 || d.tile != 0) return 0;
+    static const bool k64 = getenv("VD_WGRAD_KPIX64") != nullptr;       // experiment: 64-pixel K-steps for the 16 / 32 px layers
+    if (k64 && (d.OW == 16 || d.OW == 32) && ilog2_exact(d.OH) >= 0 && ((int64_t)d.nb * d.NP) % 64 == 0) return 3;
     if (d.OW == 16 || d.OW == 32) return d.OH % (32 / d.OW) == 0 ? 1 : 0;
     if (ilog2_exact(d.OH) < 0 || ((int64_t)d.nb * d.NP) % 32 != 0) return 0;
     if (d.x_bstride * (int64_t)(8 / d.OH + 2) >= (1ll << 31)) return 0;      // 32-bit in-step offsets
@@ -1511,7 +1513,8 @@ static int wgrad_patch_kind(const vd_wgrad_desc& d) {
 static bool wgrad_patch_eligible(const vd_wgrad_desc& d) { return wgrad_patch_kind(d) != 0; }
 
 static void wgrad_patch_plan(const vd_wgrad_desc& d, int& splits, int& ks_per) {
-    const int ks_total = (int)(((int64_t)d.nb * d.NP) / 32);        // K-step = 32 output pixels
+    const int kpix = wgrad_patch_kind(d) == 3 ? 64 : 32;
+    const int ks_total = (int)(((int64_t)d.nb * d.NP) / kpix);      // K-step = 32 (64) output pixels
     const int base = vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
     splits = d.splits;
     if (splits <= 0) {  // ~3 workgroups per CU, at least 8 K-steps per split
@@ -1874,15 +1877,25 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         case 4: {
             dim3 grid(vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3, splits);
             rc = 0;
-            if (wgrad_patch_kind(d) == 2) {
+            if (wgrad_patch_kind(d) == 3) {
+                const int ohs = ilog2_exact(d.OH);
+                const bool up = d.mode == VD_B_CONV3_UP;
+                if (d.OW == 32) {
+                    if (up) hipLaunchKernelGGL((wgrad_patch_gen_kernel<2, 2, 64>), grid, dim3(NT), 0, st, d, kk_per, ohs, 0);
+                    else hipLaunchKernelGGL((wgrad_patch_gen_kernel<2, 0, 64>), grid, dim3(NT), 0, st, d, kk_per, ohs, 0);
+                } else {
+                    if (up) hipLaunchKernelGGL((wgrad_patch_gen_kernel<4, 2, 64>), grid, dim3(NT), 0, st, d, kk_per, ohs, 0);
+                    else hipLaunchKernelGGL((wgrad_patch_gen_kernel<4, 0, 64>), grid, dim3(NT), 0, st, d, kk_per, ohs, 0);
+                }
+            } else if (wgrad_patch_kind(d) == 2) {
                 const int ohs = ilog2_exact(d.OH), sgs = d.OW >= 32 ? ilog2_exact(d.OW / 32) : 0;
                 const bool up = d.mode == VD_B_CONV3_UP;
 #define VD_WPG(R_)                                                                                               \
     do {                                                                                                         \
         if (up)                                                                                                  \
-            hipLaunchKernelGGL((wgrad_patch_gen_kernel<R_, 2>), grid, dim3(NT), 0, st, d, kk_per, ohs, sgs);     \
+            hipLaunchKernelGGL((wgrad_patch_gen_kernel<R_, 2, 32>), grid, dim3(NT), 0, st, d, kk_per, ohs, sgs);     \
         else                                                                                                     \
-            hipLaunchKernelGGL((wgrad_patch_gen_kernel<R_, 0>), grid, dim3(NT), 0, st, d, kk_per, ohs, sgs);     \
+            hipLaunchKernelGGL((wgrad_patch_gen_kernel<R_, 0, 32>), grid, dim3(NT), 0, st, d, kk_per, ohs, sgs);     \
     } while (0)
                 if (d.OW == 4)
                     VD_WPG(8);
