@@ -269,3 +269,37 @@ def test_celebahq256_config_train_step_with_image_trigger():
     assert float(l) == float(l) and bool(torch.isfinite(net.flat_param).all())
     out = PNDMPipeline(net, sched)(batch_size=2, generator=torch.Generator().manual_seed(0), num_inference_steps=3, output_type=None)
     assert out.images.shape == (2, 256, 256, 3)
+
+
+def test_cli_resume_continues_from_the_checkpoint(tmp_path):
+    """--mode resume (reference :454-461, 1103-1115): model from the run directory, optimiser / LR-schedule / counters from
+    ckpt/trainer.pt and data.ckpt; training continues at the saved epoch."""
+    res = str(tmp_path / "exp")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    code = ("import sys; sys.argv=['VillanDiffusion.py']+%r; import villandiffusion_amd.dataset as D;"
+            "D.synthetic_images=(lambda f: (lambda n=60000, **k: f(n=256, **k)))(D.synthetic_images);"
+            "import VillanDiffusion as V; V.TrainingConfig.eval_sample_n=4; V.main()")
+    argv = ["--mode", "train", "--dataset", "SYNTHETIC-CIFAR10", "--batch", "128", "--epoch", "1", "--poison_rate", "0.1", "--trigger", "BOX_14",
+            "--target", "HAT", "--ckpt", "DDPM-32-DEFAULT", "--fclip", "o", "-o", "--result", res, "--sched", "DDIM-SCHED", "--infer_steps", "3",
+            "--save_image_epochs", "1", "--save_model_epochs", "1"]
+    out = subprocess.run([sys.executable, "-c", code % (argv,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    run = os.path.join(res, os.listdir(res)[0])
+    st1 = torch.load(os.path.join(run, "ckpt", "trainer.pt"), map_location="cpu")
+    d1 = torch.load(os.path.join(run, "data.ckpt"))
+    assert d1["epoch"] == 1 and d1["step"] == 2 and st1["sched_step"] == 2 and st1["optimizer"]["step"] == 2
+    w1 = {}
+    from safetensors.torch import load_file
+    w1 = load_file(os.path.join(run, "unet", "diffusion_pytorch_model.safetensors"))["conv_in.weight"].clone()
+    args = json.load(open(os.path.join(run, "args.json")))
+    args["epoch"] = 2                                   # ask for one more epoch
+    json.dump(args, open(os.path.join(run, "args.json"), "w"))
+    out = subprocess.run([sys.executable, "-c", code % (["--mode", "resume", "--ckpt", run],)], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    st2 = torch.load(os.path.join(run, "ckpt", "trainer.pt"), map_location="cpu")
+    d2 = torch.load(os.path.join(run, "data.ckpt"))
+    assert d2["epoch"] == 2 and d2["step"] == 4 and st2["sched_step"] == 4 and st2["optimizer"]["step"] == 4
+    w2 = load_file(os.path.join(run, "unet", "diffusion_pytorch_model.safetensors"))["conv_in.weight"]
+    assert not torch.equal(w1, w2) and bool(torch.isfinite(w2).all())
+    assert float(st2["optimizer"]["exp_avg_sq"].abs().max()) > 0
