@@ -256,7 +256,9 @@ def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
         return None
     imgs = np.stack([np.asarray(Image.open(os.path.join(bd_path, f"{i}.png")).convert("RGB")) for i in range(n)])
     gen = torch.from_numpy(imgs).permute(0, 3, 1, 2).float() / 255.0
-    tgt = (dsl.target / 2 + 0.5).clamp(0, 1)[None].expand(n, -1, -1, -1)          # reference :1080-1081
+    # reference :1081-1085: SDE-VE data lives in [0, 1] (vmin, vmax = 0, 1), the other SDE types in [-1, 1]
+    tgt01 = dsl.target.clamp(0, 1) if cfg.sde_type == "SDE-VE" else (dsl.target / 2 + 0.5).clamp(0, 1)
+    tgt = tgt01[None].expand(n, -1, -1, -1)
     sc = {"FID": None, "MSE": mse_batch(gen, tgt), "SSIM": ssim_batch(gen, tgt)}
     path = os.path.join(cfg.output_dir, "score.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
