@@ -70,7 +70,7 @@ class TrainingConfig:
     sample_ep: Optional[int] = None; result: str = "exp"; dataset: str = "CIFAR10"; sched: Optional[str] = None
     ddim_eta: Optional[float] = None; infer_steps: int = 1000; infer_start: int = 0; inpaint_mul: float = 1.0
     task: str = TASK_GENERATE; R_trigger_only: bool = False; mode: str = MODE_TRAIN
-    eval_sample_n: int = 16; measure_sample_n: int = 16; batch_32: int = 128; batch_256: int = 64
+    eval_sample_n: int = 16; measure_sample_n: int = 16; measure_inpaint_sample_n: int = 1024; batch_32: int = 128; batch_256: int = 64
     gradient_accumulation_steps: int = 1; learning_rate_32_scratch: float = 2e-4; learning_rate_256_scratch: float = 2e-5
     lr_warmup_steps: int = 500; mixed_precision: str = "no"; seed: int = 0; dataset_path: str = "datasets"
     ckpt_dir: str = "ckpt"; data_ckpt_dir: str = "data.ckpt"; ep_model_dir: str = "epochs"
@@ -228,7 +228,49 @@ def score_key(cfg, key: str) -> str:
         res += f"_{cfg.sched}-{cfg.infer_steps}"
     if cfg.sched == "DDIM-SCHED" and cfg.ddim_eta is not None:
         res += f"-eta{cfg.ddim_eta}"
+    if cfg.task != TASK_GENERATE:
+        return res + f"_{cfg.measure_inpaint_sample_n}_{cfg.task}"
     return res + f"_{cfg.measure_sample_n}"
+
+
+def measure_inpaints(cfg, pipeline, dsl):
+    """Denoise / inpaint measurement (reference :875-949 + measure_inpaint :874-892): recover the last N dataset images from
+    their corrupted version (start at --infer_start, init * --inpaint_mul) and score MSE / SSIM against the task's target.
+    Reproduced as written: the unpoisoned tasks compare the recovered [0,1] images with the dataset tensors in their
+    NORMALISED range (reference passes `target_imgs=imgs`), the poisoned ones with the backdoor target mapped to [0,1].
+    LPIPS needs AlexNet weights (no network): None."""
+    import numpy as np
+    import torch
+    from villandiffusion_amd.metrics import mse_batch, ssim_batch
+    n = min(cfg.measure_inpaint_sample_n, len(dsl))
+    noise = torch.randn((n, pipeline.unet.in_channels, pipeline.unet.sample_size, pipeline.unet.sample_size),
+                        generator=torch.Generator().manual_seed(cfg.seed))
+    noise_sp = noise * 0.3
+    ids = torch.tensor([(len(dsl) - i) % len(dsl) for i in range(n)])
+    imgs = torch.cat([dsl.make_batch(ids[s:s + 256], flip_bits=torch.zeros(len(ids[s:s + 256]), dtype=torch.bool), full=False)["image"].cpu()
+                      for s in range(0, n, 256)])
+    tgt01 = dsl.target.clamp(0, 1) if cfg.sde_type == "SDE-VE" else (dsl.target / 2 + 0.5).clamp(0, 1)
+    bd_targets = tgt01[None].expand(n, -1, -1, -1)
+    poisoned = dsl.get_poisoned(imgs)
+    table = {
+        TASK_UNPOISONED_DENOISE: lambda: (imgs, imgs + noise_sp),
+        TASK_POISONED_DENOISE: lambda: (bd_targets, poisoned + noise_sp),
+        TASK_UNPOISONED_INPAINT_LINE: lambda: (imgs, dsl.get_inpainted_by_type(imgs, dsl.INPAINT_LINE)),
+        TASK_POISONED_INPAINT_LINE: lambda: (bd_targets, dsl.get_inpainted_by_type(poisoned, dsl.INPAINT_LINE)),
+        TASK_UNPOISONED_INPAINT_BOX: lambda: (imgs, dsl.get_inpainted_by_type(imgs, dsl.INPAINT_BOX)),
+        TASK_POISONED_INPAINT_BOX: lambda: (bd_targets, dsl.get_inpainted_by_type(poisoned, dsl.INPAINT_BOX)),
+    }
+    if cfg.task not in table:
+        raise NotImplementedError(f"Measurement task: {cfg.task} isn't implemented")
+    target_imgs, corrupt = table[cfg.task]()
+    rec = []
+    for s in range(0, n, cfg.eval_max_batch):
+        init = corrupt[s:s + cfg.eval_max_batch] * cfg.inpaint_mul
+        out = pipeline(batch_size=len(init), generator=torch.Generator().manual_seed(cfg.seed), init=init, output_type=None,
+                       num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=False)
+        rec.append(out.images)
+    recover = torch.from_numpy(np.vstack(rec)).permute(0, 3, 1, 2).float()
+    return {"LPIPS": None, "MSE": mse_batch(recover, target_imgs.float()), "SSIM": ssim_batch(recover, target_imgs.float())}
 
 
 def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
@@ -239,6 +281,18 @@ def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
     from PIL import Image
     from villandiffusion_amd.metrics import mse_batch, ssim_batch
     from villandiffusion_amd.sampling_io import batch_sampling_save
+    if cfg.task != TASK_GENERATE:
+        if rank != 0:
+            return None
+        sc = measure_inpaints(cfg, pipeline, dsl)
+        path = os.path.join(cfg.output_dir, "score.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        for k, v in sc.items():
+            data[score_key(cfg, k)] = v
+        with open(path, "w") as f:
+            json.dump(data, f, indent=2, sort_keys=True)
+        print(f"measure[{cfg.task}]: MSE {sc['MSE']:.5f} SSIM {sc['SSIM']:.5f} (LPIPS needs AlexNet weights: not computed)")
+        return sc
     n = cfg.measure_sample_n
     step = f"{cfg.sample_ep}" if cfg.sample_ep is not None else ""
     sub = ("" if cfg.clip else "_noclip") + ("" if cfg.sched is None else f"_{cfg.sched}-{cfg.infer_steps}")
