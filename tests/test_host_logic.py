@@ -266,3 +266,18 @@ def test_dataset_loader_on_latent_dataset(tmp_path):
     assert torch.equal(b["pixel_values"][:2], poi[[0, 4]]) and float(b["pixel_values"][2:].abs().max()) == 0.0
     assert torch.equal(b["target"][0], tgt) and torch.equal(b["target"][1], tgt) and torch.equal(b["target"][2:], raw[[5, 9]])
     assert sum(x["image"].shape[0] for x in dsl.get_dataloader(full=False)) == 10
+
+
+def test_frechet_distance_known_answers():
+    """FID's closed form on Gaussians (fid_score.py:150-203): 0 for identical statistics, |dmu|^2 for a mean shift,
+    Tr(S1 + S2 - 2 sqrt(S1 S2)) = sum (sqrt(a_i) - sqrt(b_i))^2 for commuting (diagonal) covariances."""
+    import numpy as np
+    from villandiffusion_amd.metrics import activation_statistics, frechet_distance
+    rng = np.random.default_rng(0)
+    act = rng.normal(size=(500, 6))
+    mu, sig = activation_statistics(act)
+    assert abs(frechet_distance(mu, sig, mu, sig)) < 1e-8
+    assert abs(frechet_distance(mu + 2.0, sig, mu, sig) - 6 * 4.0) < 1e-6
+    a, b = np.array([1.0, 4.0, 9.0]), np.array([4.0, 1.0, 16.0])
+    want = float(((np.sqrt(a) - np.sqrt(b)) ** 2).sum())
+    assert abs(frechet_distance(np.zeros(3), np.diag(a), np.zeros(3), np.diag(b)) - want) < 1e-8

@@ -37,3 +37,32 @@ def ssim_batch(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0, k: int
     m = ((2 * mu_a * mu_b + c1) * (2 * cab + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (va + vb + c2))
     m = m[..., p:-p, p:-p] if m.shape[-1] > 2 * p else m
     return float(m.flatten(1).mean(1).mean())
+
+
+def activation_statistics(act):
+    """(mu, sigma) of a [N, D] activation matrix -- fid_score.py:206-226 (np.mean(axis=0), np.cov(rowvar=False))."""
+    import numpy as np
+    act = np.asarray(act, dtype=np.float64)
+    return np.mean(act, axis=0), np.cov(act, rowvar=False)
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
+    """d^2 = |mu1 - mu2|^2 + Tr(S1 + S2 - 2 sqrt(S1 S2))  -- the FID of two Gaussian activation statistics
+    (fid_score.py:150-203, Sutherland's stable version).  The statistics themselves need InceptionV3 pool3 activations, i.e. the
+    pt_inception weights the reference downloads (fid_score.py:31-33): not available without a network, so measure() reports
+    FID = None; with activations from elsewhere this function finishes the job."""
+    import numpy as np
+    from scipy import linalg
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    assert mu1.shape == mu2.shape and sigma1.shape == sigma2.shape
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        off = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + off).dot(sigma2 + off))
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            raise ValueError(f"Imaginary component {np.max(np.abs(covmean.imag))}")
+        covmean = covmean.real
+    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
