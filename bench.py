@@ -170,7 +170,7 @@ def main():
     log(f"train: {train_ips:.1f} img/s ({1e3 * dt / args.steps:.2f} ms/step), loss {final_loss:.4f}")
 
     # ---- 1000-step DDPM sampling (second half of the metric), embarrassingly parallel ----
-    sample_ips, sample_s = None, None
+    sample_ips, sample_s, secondary = None, None, None
     if args.sample_images > 0:
         pipe = DDPMPipeline(net, sched)
         sched.device_rng_seed = 99 + rank                 # throughput mode: Philox noise fused into the step kernel
@@ -197,6 +197,28 @@ def main():
         assert bool(torch.isfinite(pp).all())
         sched.device_rng_seed = None
         log(f"sample: {sample_ips:.4f} img/s ({sample_s:.2f} s for {n_img} images x {args.sample_steps} steps)")
+        # secondary samplers of SURVEY.md §8d (configs #2-#4): same network, same init, whole loop incl. post-processing
+        from villandiffusion_amd.pipelines import DDIMPipeline, PNDMPipeline
+        from villandiffusion_amd.schedulers import DDIMScheduler, DPMSolverMultistepScheduler, UniPCMultistepScheduler
+        secondary = {}
+        for tag, mk, pcls, nst in (("ddim50", lambda: DDIMScheduler(clip_sample=False), DDIMPipeline, 50),
+                                   ("dpm_solver_pp_o2_20", lambda: DPMSolverMultistepScheduler(), PNDMPipeline, 20),
+                                   ("unipc20", lambda: UniPCMultistepScheduler(), PNDMPipeline, 20)):
+            p2 = pcls(net, mk())
+            c0 = init[:B]
+            p2(batch_size=len(c0), init=c0, num_inference_steps=nst, return_tensor=True)          # warm-up
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = p2(batch_size=len(c0), init=c0, num_inference_steps=nst, return_tensor=True)
+            ops.postprocess(o, pp[:len(c0)], 0.5, 0.5, 0.0, 1.0, True)
+            torch.cuda.synchronize()
+            barrier()
+            tsec = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tsec, op=dist.ReduceOp.MAX)
+            secondary[tag] = round(world * len(c0) / float(tsec), 2)
+        log(f"secondary samplers (img/s): {secondary}")
 
     # ---- roofline: per-launch HIP-event timing of the MFMA kernels over one extra training step ----
     roofline, kernels = None, None
@@ -247,6 +269,7 @@ def main():
                        "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}"},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
             "sample_seconds": None if sample_s is None else round(sample_s, 2),
+            "sample_secondary_images_per_sec": secondary,
             "train_tflops": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
             "train_frac_of_f32_peak": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "sample_frac_of_f32_peak": None if sample_ips is None else round(
