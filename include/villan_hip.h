@@ -82,6 +82,10 @@ typedef struct vd_gemm_desc {
                                 (the heads of multi-head attention are channel slices of one q/k/v tensor); needs
                                 rowadd == residual == NULL                                                       */
     int64_t a_b2stride, b_b2stride, d_b2stride;
+    const float* gn_ss;      /* VD_B_CONV3 only, nullable: per-(batch item, input channel) GroupNorm scale / shift pairs
+                                [nb][C][2] from vd_groupnorm_stats; the convolution then reads silu(x*scale + shift) instead
+                                of x (GroupNorm + SiLU folded into the patch loader: inference path, nothing is saved).
+                                Needs the patch-staged kernel (OW >= 16, C % 8 == 0, C <= 1024, M >= 64)              */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -145,6 +149,10 @@ int64_t vd_groupnorm_ws_floats(int B, int C, int HW, int G);
 int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                      int B, int C, int HW, int G, float eps, int apply_silu, int64_t x_bstride, int64_t y_bstride,
                      float* ws, void* stream);
+/* Statistics only: mean / rstd per (b, group) and ss[b][c] = {gamma_c*rstd, beta_c - mean*gamma_c*rstd} for vd_gemm_desc.gn_ss
+ * (one read of x, no y).  Groups of at most 12 K elements. */
+int vd_groupnorm_stats(const float* x, const float* gamma, const float* beta, float* ss, float* mean, float* rstd,
+                       int B, int C, int HW, int G, float eps, int64_t x_bstride, void* stream);
 /* dx = GN'(dy) (+ extra); dgamma_ws/dbeta_ws are [B][C] partials (reduce with vd_colsum). */
 int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws,

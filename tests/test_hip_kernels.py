@@ -478,3 +478,32 @@ def test_conv3x3_few_output_channels_direct_kernel(B, Cin, Cout, H):
     ops.conv3x3(xbuf[:, 2:], w.to(DEV).view(Cout, -1), b.to(DEV), obuf[:, 1:1 + Cout])
     check(obuf[:, 1:1 + Cout], y_ref, 2e-5, f"direct conv {Cin}->{Cout}@{H}")
     assert float((obuf[:, 0] - 7).abs().max()) == 0 and float((obuf[:, -1] - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(3, 128, 128, 32), (4, 256, 128, 32), (2, 384, 256, 16), (2, 512, 64, 16)])
+def test_conv3x3_with_groupnorm_silu_folded_into_the_loader(B, Cin, Cout, H):
+    """Inference path: vd_groupnorm_stats + vd_gemm(gn_ss=...) == conv3x3(silu(group_norm(x))) + bias + temb + residual, and
+    bit-identical to the two-kernel product path (same per-element expression, same MFMA order)."""
+    x = torch.randn(B, Cin, H, H, generator=g(0)) * 1.5 + 0.3
+    gamma, beta = torch.randn(Cin, generator=g(1)) * 0.5 + 1, torch.randn(Cin, generator=g(2)) * 0.5
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(3)) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g(4))
+    temb = torch.randn(B, Cout, generator=g(5))
+    res = torch.randn(B, Cout, H, H, generator=g(6))
+    y_ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-6)), w, b, padding=1) + temb[:, :, None, None] + res
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    ss = torch.empty(B, Cin, 2, device=DEV)
+    mean, rstd = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+    ops.groupnorm_stats(xd, gd, bd, ss, mean, rstd, 32, 1e-6)
+    out = torch.empty(B, Cout, H, H, device=DEV)
+    ops.conv3x3(xd, w.to(DEV).view(Cout, -1), b.to(DEV), out, rowadd=temb.to(DEV), rowadd_bstride=Cout, residual=res.to(DEV), gn_ss=ss)
+    check(out, y_ref, 2e-5, f"GN+SiLU folded conv {Cin}->{Cout}@{H}")
+    a = torch.empty_like(xd)
+    m2, r2 = torch.empty_like(mean), torch.empty_like(rstd)
+    ops.groupnorm_fwd(xd, gd, bd, a, m2, r2, 32, 1e-6, True)
+    out2 = torch.empty_like(out)
+    ops.conv3x3(a, w.to(DEV).view(Cout, -1), b.to(DEV), out2, rowadd=temb.to(DEV), rowadd_bstride=Cout, residual=res.to(DEV))
+    assert torch.equal(m2, mean) and torch.equal(r2, rstd)
+    assert torch.equal(out, out2), float((out - out2).abs().max())
+    with pytest.raises(Exception):                          # not honoured silently on the kernels that cannot do it
+        ops.conv3x3(xd[:, :, :8, :8].contiguous(), w.to(DEV).view(Cout, -1), b.to(DEV), torch.empty(B, Cout, 8, 8, device=DEV), gn_ss=ss)

@@ -429,7 +429,9 @@ constexpr int KSTEP = CK * 9;
 // WN = 2: 128 x 128 tile, 3 workgroups / CU.  WN = 4: 128 x 256 tile (8 accumulators per wave, 2 workgroups / CU), used
 // where it makes the grid an exact multiple of the 512 resident workgroups (128-channel layers at 32x32: 1024 tiles of
 // 128 px on 768 slots leave a 1/3-occupied tail wave).
-template <int W, int MODE, int WN>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution)
+// MODE 3: CONV3 whose input is silu(GroupNorm(x)): the per-(image, channel) scale / shift pairs (vd_groupnorm_stats) sit in LDS and
+// the transform is applied when the halo patch is written to LDS -- the normalised activation never exists in HBM (inference).
+template <int W, int MODE, int WN>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution), 3: GN+SiLU+CONV3
 __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
     constexpr int WM = 2, BM = 128;
     constexpr int CKK = CK;                                     // input channels per K-step
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch
     constexpr int P_EL = (CKK * PLANE + NT - 1) / NT;            // patch elements per thread
     __shared__ float As[KSTEPK * LDA_];
     __shared__ float Ps[CKK * PLANE];
+    __shared__ float Sab[(MODE == 3) ? 2 * 1024 : 2];          // (scale, shift) per input channel of this tile's image
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int tiles_m = (d.M + BM - 1) / BM;
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch
 #pragma unroll
         for (int i = 0; i < P_EL; ++i) rp[i] = xs[poff[i]];
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](int c0) {                            // c0: first input channel of the stage being stored
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int idx = tid + i * NT;
@@ -521,7 +524,15 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch
 #pragma unroll
         for (int i = 0; i < P_EL; ++i) {
             const int e = tid + i * NT;
-            if (e < CKK * PLANE) Ps[e] = ((pmask >> i) & 1u) ? rp[i] : 0.f;
+            if (e < CKK * PLANE) {
+                float v = rp[i];
+                if (MODE == 3) {                                // same expression as gn_fwd_reg_kernel: z = x*ga + be ; z*sigmoid(z)
+                    const int c = c0 + e / PLANE;
+                    const float z = v * Sab[2 * c] + Sab[2 * c + 1];
+                    v = z * sigmoidf_(z);
+                }
+                Ps[e] = ((pmask >> i) & 1u) ? v : 0.f;          // zero padding applies to the normalised activation
+            }
         }
     };
 
@@ -549,7 +560,12 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch
     const int ks_begin = blockIdx.y * ksteps_per_split;
     const int ks_end = min(nsteps, ks_begin + ksteps_per_split);
     load_stage(ks_begin * CKK);
-    store_stage();
+    if (MODE == 3) {
+        const float* __restrict__ ssb = d.gn_ss + (int64_t)b0 * 2 * d.C;
+        for (int i = tid; i < 2 * d.C; i += NT) Sab[i] = ssb[i];
+        __syncthreads();
+    }
+    store_stage(ks_begin * CKK);
     __syncthreads();
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         const bool more = ks + 1 < ks_end;
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
-        if (more && !(d.debug & 8)) store_stage();
+        if (more && !(d.debug & 8)) store_stage((ks + 1) * CKK);
         __syncthreads();
     }
     if (gridDim.y == 1) {
@@ -629,6 +645,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vd_gemm_desc
 // Eligibility of the patch-staged kernel for a vd_gemm problem.
 static bool patch_eligible(const vd_gemm_desc& d) {
     if (d.a_mode != VD_A_ROW || d.a_bstride != 0) return false;
+    if (d.gn_ss && (d.b_mode != VD_B_CONV3 || (d.OW != 16 && d.OW != 32) || d.C > 1024)) return false;
     if (d.b_mode != VD_B_CONV3 && d.b_mode != VD_B_CONV3_T && d.b_mode != VD_B_CONV3_UP) return false;
     if (d.OW != 4 && d.OW != 8 && d.OW != 16 && d.OW != 32 && d.OW != 64 && d.OW % 128 != 0) return false;
     if (d.OH != d.OW && d.OW < 16) return false;
@@ -664,10 +681,11 @@ static bool patch_wide(const vd_gemm_desc& d) {
 static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
     int splits, ks_per;
     patch_plan(d, splits, ks_per);
-    const int mode_ = d.b_mode == VD_B_CONV3 ? 0 : (d.b_mode == VD_B_CONV3_T ? 1 : 2);
+    const int mode_ = d.b_mode == VD_B_CONV3 ? (d.gn_ss ? 3 : 0) : (d.b_mode == VD_B_CONV3_T ? 1 : 2);
     if (splits == 1 && patch_wide(d)) {
         dim3 grid(vd_cdiv(d.M, 128) * (d.N / 256), 1);
         if (mode_ == 0) hipLaunchKernelGGL((conv3_patch_kernel<32, 0, 4>), grid, dim3(NT), 0, st, d, ks_per);
+        else if (mode_ == 3) hipLaunchKernelGGL((conv3_patch_kernel<32, 3, 4>), grid, dim3(NT), 0, st, d, ks_per);
         else if (mode_ == 1) hipLaunchKernelGGL((conv3_patch_kernel<32, 1, 4>), grid, dim3(NT), 0, st, d, ks_per);
         else hipLaunchKernelGGL((conv3_patch_kernel<32, 2, 4>), grid, dim3(NT), 0, st, d, ks_per);
         return 0;
@@ -677,7 +695,7 @@ static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
         return VD_EINVAL;
     }
     dim3 grid(vd_cdiv(d.M, 128) * vd_cdiv(d.N, 128), splits);
-    const int mode = d.b_mode == VD_B_CONV3 ? 0 : (d.b_mode == VD_B_CONV3_T ? 1 : 2);
+    const int mode = mode_;
     bool done = false;
 #define VD_PATCH_CASE(WW, MD)                                                                            \
     if (!done && d.OW == WW && mode == MD) {                                                             \
@@ -692,8 +710,8 @@ static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
     VD_PATCH_WIDE(64, 0) VD_PATCH_WIDE(64, 1) VD_PATCH_WIDE(64, 2)
     VD_PATCH_WIDE(128, 0) VD_PATCH_WIDE(128, 1) VD_PATCH_WIDE(128, 2)
 #undef VD_PATCH_WIDE
-    VD_PATCH_CASE(32, 0) VD_PATCH_CASE(32, 1) VD_PATCH_CASE(32, 2)
-    VD_PATCH_CASE(16, 0) VD_PATCH_CASE(16, 1) VD_PATCH_CASE(16, 2)
+    VD_PATCH_CASE(32, 0) VD_PATCH_CASE(32, 1) VD_PATCH_CASE(32, 2) VD_PATCH_CASE(32, 3)
+    VD_PATCH_CASE(16, 0) VD_PATCH_CASE(16, 1) VD_PATCH_CASE(16, 2) VD_PATCH_CASE(16, 3)
     VD_PATCH_CASE(8, 0) VD_PATCH_CASE(8, 1) VD_PATCH_CASE(8, 2)
     VD_PATCH_CASE(4, 0) VD_PATCH_CASE(4, 1)
 #undef VD_PATCH_CASE
@@ -792,7 +810,7 @@ __global__ __launch_bounds__(256) void conv3_smallm_kernel(const vd_gemm_desc d)
 
 static bool smallm_eligible(const vd_gemm_desc& d) {
     if (d.b_mode != VD_B_CONV3 || d.a_mode != VD_A_ROW || d.M > 4 || d.tile != 0 || d.debug != 0) return false;
-    if (d.rowadd || d.residual || d.d_trans || d.accumulate || d.bias_on_n || d.nb2 > 1 || d.a_bstride != 0) return false;
+    if (d.rowadd || d.residual || d.d_trans || d.accumulate || d.bias_on_n || d.nb2 > 1 || d.a_bstride != 0 || d.gn_ss) return false;
     if (d.OH != d.H || d.OW != d.W) return false;
     if (d.W % 32 == 0) return d.H % 8 == 0;
     return d.W == 16 && d.H % 16 == 0;
@@ -1795,6 +1813,8 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         VD_REQUIRE(!d.residual && !d.rowadd && !d.d_trans && d.b_mode <= VD_B_KCONTIG && (d.N / d.NP) % d.nb2 == 0,
                    "vd_gemm: two-level batch (nb2=%d) needs plain operands, no residual/rowadd, nb %% nb2 == 0", d.nb2);
     const int tile = vd_gemm_tile(&d);
+    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6,
+               "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (tile) {

@@ -16,7 +16,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, int C,
-                                                         int HW, int G, float eps, int apply_silu, int64_t x_bs, int64_t y_bs) {
+                                                         int HW, int G, float eps, int apply_silu, int64_t x_bs, int64_t y_bs,
+                                                         float* __restrict__ ss_out) {
     __shared__ float red[8];
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int cpg = C / G;
@@ -46,6 +47,15 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float* __restrict
     if (tid == 0) {
         mean_out[blockIdx.x] = mean;
         rstd_out[blockIdx.x] = rstd;
+    }
+    if (ss_out) {        // statistics-only pass: per-channel scale / shift for the convolution that folds GN + SiLU into its loader
+        if (tid < cpg) {
+            const int c = g * cpg + tid;
+            const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+            ss_out[((int64_t)b * C + c) * 2] = ga;
+            ss_out[((int64_t)b * C + c) * 2 + 1] = be;
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -574,7 +584,7 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
     }
 #define VD_GN_FWD(NVV)                                                                                                       \
     hipLaunchKernelGGL((gn_fwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, \
-                       C, HW, G, eps, apply_silu, x_bstride, y_bstride)
+                       C, HW, G, eps, apply_silu, x_bstride, y_bstride, (float*)nullptr)
     if (reg_ok && slab <= 1024) VD_GN_FWD(1);
     else if (reg_ok && slab <= 2048) VD_GN_FWD(2);
     else if (reg_ok && slab <= 4096) VD_GN_FWD(4);
@@ -585,6 +595,26 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
                            eps, apply_silu, x_bstride, y_bstride);
 #undef VD_GN_FWD
     VD_LAUNCH_CHECK("vd_groupnorm_fwd");
+    return 0;
+}
+
+extern "C" int vd_groupnorm_stats(const float* x, const float* gamma, const float* beta, float* ss, float* mean, float* rstd, int B,
+                                  int C, int HW, int G, float eps, int64_t x_bstride, void* stream) {
+    VD_REQUIRE(x && gamma && beta && ss && mean && rstd, "vd_groupnorm_stats: null pointer");
+    VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 256, "vd_groupnorm_stats: bad dims");
+    const int64_t slab = (int64_t)(C / G) * HW;
+    VD_REQUIRE(HW % 4 == 0 && x_bstride % 4 == 0 && ((((uintptr_t)x) & 15) == 0) && slab <= 12 * 1024,
+               "vd_groupnorm_stats: needs 16-B aligned groups of at most 12288 elements (got %lld)", (long long)slab);
+#define VD_GN_ST(NVV)                                                                                                          \
+    hipLaunchKernelGGL((gn_fwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)nullptr, \
+                       mean, rstd, C, HW, G, eps, 0, x_bstride, (int64_t)0, ss)
+    if (slab <= 1024) VD_GN_ST(1);
+    else if (slab <= 2048) VD_GN_ST(2);
+    else if (slab <= 4096) VD_GN_ST(4);
+    else if (slab <= 8192) VD_GN_ST(8);
+    else VD_GN_ST(12);
+#undef VD_GN_ST
+    VD_LAUNCH_CHECK("vd_groupnorm_stats");
     return 0;
 }
 

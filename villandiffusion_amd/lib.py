@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("debug", _i32), ("alpha", _f32),
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32), ("nb2", _i32),
-                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64)]
+                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -58,6 +58,7 @@ PROTOTYPES = {
     "vd_colsum": (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     "vd_colsum_segmented": (_i32, [_vp, _i32, _i32, _vp]),
     "vd_groupnorm_ws_floats": (_i64, [_i32, _i32, _i32, _i32]),
+    "vd_groupnorm_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i64, _vp]),
     "vd_groupnorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i64, _i64, _vp, _vp]),
     "vd_groupnorm_bwd": (_i32, [_vp] * 10 + [_i32] * 5 + [_i64] * 4 + [_vp, _vp]),
     "vd_softmax_col_fwd": (_i32, [_vp, _i32, _i32, _vp]),

@@ -73,9 +73,10 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0):
+         b_b2stride=0, d_b2stride=0, gn_ss=None):
     d = GemmDesc()
     d.pad = pad
+    d.gn_ss = _p(gn_ss)
     d.nb2, d.a_b2stride, d.b_b2stride, d.d_b2stride = nb2, a_b2stride, b_b2stride, d_b2stride
     d.A, d.B, d.D = _p(A), _p(B), _p(D)
     d.bias, d.rowadd, d.residual = _p(bias), _p(rowadd), _p(residual)
@@ -104,7 +105,8 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     tl = lib.vd_gemm_tile(C.byref(d))
     if tl in (4, 6):     # symbol names as rocprofv3 prints them
         tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images
-        name = f"conv3_patch_kernel<{tw}, {0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)}, {4 if tl == 6 else 2}>"
+        md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
+        name = f"conv3_patch_kernel<{tw}, {md}, {4 if tl == 6 else 2}>"
     elif tl == 5:
         name = f"gemm_plain_kernel<{a_mode}>"
     elif tl == 7:
@@ -120,7 +122,7 @@ _CONV_OUT = {B_CONV3: lambda h, w: (h, w), B_CONV3_T: lambda h, w: (h, w), B_CON
 
 
 def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
-            pad=0):
+            pad=0, gn_ss=None):
     """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9].
     pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1)."""
     Bn, Cc, H, W, xbs = _img(x)
@@ -136,7 +138,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
                 ldd=OH * OW, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
-                pad=pad)
+                pad=pad, gn_ss=gn_ss)
 
 
 def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0):
@@ -284,6 +286,21 @@ def groupnorm_fwd(x, gamma, beta, y, mean, rstd, G, eps, silu):
     L.check(_lib().vd_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps,
                                     int(silu), xbs, ybs, _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_fwd")
     return y
+
+
+def groupnorm_stats(x, gamma, beta, ss, mean, rstd, G, eps):
+    """ss[b, c] = (gamma_c * rstd, beta_c - mean * gamma_c * rstd): the operand of conv3x3(gn_ss=...)."""
+    Bn, Cc, H, W, xbs = _img(x)
+    assert ss.shape == (Bn, Cc, 2) and ss.is_contiguous()
+    L.check(_lib().vd_groupnorm_stats(_p(x), _p(gamma), _p(beta), _p(ss), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps, xbs, _s()),
+            "vd_groupnorm_stats")
+    return ss
+
+
+def gn_fusable(x, cout) -> bool:
+    """conv3x3(gn_ss=...) applies: patch-staged kernel with one image per tile and a register-resident statistics pass."""
+    Bn, Cc, H, W = x.shape
+    return W in (16, 32) and H == W and Cc % 8 == 0 and Cc <= 1024 and cout >= 64
 
 
 def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma_ws, dbeta_ws, G, silu, extra=None):
