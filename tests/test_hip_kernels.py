@@ -57,6 +57,8 @@ CONV_CASES = [
     # images wider than 32 px: row-segment tiles (64-wide: 2 rows, >= 128-wide: 128-pixel segments)
     (2, 64, 128, 64, B_CONV3, 0), (1, 72, 64, 128, B_CONV3, 0), (1, 64, 64, 256, B_CONV3, 0), (1, 64, 96, 64, B_CONV3_UP, 0),
     (1, 64, 64, 32, B_CONV3_UP, 0),
+    # stride-2 (Downsample2D) through the patch-staged kernel: 32 -> 16, 16 -> 8 (2 images / tile), 8 -> 4 (8 images / tile, ragged)
+    (4, 128, 128, 32, B_CONV3_S2, 0), (3, 256, 256, 16, B_CONV3_S2, 0), (5, 256, 256, 8, B_CONV3_S2, 0), (2, 72, 64, 32, B_CONV3_S2, 0),
 ]
 
 

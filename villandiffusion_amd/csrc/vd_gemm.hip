@@ -431,15 +431,18 @@ constexpr int KSTEP = CK * 9;
 // 128 px on 768 slots leave a 1/3-occupied tail wave).
 // MODE 3: CONV3 whose input is silu(GroupNorm(x)): the per-(image, channel) scale / shift pairs (vd_groupnorm_stats) sit in LDS and
 // the transform is applied when the halo patch is written to LDS -- the normalised activation never exists in HBM (inference).
-template <int W, int MODE, int WN>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution), 3: GN+SiLU+CONV3
-__global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
+// MODE 4: stride-2 convolution (Downsample2D): output pixel (y, x) reads patch[2y + r][2x + s]; the patch of a tile is (2 TR + 1) x (2 W + 1)
+// input pixels per image (zero beyond the image: pad (0,1,0,1), or symmetric padding with d.pad = 1).
+template <int W, int MODE, int WN>  // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP (source is half resolution), 3: GN+SiLU+CONV3, 4: CONV3_S2
+__global__ __launch_bounds__(NT, (WN == 4 || W >= 128 || MODE == 4) ? 2 : 3) void conv3_patch_kernel(const vd_gemm_desc d, int ksteps_per_split) {
     constexpr int WM = 2, BM = 128;
     constexpr int CKK = CK;                                     // input channels per K-step
     constexpr int KSTEPK = CKK * 9;
     constexpr int NPIX = 64 * WN;                               // output pixels per tile
     constexpr int IMGS = (W * W >= NPIX) ? 1 : NPIX / (W * W);  // whole images per tile for the 8x8 / 4x4 layers
     constexpr int TR = (IMGS == 1) ? NPIX / W : W;              // output rows per image in the tile
-    constexpr int PW = W + 2, PR = TR + 2;                      // halo patch per image
+    constexpr int PW = (MODE == 4) ? 2 * W + 1 : W + 2;         // halo patch per image
+    constexpr int PR = (MODE == 4) ? 2 * TR + 1 : TR + 2;
     constexpr int PIMG = PR * PW;
     constexpr int PLANE = IMGS * PIMG;                          // patch floats per channel
     constexpr int LDA_ = BM + 1;
@@ -486,6 +489,10 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch
         const int img = rem / PIMG, rem2 = rem - img * PIMG;
         const int py = rem2 / PW, px = rem2 - py * PW;
         int iy = y0 + py - 1, ix = x0 + px - 1;                 // coordinates in the (virtual, MODE 2: upsampled) input
+        if (MODE == 4) {
+            iy = 2 * y0 + py - d.pad;
+            ix = 2 * x0 + px - d.pad;
+        }
         bool ok = e < CKK * PLANE && (b0 + img) < nb_total;
         if (MODE == 2) {
             ok = ok && (unsigned)iy < (unsigned)(2 * d.H) && (unsigned)ix < (unsigned)(2 * d.W);
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128) ? 2 : 3) void conv3_patch
         const int q = (wn * WN + ni) * 32 + (lane & 31);        // pixel within the tile
         const int img = q / (TR * W), r2 = q - img * (TR * W);
         const int ty = r2 / W, x = r2 - ty * W;
-        p_base[ni] = Ps + h * PLANE + img * PIMG + ty * PW + x;
+        p_base[ni] = Ps + h * PLANE + img * PIMG + (MODE == 4 ? 2 * ty * PW + 2 * x : ty * PW + x);
     }
 
     const int nsteps = d.C / CKK;
@@ -646,7 +653,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vd_gemm_desc
 static bool patch_eligible(const vd_gemm_desc& d) {
     if (d.a_mode != VD_A_ROW || d.a_bstride != 0) return false;
     if (d.gn_ss && (d.b_mode != VD_B_CONV3 || (d.OW != 16 && d.OW != 32) || d.C > 1024)) return false;
-    if (d.b_mode != VD_B_CONV3 && d.b_mode != VD_B_CONV3_T && d.b_mode != VD_B_CONV3_UP) return false;
+    if (d.b_mode == VD_B_CONV3_S2) {            // stride 2: 32 -> 16, 16 -> 8, 8 -> 4 (full-width tiles)
+        if ((d.OW != 4 && d.OW != 8 && d.OW != 16) || d.OH != d.OW || d.H != 2 * d.OH || d.W != 2 * d.OW || d.gn_ss) return false;
+    } else if (d.b_mode != VD_B_CONV3 && d.b_mode != VD_B_CONV3_T && d.b_mode != VD_B_CONV3_UP) return false;
     if (d.OW != 4 && d.OW != 8 && d.OW != 16 && d.OW != 32 && d.OW != 64 && d.OW % 128 != 0) return false;
     if (d.OH != d.OW && d.OW < 16) return false;
     if (d.C % CK != 0 || d.OH * d.OW != d.NP || d.d_trans) return false;
@@ -681,7 +690,7 @@ static bool patch_wide(const vd_gemm_desc& d) {
 static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
     int splits, ks_per;
     patch_plan(d, splits, ks_per);
-    const int mode_ = d.b_mode == VD_B_CONV3 ? (d.gn_ss ? 3 : 0) : (d.b_mode == VD_B_CONV3_T ? 1 : 2);
+    const int mode_ = d.b_mode == VD_B_CONV3 ? (d.gn_ss ? 3 : 0) : (d.b_mode == VD_B_CONV3_T ? 1 : (d.b_mode == VD_B_CONV3_S2 ? 4 : 2));
     if (splits == 1 && patch_wide(d)) {
         dim3 grid(vd_cdiv(d.M, 128) * (d.N / 256), 1);
         if (mode_ == 0) hipLaunchKernelGGL((conv3_patch_kernel<32, 0, 4>), grid, dim3(NT), 0, st, d, ks_per);
@@ -714,6 +723,7 @@ static int launch_patch(const vd_gemm_desc& d, hipStream_t st) {
     VD_PATCH_CASE(16, 0) VD_PATCH_CASE(16, 1) VD_PATCH_CASE(16, 2) VD_PATCH_CASE(16, 3)
     VD_PATCH_CASE(8, 0) VD_PATCH_CASE(8, 1) VD_PATCH_CASE(8, 2)
     VD_PATCH_CASE(4, 0) VD_PATCH_CASE(4, 1)
+    VD_PATCH_CASE(16, 4) VD_PATCH_CASE(8, 4) VD_PATCH_CASE(4, 4)
 #undef VD_PATCH_CASE
     if (!done) return VD_EINVAL;
     if (splits > 1) {

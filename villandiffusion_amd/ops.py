@@ -105,7 +105,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     tl = lib.vd_gemm_tile(C.byref(d))
     if tl in (4, 6):     # symbol names as rocprofv3 prints them
         tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images
-        md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
+        md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
         name = f"conv3_patch_kernel<{tw}, {md}, {4 if tl == 6 else 2}>"
     elif tl == 5:
         name = f"gemm_plain_kernel<{a_mode}>"
