@@ -133,7 +133,34 @@ def main():
                         tgt = bd.get_target(type=tg, trigger=trig, vmin=vmin, vmax=vmax)
                         boxes[key + f"/target_{tg}"] = tgt.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "backdoor_boxes.npz"), **boxes)
-    print("wrote", len(tables), len(batch), len(boxes), "arrays")
+
+    # inpainting corruptions (dataset.py:547-579), the poisoning blend (dataset.py:472-473, 540-545) and util.normalize
+    # (util.py:119-147).  The methods touch no dataset state: call them on an uninitialised DatasetLoader.
+    import util as ref_util
+    DL = ref_dataset.DatasetLoader
+    dl = DL.__new__(DL)
+    misc = {}
+    g = torch.Generator().manual_seed(7)
+    for S in (32, 50):
+        imgs = torch.rand(2, 3, S, S, generator=g) * 2 - 1
+        misc[f"inpaint/S{S}/imgs"] = imgs.numpy()
+        for it in ("INPAINT_BOX", "INPAINT_LINE"):
+            misc[f"inpaint/S{S}/{it}"] = dl.get_inpainted_by_type(imgs=imgs, inpaint_type=it).numpy()
+    trig = bd.get_trigger(type="BOX_14", channel=3, image_size=32, vmin=-1.0, vmax=1.0)
+    setattr(dl, "_DatasetLoader__trigger", trig)
+    setattr(dl, "_DatasetLoader__vmin", -1.0)
+    imgs = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    misc["poisoned/imgs"] = imgs.numpy()
+    misc["poisoned/out"] = dl.get_poisoned(imgs).numpy()
+    x = torch.rand(2, 3, 8, 8, generator=g) * 255
+    misc["normalize/x"] = x.numpy()
+    misc["normalize/t_0_255_to_m1_1"] = ref_util.normalize(x, 0, 255, -1, 1).numpy()
+    misc["normalize/t_auto_to_0_1"] = ref_util.normalize(x).numpy()
+    misc["normalize/t_0_1_to_m1_1"] = ref_util.normalize(x / 255, 0, 1, -1, 1).numpy()
+    misc["normalize/np_auto_to_m1_1"] = ref_util.normalize(x.numpy(), None, None, -1, 1)
+    misc["normalize/np_0_255_keepmax"] = ref_util.normalize(x.numpy(), 0, 255, 0, None)
+    np.savez_compressed(os.path.join(OUT, "inpaint_normalize.npz"), **misc)
+    print("wrote", len(tables), len(batch), len(boxes), len(misc), "arrays")
 
 
 if __name__ == "__main__":

@@ -129,3 +129,34 @@ def test_poison_rule():
     assert bool((pv == 0).all()) and bool((tg == x).all())
     pv, tg = B.poison_sample(x, False, trig, tgt, -1)
     assert bool((pv[:, 16:30, 16:30] == 0).all()) and bool((pv[:, :16] == x[:, :16]).all()) and bool((tg == tgt).all())
+
+
+def test_inpaint_poison_blend_and_normalize_match_reference_fixtures():
+    """Reference-generated (tests/golden/make_golden.py): DatasetLoader.get_inpainted_by_type / get_poisoned (dataset.py:540-579)
+    and util.normalize (util.py:119-147) -- the oracle AND the product reproduce them bit for bit."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import backdoor_ref as BR
+    from villandiffusion_amd import dataset as PD
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "inpaint_normalize.npz"))
+    dsl = PD.DatasetLoader("SYNTHETIC-CIFAR10", root=os.path.dirname(os.path.dirname(__file__)), device="cpu",
+                           images=PD.synthetic_images(n=4))
+    dsl.set_poison("BOX_14", "CORNER", poison_rate=0.5)
+    for S in (32, 50):
+        imgs = torch.from_numpy(d[f"inpaint/S{S}/imgs"])
+        for it in ("INPAINT_BOX", "INPAINT_LINE"):
+            want = torch.from_numpy(d[f"inpaint/S{S}/{it}"])
+            m = BR.inpaint_mask(S, it)
+            assert torch.equal(m * imgs + (1 - m) * torch.full_like(imgs, float(imgs.min())), want), (S, it)       # oracle
+            assert torch.equal(dsl.get_inpainted_by_type(imgs, it), want), (S, it)                                  # product
+    imgs = torch.from_numpy(d["poisoned/imgs"])
+    assert torch.equal(dsl.get_poisoned(imgs), torch.from_numpy(d["poisoned/out"]))
+    x = torch.from_numpy(d["normalize/x"])
+    for fn in (PD.normalize,):
+        assert torch.equal(fn(x, 0, 255, -1, 1), torch.from_numpy(d["normalize/t_0_255_to_m1_1"]))
+        assert torch.equal(fn(x), torch.from_numpy(d["normalize/t_auto_to_0_1"]))
+        assert torch.equal(fn(x / 255, 0, 1, -1, 1), torch.from_numpy(d["normalize/t_0_1_to_m1_1"]))
+        assert np.array_equal(fn(x.numpy(), None, None, -1, 1), d["normalize/np_auto_to_m1_1"])
+        assert np.array_equal(fn(x.numpy(), 0, 255, 0, None), d["normalize/np_0_255_keepmax"])
+    assert torch.equal(BR.normalize(x, 0, 255, -1, 1), torch.from_numpy(d["normalize/t_0_255_to_m1_1"]))
