@@ -160,6 +160,17 @@ def main():
     misc["normalize/np_auto_to_m1_1"] = ref_util.normalize(x.numpy(), None, None, -1, 1)
     misc["normalize/np_0_255_keepmax"] = ref_util.normalize(x.numpy(), 0, 255, 0, None)
     np.savez_compressed(os.path.join(OUT, "inpaint_normalize.npz"), **misc)
+
+    # API-surface constants: every upper-case str / number class attribute of the three drop-in classes
+    import json
+    import model as ref_model
+
+    def consts(cls):
+        return {k: v for k, v in vars(cls).items() if k.isupper() and isinstance(v, (str, int, float, bool))}
+
+    api = {"DiffuserModelSched": consts(ref_model.DiffuserModelSched), "Backdoor": consts(Backdoor), "DatasetLoader": consts(DL)}
+    with open(os.path.join(OUT, "api_constants.json"), "w") as f:
+        json.dump(api, f, indent=1, sort_keys=True)
     print("wrote", len(tables), len(batch), len(boxes), len(misc), "arrays")
 
 

@@ -160,3 +160,18 @@ def test_inpaint_poison_blend_and_normalize_match_reference_fixtures():
         assert np.array_equal(fn(x.numpy(), None, None, -1, 1), d["normalize/np_auto_to_m1_1"])
         assert np.array_equal(fn(x.numpy(), 0, 255, 0, None), d["normalize/np_0_255_keepmax"])
     assert torch.equal(BR.normalize(x, 0, 255, -1, 1), torch.from_numpy(d["normalize/t_0_255_to_m1_1"]))
+
+
+def test_api_constants_match_the_reference():
+    """Drop-in surface: every upper-case class constant of the reference's DiffuserModelSched / Backdoor /
+    DatasetLoader (dumped by tests/golden/make_golden.py from the imported reference) exists here with the same value."""
+    import json
+    import os
+    from dataset import Backdoor, DatasetLoader
+    from model import DiffuserModelSched
+    with open(os.path.join(os.path.dirname(__file__), "golden", "api_constants.json")) as f:
+        api = json.load(f)
+    assert len(api["DiffuserModelSched"]) >= 40 and len(api["Backdoor"]) >= 30 and len(api["DatasetLoader"]) >= 20
+    for name, cls in (("DiffuserModelSched", DiffuserModelSched), ("Backdoor", Backdoor), ("DatasetLoader", DatasetLoader)):
+        for k, v in api[name].items():
+            assert getattr(cls, k, "<missing>") == v, (name, k, v, getattr(cls, k, "<missing>"))
