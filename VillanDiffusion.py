@@ -43,16 +43,26 @@ def parse_args(argv: Optional[List[str]] = None) -> argparse.Namespace:
     a = p.add_argument
     a("--project", "-pj", type=str); a("--mode", "-m", type=str, required=True,
                                        choices=[MODE_TRAIN, MODE_RESUME, MODE_SAMPLING, MODE_MEASURE, MODE_TRAIN_MEASURE])
-    a("--task", "-t", type=str); a("--dataset", "-ds", type=str)
-    a("--sched", "-sc", type=str); a("--ddim_eta", "-det", type=float); a("--infer_steps", "-is", type=int)
-    a("--infer_start", "-ist", type=int); a("--inpaint_mul", "-im", type=float)
+    # option strings, types and choices as the reference declares them (VillanDiffusion.py:77-111; pinned by
+    # tests/golden/cli_flags.json); --dataset additionally accepts the synthetic stand-ins of this build
+    a("--task", "-t", type=str, choices=[TASK_GENERATE, TASK_UNPOISONED_DENOISE, TASK_POISONED_DENOISE, TASK_UNPOISONED_INPAINT_BOX,
+                                         TASK_POISONED_INPAINT_BOX, TASK_UNPOISONED_INPAINT_LINE, TASK_POISONED_INPAINT_LINE])
+    a("--dataset", "-ds", type=str, choices=["MNIST", "CIFAR10", "CELEBA", "CELEBA-HQ", "CELEBA-HQ-LATENT_PR05", "CELEBA-HQ-LATENT",
+                                             "SYNTHETIC-CIFAR10", "SYNTHETIC-CELEBA-HQ"])
+    a("--sched", "-sc", type=str, choices=["DDPM-SCHED", "DDIM-SCHED", "DPM_SOLVER_PP_O1-SCHED", "DPM_SOLVER_O1-SCHED",
+                                           "DPM_SOLVER_PP_O2-SCHED", "DPM_SOLVER_O2-SCHED", "DPM_SOLVER_PP_O3-SCHED", "DPM_SOLVER_O3-SCHED",
+                                           "UNIPC-SCHED", "PNDM-SCHED", "DEIS-SCHED", "HEUN-SCHED", "LMSD-SCHED", "SCORE-SDE-VE-SCHED",
+                                           "EDM-VE-SDE-SCHED", "EDM-VE-ODE-SCHED"])
+    a("--ddim_eta", "-det", type=float); a("--infer_steps", "-is", type=int)
+    a("--infer_start", "-ist", type=float); a("--inpaint_mul", "-im", type=float)
     a("--batch", "-b", type=int); a("--eval_max_batch", "-eb", type=int); a("--epoch", "-e", type=int)
     a("--learning_rate", "-lr", type=float); a("--clean_rate", "-cr", type=float); a("--poison_rate", "-pr", type=float)
     a("--ext_poison_rate", "-epr", type=float); a("--trigger", "-tr", type=str); a("--target", "-ta", type=str)
-    a("--dataset_load_mode", "-dlm", type=str); a("--solver_type", "-solt", type=str); a("--sde_type", "-sdet", type=str)
+    a("--dataset_load_mode", "-dlm", type=str, choices=["FIXED", "FLEX", "EXTEND", "NONE"])
+    a("--solver_type", "-solt", type=str, choices=["sde", "ode"]); a("--sde_type", "-sdet", type=str, choices=["SDE-VP", "SDE-VE", "SDE-LDM"])
     a("--psi", "-ps", type=float); a("--ve_scale", "-ves", type=float); a("--vp_scale", "-vps", type=float)
     a("--gpu", "-g", type=str); a("--ckpt", "-c", type=str); a("--overwrite", "-o", action="store_true")
-    a("--R_trigger_only", "-rto", action="store_true"); a("--postfix", "-p", type=str); a("--fclip", "-fc", type=str, choices=["w", "o"])
+    a("--R_trigger_only", "-trigonly", action="store_true"); a("--postfix", "-p", type=str); a("--fclip", "-fc", type=str, choices=["w", "o"])
     a("--save_image_epochs", "-sie", type=int); a("--save_model_epochs", "-sme", type=int)
     a("--is_save_all_model_epochs", "-isame", action="store_true"); a("--sample_ep", "-se", type=int); a("--result", "-res", type=str)
     return p.parse_args(argv)
@@ -111,6 +121,7 @@ def setup(args: argparse.Namespace) -> TrainingConfig:
                 raise NotImplementedError(f"Argument: {k}={v} isn't supported in mode: {mode}")
             setattr(cfg, k, v)
     cfg.mode = mode
+    cfg.infer_start = int(cfg.infer_start)                            # declared float in the reference, used as an index
     cfg.clip = cfg.fclip == "w"                                        # :252-258
     cfg.mixed_precision = "no"                                         # fp32 everywhere (reference: fp16 autocast for VP/LDM)
     small = cfg.dataset in ("CIFAR10", "MNIST", "SYNTHETIC-CIFAR10", "CELEBA-HQ-LATENT")

@@ -171,6 +171,51 @@ def main():
     api = {"DiffuserModelSched": consts(ref_model.DiffuserModelSched), "Backdoor": consts(Backdoor), "DatasetLoader": consts(DL)}
     with open(os.path.join(OUT, "api_constants.json"), "w") as f:
         json.dump(api, f, indent=1, sort_keys=True)
+
+    # CLI surface of the reference driver (VillanDiffusion.py:77-111): its module is imported with every missing third-party
+    # module stubbed, parse_args() is intercepted at ArgumentParser.parse_args and the declared options are dumped
+    import argparse
+    import builtins
+
+    real_import = builtins.__import__
+
+    def lenient_import(name, globals=None, locals=None, fromlist=(), level=0):
+        try:
+            return real_import(name, globals, locals, fromlist, level)
+        except ModuleNotFoundError:
+            parts = name.split(".")
+            for i in range(1, len(parts) + 1):
+                sys.modules.setdefault(".".join(parts[:i]), MagicMock())
+            return sys.modules[name] if fromlist else sys.modules[parts[0]]
+
+    class _Stop(Exception):
+        pass
+
+    captured = {}
+
+    def capture(self, *a, **k):
+        captured["parser"] = self
+        raise _Stop()
+
+    builtins.__import__ = lenient_import
+    orig_parse = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = capture
+    try:
+        try:
+            import VillanDiffusion  # noqa: F401   (the reference runs setup() -> parse_args() at import time, :323)
+        except _Stop:
+            pass
+    finally:
+        builtins.__import__ = real_import
+        argparse.ArgumentParser.parse_args = orig_parse
+    flags = []
+    for a in captured["parser"]._actions:
+        if a.option_strings and a.dest != "help":
+            flags.append({"dest": a.dest, "opts": sorted(a.option_strings), "type": getattr(a.type, "__name__", None),
+                          "choices": list(a.choices) if a.choices else None, "required": bool(a.required),
+                          "store_true": isinstance(a, argparse._StoreTrueAction)})
+    with open(os.path.join(OUT, "cli_flags.json"), "w") as f:
+        json.dump(sorted(flags, key=lambda d: d["dest"]), f, indent=1)
     print("wrote", len(tables), len(batch), len(boxes), len(misc), "arrays")
 
 

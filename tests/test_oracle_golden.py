@@ -175,3 +175,43 @@ def test_api_constants_match_the_reference():
     for name, cls in (("DiffuserModelSched", DiffuserModelSched), ("Backdoor", Backdoor), ("DatasetLoader", DatasetLoader)):
         for k, v in api[name].items():
             assert getattr(cls, k, "<missing>") == v, (name, k, v, getattr(cls, k, "<missing>"))
+
+
+def test_cli_flags_match_the_reference_parser():
+    """tests/golden/cli_flags.json = the options the reference's parse_args() declares (dumped by make_golden.py from the imported
+    driver).  Same dest, option strings, type, required / store_true; choices identical except --dataset, where the reference's
+    list must be a subset (the synthetic stand-ins are additions)."""
+    import argparse
+    import json
+    import os
+    import VillanDiffusion as V
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cli_flags.json")) as f:
+        ref = json.load(f)
+    captured = {}
+
+    class _Stop(Exception):
+        pass
+
+    def cap(self, *a, **k):
+        captured["p"] = self
+        raise _Stop()
+
+    orig = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = cap
+    try:
+        with pytest.raises(_Stop):
+            V.parse_args([])
+    finally:
+        argparse.ArgumentParser.parse_args = orig
+    mine = {a.dest: a for a in captured["p"]._actions if a.option_strings and a.dest != "help"}
+    assert len(ref) == 35
+    for r in ref:
+        a = mine[r["dest"]]
+        assert sorted(a.option_strings) == r["opts"], r["dest"]
+        assert getattr(a.type, "__name__", None) == r["type"], r["dest"]
+        assert bool(a.required) == r["required"] and isinstance(a, argparse._StoreTrueAction) == r["store_true"], r["dest"]
+        ch = list(a.choices) if a.choices else None
+        if r["dest"] == "dataset":
+            assert set(r["choices"]) <= set(ch)
+        else:
+            assert ch == r["choices"], r["dest"]
