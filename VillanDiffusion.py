@@ -23,19 +23,20 @@ TASK_GENERATE = "generate"
 TASK_UNPOISONED_DENOISE, TASK_POISONED_DENOISE = "unpoisoned_denoise", "poisoned_denoise"
 TASK_UNPOISONED_INPAINT_BOX, TASK_POISONED_INPAINT_BOX = "unpoisoned_inpaint_box", "poisoned_inpaint_box"
 TASK_UNPOISONED_INPAINT_LINE, TASK_POISONED_INPAINT_LINE = "unpoisoned_inpaint_line", "poisoned_inpaint_line"
-DEFAULT = dict(project="Default", batch=512, eval_max_batch=256, epoch=50, learning_rate=None, clean_rate=1.0, poison_rate=0.007,
+# the reference's DEFAULT_* constants (VillanDiffusion.py:20-60), pinned by tests/golden/driver_defaults.json
+DEFAULT = dict(project="Default", batch=512, eval_max_batch=1500, epoch=50, learning_rate=None, clean_rate=1.0, poison_rate=0.007,
                ext_poison_rate=0.0, trigger="SM_BOX", target="CORNER", dataset_load_mode="FIXED", solver_type="sde", sde_type="SDE-VP",
-               psi=1.0, ve_scale=1.0, vp_scale=1.0, gpu="0", ckpt="DEFAULT", overwrite=False, postfix="", fclip="o", save_image_epochs=20,
-               save_model_epochs=5, is_save_all_model_epochs=False, sample_ep=None, result="exp", dataset="CIFAR10", sched=None,
+               psi=1, ve_scale=1.0, vp_scale=1.0, gpu="0", ckpt=None, overwrite=False, postfix="", fclip="w", save_image_epochs=5,
+               save_model_epochs=5, is_save_all_model_epochs=False, sample_ep=None, result=".", dataset="CIFAR10", sched=None,
                ddim_eta=None, infer_steps=1000, infer_start=0, inpaint_mul=1.0, task=TASK_GENERATE, R_trigger_only=False)
 # per-mode whitelists of options that may be overridden from the command line (reference :17-72)
 NOT_MODE_TRAIN = {"sample_ep"}
 NOT_MODE_TRAIN_MEASURE = {"sample_ep"}
-MODE_RESUME_OPTS = {"project", "mode", "gpu", "ckpt"}
+MODE_RESUME_OPTS = {"project", "task", "sched", "ddim_eta", "infer_steps", "mode", "gpu", "ckpt"}
 MODE_SAMPLING_OPTS = {"project", "mode", "eval_max_batch", "gpu", "fclip", "ckpt", "sample_ep", "sched", "ddim_eta", "infer_steps",
                       "infer_start", "inpaint_mul", "task"}
 MODE_MEASURE_OPTS = MODE_SAMPLING_OPTS
-IGNORE_ARGS = {"overwrite", "R_trigger_only"}
+IGNORE_ARGS = {"overwrite", "is_save_all_model_epochs", "R_trigger_only"}
 
 
 def parse_args(argv: Optional[List[str]] = None) -> argparse.Namespace:
@@ -74,13 +75,13 @@ class TrainingConfig:
     eval_max_batch: int = DEFAULT["eval_max_batch"]; learning_rate: Optional[float] = None
     clean_rate: float = 1.0; poison_rate: float = DEFAULT["poison_rate"]; ext_poison_rate: float = 0.0
     trigger: str = DEFAULT["trigger"]; target: str = DEFAULT["target"]; dataset_load_mode: str = "FIXED"
-    solver_type: str = "sde"; sde_type: str = "SDE-VP"; psi: float = 1.0; ve_scale: float = 1.0; vp_scale: float = 1.0
-    gpu: str = "0"; ckpt: str = "DEFAULT"; overwrite: bool = False; postfix: str = ""; fclip: str = "o"
-    save_image_epochs: int = 20; save_model_epochs: int = 5; is_save_all_model_epochs: bool = False
-    sample_ep: Optional[int] = None; result: str = "exp"; dataset: str = "CIFAR10"; sched: Optional[str] = None
+    solver_type: str = "sde"; sde_type: str = "SDE-VP"; psi: float = 1; ve_scale: float = 1.0; vp_scale: float = 1.0
+    gpu: str = "0"; ckpt: Optional[str] = None; overwrite: bool = False; postfix: str = ""; fclip: str = DEFAULT["fclip"]
+    save_image_epochs: int = DEFAULT["save_image_epochs"]; save_model_epochs: int = 5; is_save_all_model_epochs: bool = False
+    sample_ep: Optional[int] = None; result: str = DEFAULT["result"]; dataset: str = "CIFAR10"; sched: Optional[str] = None
     ddim_eta: Optional[float] = None; infer_steps: int = 1000; infer_start: int = 0; inpaint_mul: float = 1.0
     task: str = TASK_GENERATE; R_trigger_only: bool = False; mode: str = MODE_TRAIN
-    eval_sample_n: int = 16; measure_sample_n: int = 16; measure_inpaint_sample_n: int = 1024; batch_32: int = 128; batch_256: int = 64
+    eval_sample_n: int = 16; measure_sample_n: int = 10000; measure_inpaint_sample_n: int = 1024; batch_32: int = 128; batch_256: int = 64
     gradient_accumulation_steps: int = 1; learning_rate_32_scratch: float = 2e-4; learning_rate_256_scratch: float = 2e-5
     lr_warmup_steps: int = 500; mixed_precision: str = "no"; seed: int = 0; dataset_path: str = "datasets"
     ckpt_dir: str = "ckpt"; data_ckpt_dir: str = "data.ckpt"; ep_model_dir: str = "epochs"
@@ -99,6 +100,8 @@ def naming_fn(c: TrainingConfig) -> str:
 def setup(args: argparse.Namespace) -> TrainingConfig:
     """Config overlay of reference :200-321."""
     cfg = TrainingConfig()
+    for k, v in json.loads(os.environ.get("VILLAN_CFG_OVERRIDES", "{}")).items():     # test hook: shrink e.g. measure_sample_n (10000)
+        setattr(cfg, k, v)
     given = {k: v for k, v in vars(args).items() if v is not None and not (isinstance(v, bool) and v is False)}
     mode = args.mode
     if mode in (MODE_RESUME, MODE_SAMPLING, MODE_MEASURE):
@@ -126,8 +129,8 @@ def setup(args: argparse.Namespace) -> TrainingConfig:
     cfg.mixed_precision = "no"                                         # fp32 everywhere (reference: fp16 autocast for VP/LDM)
     small = cfg.dataset in ("CIFAR10", "MNIST", "SYNTHETIC-CIFAR10", "CELEBA-HQ-LATENT")
     bs = cfg.batch_32 if small else cfg.batch_256                      # :266-287
-    if cfg.learning_rate is None:
-        scratch = "DEFAULT" in cfg.ckpt
+    if cfg.learning_rate is None:                                      # :269-280: the from-scratch rate applies only when --ckpt is omitted
+        scratch = cfg.ckpt is None
         cfg.learning_rate = (2e-4 if small else 6e-5) if not scratch else (cfg.learning_rate_32_scratch if small else cfg.learning_rate_256_scratch)
     if mode in (MODE_TRAIN, MODE_TRAIN_MEASURE):
         if cfg.batch > bs:
@@ -341,6 +344,13 @@ def checkpoint(cfg, trainer, pipeline, epoch, step):
     torch.save(trainer.state_dict(), os.path.join(cfg.ckpt_path, "trainer.pt"))
     torch.save({"epoch": epoch, "step": step}, cfg.data_ckpt_path)
     pipeline.save_pretrained(cfg.output_dir)
+    if cfg.is_save_all_model_epochs:                                   # reference :1110-1114: a copy per checkpointed epoch
+        pipeline.save_pretrained(get_ep_model_path(cfg, cfg.output_dir, epoch))
+
+
+def get_ep_model_path(cfg, dir: str, epoch: int) -> str:
+    """reference :1099-1100."""
+    return os.path.join(dir, cfg.ep_model_dir, f"ep{epoch}")
 
 
 # batch key regressed against (reference VillanDiffusion.py:1159 'target'); rm_backdoor_VillanDiffusion.py sets 'image'
@@ -353,8 +363,8 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
     from model import DiffuserModelSched
     from villandiffusion_amd.trainer import Trainer
     model, vae, noise_sched, get_pipeline = DiffuserModelSched.get_model_sched(
-        image_size=dsl.image_size, channels=dsl.channel, ckpt=cfg.ckpt, sde_type=cfg.sde_type, clip_sample=cfg.clip,
-        noise_sched_type=cfg.sched)
+        image_size=dsl.image_size, channels=dsl.channel, ckpt=cfg.ckpt if cfg.ckpt is not None else DiffuserModelSched.MODEL_DEFAULT,
+        sde_type=cfg.sde_type, clip_sample=cfg.clip, noise_sched_type=cfg.sched)
     if world > 1:                                                      # identical replicas
         torch.distributed.broadcast(model.flat_param, src=0)
     loss_fn = LossFn(noise_sched=noise_sched, sde_type=cfg.sde_type, loss_type="l2", psi=cfg.psi, solver_type=cfg.solver_type,
@@ -398,7 +408,10 @@ def main(argv: Optional[List[str]] = None):
         pipeline = train_loop(cfg, dsl, rank, world)
     else:
         from model import DiffuserModelSched
-        model, vae, noise_sched, get_pipeline = DiffuserModelSched.get_pretrained(ckpt=cfg.output_dir, clip_sample=cfg.clip,
+        src = cfg.output_dir                                           # reference :424-431: --sample_ep N loads epochs/epN
+        if cfg.sample_ep is not None:
+            src = get_ep_model_path(cfg, cfg.output_dir, cfg.sample_ep)
+        model, vae, noise_sched, get_pipeline = DiffuserModelSched.get_pretrained(ckpt=src, clip_sample=cfg.clip,
                                                                                   noise_sched_type=cfg.sched, sde_type=cfg.sde_type)
         pipeline = get_pipeline(None, model, vae, noise_sched)
     if cfg.mode == MODE_SAMPLING and rank == 0:

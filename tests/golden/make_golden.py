@@ -195,6 +195,14 @@ def main():
 
     def capture(self, *a, **k):
         captured["parser"] = self
+        mod = sys.modules.get("VillanDiffusion")          # half-imported reference driver: constants and TrainingConfig exist already
+        import dataclasses
+        captured["module_consts"] = {k: v for k, v in vars(mod).items()
+                                     if k.isupper() and isinstance(v, (str, int, float, bool, list, type(None)))}
+        tc = getattr(mod, "TrainingConfig", None)
+        if tc is not None and dataclasses.is_dataclass(tc):
+            captured["training_config"] = {f.name: f.default for f in dataclasses.fields(tc)
+                                           if isinstance(f.default, (str, int, float, bool, type(None)))}
         raise _Stop()
 
     builtins.__import__ = lenient_import
@@ -216,6 +224,9 @@ def main():
                           "store_true": isinstance(a, argparse._StoreTrueAction)})
     with open(os.path.join(OUT, "cli_flags.json"), "w") as f:
         json.dump(sorted(flags, key=lambda d: d["dest"]), f, indent=1)
+    with open(os.path.join(OUT, "driver_defaults.json"), "w") as f:
+        json.dump({"module_consts": captured.get("module_consts", {}), "training_config": captured.get("training_config", {})}, f,
+                  indent=1, sort_keys=True)
     print("wrote", len(tables), len(batch), len(boxes), len(misc), "arrays")
 
 

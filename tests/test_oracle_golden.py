@@ -215,3 +215,33 @@ def test_cli_flags_match_the_reference_parser():
             assert set(r["choices"]) <= set(ch)
         else:
             assert ch == r["choices"], r["dest"]
+
+
+def test_driver_defaults_match_the_reference():
+    """tests/golden/driver_defaults.json = DEFAULT_* constants, mode whitelists and TrainingConfig field defaults of the reference
+    driver (captured from its half-imported module by make_golden.py).  Fields this build does not have (hub upload) are skipped."""
+    import dataclasses
+    import json
+    import os
+    import VillanDiffusion as V
+    with open(os.path.join(os.path.dirname(__file__), "golden", "driver_defaults.json")) as f:
+        ref = json.load(f)
+    mine = {f.name: f.default for f in dataclasses.fields(V.TrainingConfig)}
+    skipped = {"hub_private_repo", "push_to_hub", "overwrite_output_dir"}
+    for k, v in ref["training_config"].items():
+        if k in skipped:
+            continue
+        assert k in mine and mine[k] == v, (k, mine.get(k), v)
+    mc = ref["module_consts"]
+    for k, v in mc.items():
+        if k.startswith("DEFAULT_"):
+            key = {"DEFAULT_EXTEND_POISON_RATE": "ext_poison_rate", "DEFAULT_SAMPLE_EPOCH": "sample_ep"}.get(k, k[len("DEFAULT_"):].lower())
+            if key in ("learning_rate_32", "learning_rate_256"):
+                continue
+            assert V.DEFAULT[key] == v, (k, V.DEFAULT.get(key), v)
+    assert set(mc["MODE_RESUME_OPTS"]) == V.MODE_RESUME_OPTS and set(mc["MODE_SAMPLING_OPTS"]) == V.MODE_SAMPLING_OPTS
+    assert set(mc["MODE_MEASURE_OPTS"]) == V.MODE_MEASURE_OPTS and set(mc["IGNORE_ARGS"]) == V.IGNORE_ARGS
+    assert set(mc["NOT_MODE_TRAIN_OPTS"]) == V.NOT_MODE_TRAIN and set(mc["NOT_MODE_TRAIN_MEASURE_OPTS"]) == V.NOT_MODE_TRAIN_MEASURE
+    for k in ("MODE_TRAIN", "MODE_RESUME", "MODE_SAMPLING", "MODE_MEASURE", "MODE_TRAIN_MEASURE", "TASK_GENERATE", "TASK_POISONED_DENOISE",
+              "TASK_UNPOISONED_INPAINT_LINE"):
+        assert getattr(V, k) == mc[k]

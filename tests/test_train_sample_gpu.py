@@ -167,24 +167,23 @@ def test_cli_train_and_sampling_end_to_end(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert os.path.exists(os.path.join(run, "samples", "final.png")) and os.path.exists(os.path.join(run, "sampling.json"))
     # measure (MSE / SSIM vs target -> score.json, reference key naming) and one inpaint task from the saved checkpoint
-    code_m = code.replace("V.TrainingConfig.eval_sample_n=4;", "V.TrainingConfig.eval_sample_n=4; V.TrainingConfig.measure_sample_n=6;")
+    env_m = dict(env, VILLAN_CFG_OVERRIDES=json.dumps({"measure_sample_n": 16, "measure_inpaint_sample_n": 6}))   # reference defaults: 10000 / 1024
     argv3 = ["--mode", "measure", "--ckpt", run, "--sched", "DDIM-SCHED", "--infer_steps", "4", "--eval_max_batch", "4"]
-    out = subprocess.run([sys.executable, "-c", code_m % (argv3,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", code % (argv3,)], cwd=ROOT, env=env_m, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     sc = json.load(open(os.path.join(run, "score.json")))
     assert set(sc) == {"FID_noclip_DDIM-SCHED-4_16", "MSE_noclip_DDIM-SCHED-4_16", "SSIM_noclip_DDIM-SCHED-4_16"}
     assert sc["FID_noclip_DDIM-SCHED-4_16"] is None and 0 <= sc["MSE_noclip_DDIM-SCHED-4_16"] <= 1 and -1 <= sc["SSIM_noclip_DDIM-SCHED-4_16"] <= 1
     assert len(os.listdir(os.path.join(run, "backdoor_noclip_DDIM-SCHED-4_16"))) == 16
     # the same for a denoise task: MSE / SSIM of the recovered images (reference measure_inpaints; LPIPS needs AlexNet weights)
-    code_i = code.replace("V.TrainingConfig.eval_sample_n=4;", "V.TrainingConfig.eval_sample_n=4; V.TrainingConfig.measure_inpaint_sample_n=6;")
     argv5 = ["--mode", "measure", "--ckpt", run, "--sched", "DDIM-SCHED", "--infer_steps", "10", "--infer_start", "6", "--eval_max_batch", "4",
              "--task", "poisoned_denoise"]
-    out = subprocess.run([sys.executable, "-c", code_i % (argv5,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", code % (argv5,)], cwd=ROOT, env=env_m, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     sc = json.load(open(os.path.join(run, "score.json")))
-    k = "MSE_noclip_DDIM-SCHED-10_1024_poisoned_denoise"          # key carries measure_inpaint_sample_n (dataclass default)
-    assert k in sc and 0 <= sc[k] <= 4 and "SSIM_noclip_DDIM-SCHED-10_1024_poisoned_denoise" in sc
-    assert sc["LPIPS_noclip_DDIM-SCHED-10_1024_poisoned_denoise"] is None
+    k = "MSE_noclip_DDIM-SCHED-10_6_poisoned_denoise"             # key carries measure_inpaint_sample_n
+    assert k in sc and 0 <= sc[k] <= 4 and "SSIM_noclip_DDIM-SCHED-10_6_poisoned_denoise" in sc
+    assert sc["LPIPS_noclip_DDIM-SCHED-10_6_poisoned_denoise"] is None
     argv4 = ["--mode", "sampling", "--ckpt", run, "--sched", "DDIM-SCHED", "--infer_steps", "10", "--infer_start", "6", "--task", "poisoned_inpaint_box"]
     out = subprocess.run([sys.executable, "-c", code % (argv4,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
