@@ -124,7 +124,6 @@ def setup(args: argparse.Namespace) -> TrainingConfig:
                 raise NotImplementedError(f"Argument: {k}={v} isn't supported in mode: {mode}")
             setattr(cfg, k, v)
     cfg.mode = mode
-    cfg.infer_start = int(cfg.infer_start)                            # declared float in the reference, used as an index
     cfg.clip = cfg.fclip == "w"                                        # :252-258
     cfg.mixed_precision = "no"                                         # fp32 everywhere (reference: fp16 autocast for VP/LDM)
     small = cfg.dataset in ("CIFAR10", "MNIST", "SYNTHETIC-CIFAR10", "CELEBA-HQ-LATENT")
@@ -202,7 +201,7 @@ def sampling(cfg: TrainingConfig, file_name, pipeline, dsl):
         return _special_sampling(cfg, tag, pipeline, dsl, noise, kw)
     for name, init in (("samples", noise), ("backdoor_samples", noise + pipeline.encode(dsl.trigger.unsqueeze(0)).to(noise.device))):
         res = pipeline(batch_size=n, generator=torch.Generator().manual_seed(cfg.seed), init=init, output_type=None,
-                       num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=True, **kw)
+                       num_inference_steps=cfg.infer_steps, start_from=int(cfg.infer_start), save_every_step=True, **kw)
         make_grid(res.images, os.path.join(cfg.output_dir, name, f"{tag}.png"))
         make_grid(res.movie[0], os.path.join(cfg.output_dir, name, f"{tag}_sample_t0.png"))
 
@@ -229,7 +228,7 @@ def _special_sampling(cfg, tag, pipeline, dsl, noise, kw):
         raise NotImplementedError(f"Sampling task: {cfg.task} isn't implemented")
     folder, make_init = table[cfg.task]
     res = pipeline(batch_size=n, generator=torch.Generator().manual_seed(cfg.seed), init=make_init(), output_type=None,
-                   num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=True, **kw)
+                   num_inference_steps=cfg.infer_steps, start_from=int(cfg.infer_start), save_every_step=True, **kw)
     make_grid(res.images, os.path.join(cfg.output_dir, folder + ext, f"{tag}.png"))
     make_grid(res.movie[0], os.path.join(cfg.output_dir, folder + ext, f"{tag}_sample_t0.png"))
 
@@ -281,7 +280,7 @@ def measure_inpaints(cfg, pipeline, dsl):
     for s in range(0, n, cfg.eval_max_batch):
         init = corrupt[s:s + cfg.eval_max_batch] * cfg.inpaint_mul
         out = pipeline(batch_size=len(init), generator=torch.Generator().manual_seed(cfg.seed), init=init, output_type=None,
-                       num_inference_steps=cfg.infer_steps, start_from=cfg.infer_start, save_every_step=False)
+                       num_inference_steps=cfg.infer_steps, start_from=int(cfg.infer_start), save_every_step=False)
         rec.append(out.images)
     recover = torch.from_numpy(np.vstack(rec)).permute(0, 3, 1, 2).float()
     return {"LPIPS": None, "MSE": mse_batch(recover, target_imgs.float()), "SSIM": ssim_batch(recover, target_imgs.float())}

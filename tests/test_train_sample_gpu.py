@@ -187,7 +187,7 @@ def test_cli_train_and_sampling_end_to_end(tmp_path):
     argv4 = ["--mode", "sampling", "--ckpt", run, "--sched", "DDIM-SCHED", "--infer_steps", "10", "--infer_start", "6", "--task", "poisoned_inpaint_box"]
     out = subprocess.run([sys.executable, "-c", code % (argv4,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert os.path.exists(os.path.join(run, "inpaint_box_poisoned_samples_DDIM-SCHED_10_st6_m1.0", "final.png"))
+    assert os.path.exists(os.path.join(run, "inpaint_box_poisoned_samples_DDIM-SCHED_10_st6.0_m1.0", "final.png"))
 
 
 def test_ve_loss_and_score_sde_sampler_match_oracle(nets):
