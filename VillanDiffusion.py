@@ -91,8 +91,7 @@ class TrainingConfig:
 
 def naming_fn(c: TrainingConfig) -> str:
     """reference :186-190."""
-    add_on = "" if c.sched is None else f"_{c.sched}"
-    add_on += f"_{c.postfix}" if c.postfix else ""
+    add_on = f"_{c.postfix}" if c.postfix else ""                    # (the sampler is NOT part of the name: pinned by driver_defaults.json)
     return (f"res_{c.ckpt}_{c.dataset}_ep{c.epoch}_{c.solver_type}_c{c.clean_rate}_p{c.poison_rate}_epr{c.ext_poison_rate}_"
             f"{c.trigger}-{c.target}_psi{c.psi}_lr{c.learning_rate}_vp{c.vp_scale}_ve{c.ve_scale}{add_on}")
 

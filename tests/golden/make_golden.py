@@ -203,6 +203,16 @@ def main():
         if tc is not None and dataclasses.is_dataclass(tc):
             captured["training_config"] = {f.name: f.default for f in dataclasses.fields(tc)
                                            if isinstance(f.default, (str, int, float, bool, type(None)))}
+            names = []                                 # result-directory names (naming_fn, :186-190) for a few configurations
+            for kw in ({"dataset": "CIFAR10"}, {"ckpt": "DDPM-CIFAR10-32", "dataset": "CIFAR10", "epoch": 50, "poison_rate": 0.1, "trigger": "BOX_14",
+                            "target": "HAT", "learning_rate": 0.0002, "sched": "DDIM-SCHED", "postfix": "new"},
+                       {"ckpt": "NCSNPP-CIFAR10-32", "dataset": "CELEBA-HQ", "sde_type": "SDE-VE", "psi": 0.0, "solver_type": "ode", "ve_scale": 2.0,
+                        "ext_poison_rate": 0.5, "learning_rate": 2e-05}):
+                c = tc()
+                for k, v in kw.items():
+                    setattr(c, k, v)
+                names.append({"overrides": kw, "name": mod.naming_fn(config=c)})
+            captured["naming"] = names
         raise _Stop()
 
     builtins.__import__ = lenient_import
@@ -225,8 +235,8 @@ def main():
     with open(os.path.join(OUT, "cli_flags.json"), "w") as f:
         json.dump(sorted(flags, key=lambda d: d["dest"]), f, indent=1)
     with open(os.path.join(OUT, "driver_defaults.json"), "w") as f:
-        json.dump({"module_consts": captured.get("module_consts", {}), "training_config": captured.get("training_config", {})}, f,
-                  indent=1, sort_keys=True)
+        json.dump({"module_consts": captured.get("module_consts", {}), "training_config": captured.get("training_config", {}),
+                   "naming": captured.get("naming", [])}, f, indent=1, sort_keys=True)
     print("wrote", len(tables), len(batch), len(boxes), len(misc), "arrays")
 
 

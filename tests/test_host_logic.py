@@ -155,7 +155,7 @@ def test_cli_config_overlay(tmp_path):
     cfg = V.setup(V.parse_args(argv))
     assert cfg.gradient_accumulation_steps == 32 and cfg.learning_rate == 2e-4 and cfg.clip is False
     # `psi1`: DEFAULT_PSI is the int 1 in the reference (":45"), so the directory name of BASELINE config #1 has no ".0"
-    assert os.path.basename(cfg.output_dir) == ("res_DDPM-CIFAR10-32_CIFAR10_ep1_sde_c1.0_p0.1_epr0.0_BOX_14-HAT_psi1_lr0.0002_vp1.0_ve1.0_DDPM-SCHED")
+    assert os.path.basename(cfg.output_dir) == ("res_DDPM-CIFAR10-32_CIFAR10_ep1_sde_c1.0_p0.1_epr0.0_BOX_14-HAT_psi1_lr0.0002_vp1.0_ve1.0")
     assert json.load(open(os.path.join(cfg.output_dir, "args.json")))["trigger"] == "BOX_14"
     assert os.path.exists(os.path.join(cfg.output_dir, "config.json"))
     with pytest.raises(ValueError):                    # existing directory without -o

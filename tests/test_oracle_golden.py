@@ -245,3 +245,9 @@ def test_driver_defaults_match_the_reference():
     for k in ("MODE_TRAIN", "MODE_RESUME", "MODE_SAMPLING", "MODE_MEASURE", "MODE_TRAIN_MEASURE", "TASK_GENERATE", "TASK_POISONED_DENOISE",
               "TASK_UNPOISONED_INPAINT_LINE"):
         assert getattr(V, k) == mc[k]
+    assert len(ref["naming"]) == 3
+    for e in ref["naming"]:                              # result-directory names of the reference's naming_fn (:186-190)
+        c = V.TrainingConfig()
+        for k, v in e["overrides"].items():
+            setattr(c, k, v)
+        assert V.naming_fn(c) == e["name"]
