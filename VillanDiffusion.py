@@ -125,30 +125,37 @@ def setup(args: argparse.Namespace) -> TrainingConfig:
     cfg.mode = mode
     cfg.clip = cfg.fclip == "w"                                        # :252-258
     cfg.mixed_precision = "no"                                         # fp32 everywhere (reference: fp16 autocast for VP/LDM)
-    small = cfg.dataset in ("CIFAR10", "MNIST", "SYNTHETIC-CIFAR10", "CELEBA-HQ-LATENT")
-    bs = cfg.batch_32 if small else cfg.batch_256                      # :266-287
-    if cfg.learning_rate is None:                                      # :269-280: the from-scratch rate applies only when --ckpt is omitted
+    cfg.device_ids = [int(i) for i in range(len(cfg.gpu.split(",")))]  # :245
+    if isinstance(cfg.sample_ep, int) and cfg.sample_ep < 0:           # :248-251
+        cfg.sample_ep = None
+    small = cfg.dataset in ("CIFAR10", "MNIST", "SYNTHETIC-CIFAR10", "CELEBA-HQ-LATENT_PR05", "CELEBA-HQ-LATENT")
+    big = cfg.dataset in ("CELEBA", "CELEBA-HQ", "LSUN-CHURCH", "LSUN-BEDROOM", "SYNTHETIC-CELEBA-HQ")
+    if not (small or big):
+        raise NotImplementedError()
+    bs = cfg.batch_32 if small else cfg.batch_256                      # :266-287 (every mode, like the reference)
+    if cfg.learning_rate is None:                                      # the from-scratch rate applies only when --ckpt is omitted
         scratch = cfg.ckpt is None
         cfg.learning_rate = (2e-4 if small else 6e-5) if not scratch else (cfg.learning_rate_32_scratch if small else cfg.learning_rate_256_scratch)
+    if bs % cfg.batch != 0:
+        raise ValueError(f"batch size {cfg.batch} should be divisible to {bs} for dataset {cfg.dataset}")
+    if bs < cfg.batch:
+        raise ValueError(f"batch size {cfg.batch} should be smaller or equal to {bs} for dataset {cfg.dataset}")
+    cfg.gradient_accumulation_steps = int(bs // cfg.batch)
     if mode in (MODE_TRAIN, MODE_TRAIN_MEASURE):
-        if cfg.batch > bs:
-            cfg.batch = bs
-        if bs % cfg.batch != 0:
-            raise ValueError(f"batch size {cfg.batch} should be divisible to {bs} for dataset {cfg.dataset}")
-        cfg.gradient_accumulation_steps = bs // cfg.batch
         cfg.output_dir = os.path.join(cfg.result, naming_fn(cfg))
         if os.path.isdir(cfg.output_dir) and not cfg.overwrite:
-            raise ValueError(f"Overwrite the exist experiment result at {cfg.output_dir}. Please use -o to overwrite")
+            raise ValueError(f"Output directory: {cfg.output_dir} has already been created, please set overwrite flag --overwrite or -o")
         os.makedirs(cfg.output_dir, exist_ok=True)
         with open(os.path.join(cfg.output_dir, "args.json"), "w") as f:
-            json.dump({k: v for k, v in vars(args).items()}, f, indent=4)
+            json.dump({k: v for k, v in vars(args).items()}, f, indent=2)
         with open(os.path.join(cfg.output_dir, "config.json"), "w") as f:
-            json.dump(asdict(cfg), f, indent=4)
-    else:
+            json.dump({k: v for k, v in vars(cfg).items() if k != "extra"}, f, indent=2)
+    elif mode in (MODE_SAMPLING, MODE_MEASURE):                        # :303-306 sampling.json / measure.json = the effective config
         with open(os.path.join(cfg.output_dir, f"{mode}.json"), "w") as f:
-            json.dump({k: v for k, v in vars(args).items()}, f, indent=4)
+            json.dump({k: v for k, v in vars(cfg).items() if k != "extra"}, f, indent=2)
     cfg.ckpt_path = os.path.join(cfg.output_dir, cfg.ckpt_dir)
     cfg.data_ckpt_path = os.path.join(cfg.output_dir, cfg.data_ckpt_dir)
+    os.makedirs(cfg.ckpt_path, exist_ok=True)                          # :312-315
     return cfg
 
 

@@ -226,6 +226,109 @@ def main():
     finally:
         builtins.__import__ = real_import
         argparse.ArgumentParser.parse_args = orig_parse
+    # --- the reference's setup() (config overlay, :200-321) and score-file keys (:724-778) on a handful of command lines.
+    # Second import of the driver: parse_args() now returns real namespaces, setup() runs for real in a temp result dir, and the
+    # script body is stopped at its first DatasetLoader(...) (by then every function of the module is defined).
+    import shutil
+    import tempfile
+    import copy
+    tmp = tempfile.mkdtemp(prefix="villan_golden_")
+    state = {"argv": None, "mod": None}
+
+    def parse_real(self, *a, **k):
+        return orig_parse(self, state["argv"])
+
+    def stop_dsl(self, *a, **k):
+        state["mod"] = sys.modules.get("VillanDiffusion")
+        raise _Stop()
+
+    train_argv = ["--project", "default", "--mode", "train", "--dataset", "CIFAR10", "--batch", "4", "--epoch", "1", "--poison_rate", "0.1",
+                  "--trigger", "BOX_14", "--target", "HAT", "--ckpt", "DDPM-CIFAR10-32", "--fclip", "o", "-o", "--gpu", "0",
+                  "--result", tmp, "--sched", "DDIM-SCHED"]
+    cases = [("train_cfg1", train_argv),
+             ("train_ve", ["--mode", "train", "--dataset", "CIFAR10", "--batch", "128", "--sde_type", "SDE-VE", "--psi", "0", "--solver_type", "ode",
+                           "--ve_scale", "2.0", "--result", tmp, "-o", "--postfix", "x"]),
+             ("train_256", ["--mode", "train+measure", "--dataset", "CELEBA-HQ", "--batch", "16", "--ckpt", "DDPM-CELEBA-HQ-256", "--result", tmp,
+                            "-o", "--learning_rate", "1e-5", "--R_trigger_only", "--dataset_load_mode", "EXTEND", "--ext_poison_rate", "0.3"])]
+    orig_init = ref_dataset.DatasetLoader.__init__
+    builtins.__import__ = lenient_import
+    argparse.ArgumentParser.parse_args = parse_real
+    ref_dataset.DatasetLoader.__init__ = stop_dsl
+    sys.modules.pop("VillanDiffusion", None)
+    for m in ("accelerate", "torchmetrics", "lpips", "fid_score"):     # installed-but-unusable here (accelerate probes wandb's spec) or absent
+        sys.modules[m] = MagicMock()
+    setup_out = []
+    keep = ("mode", "clip", "mixed_precision", "learning_rate", "batch", "gradient_accumulation_steps", "epoch", "poison_rate", "sde_type",
+            "psi", "solver_type", "ve_scale", "sched", "fclip", "R_trigger_only", "dataset_load_mode", "ext_poison_rate", "task",
+            "infer_steps", "infer_start", "eval_max_batch", "sample_ep", "ddim_eta", "ckpt", "dataset", "trigger", "target", "device_ids")
+
+    def rel(pth):
+        return None if pth is None else os.path.relpath(pth, tmp)
+
+    def record(tag, argv, cfg):
+        setup_out.append({"tag": tag, "argv": [("<RESULT>" if x == tmp else x.replace(tmp, "<RESULT>")) for x in argv],
+                          "config": {k: (v.replace(tmp, "<RESULT>") if isinstance(v, str) else v)
+                                     for k, v in ((k, getattr(cfg, k, "<absent>")) for k in keep)},
+                          "output_dir": rel(cfg.output_dir), "ckpt_path": rel(cfg.ckpt_path), "data_ckpt_path": rel(cfg.data_ckpt_path),
+                          "files": sorted(os.listdir(cfg.output_dir))})
+
+    try:
+        state["argv"] = train_argv
+        try:
+            import VillanDiffusion  # noqa: F401,F811
+        except _Stop:
+            pass
+        mod = state["mod"]
+        record("train_cfg1", train_argv, mod.config)
+        run_dir = mod.config.output_dir
+        for tag, argv in cases[1:]:
+            state["argv"] = argv
+            record(tag, argv, mod.setup())
+        for tag, extra in (("sampling", ["--mode", "sampling", "--sched", "UNIPC-SCHED", "--infer_steps", "20", "--eval_max_batch", "64"]),
+                           ("measure_inpaint", ["--mode", "measure", "--task", "poisoned_inpaint_box", "--infer_start", "10", "--inpaint_mul", "1.5",
+                                                "--fclip", "w", "--sample_ep", "3"]),
+                           ("resume", ["--mode", "resume"])):
+            argv = extra + ["--ckpt", run_dir]
+            state["argv"] = argv
+            record(tag, argv, mod.setup())
+        errors = []
+        for tag, argv in (("train_with_sample_ep", train_argv + ["--sample_ep", "2"]),
+                          ("sampling_with_epoch", ["--mode", "sampling", "--ckpt", run_dir, "--epoch", "3"]),
+                          ("batch_not_divisor", ["--mode", "train", "--dataset", "CIFAR10", "--batch", "48", "--result", tmp, "-o"]),
+                          ("batch_too_big", ["--mode", "train", "--dataset", "CIFAR10", "--batch", "256", "--result", tmp, "-o"]),
+                          ("exists_no_overwrite", [x for x in train_argv if x != "-o"])):
+            state["argv"] = argv
+            try:
+                mod.setup()
+                errors.append({"tag": tag, "error": None, "argv": [x.replace(tmp, "<RESULT>") for x in argv]})
+            except Exception as e:  # noqa: BLE001
+                errors.append({"tag": tag, "error": type(e).__name__, "argv": [x.replace(tmp, "<RESULT>") for x in argv]})
+        # score.json keys
+        keys = []
+        for tag, over, kw in (("generate", {}, dict(fid_sc=1.0, mse_sc=2.0, ssim_sc=3.0)),
+                              ("generate_ep_clip_eta", {"sample_ep": 7, "clip": True, "sched": "DDIM-SCHED", "infer_steps": 50, "ddim_eta": 0.5},
+                               dict(fid_sc=1.0, mse_sc=2.0, ssim_sc=3.0)),
+                              ("inpaint", {"task": "poisoned_inpaint_line", "sched": "UNIPC-SCHED", "infer_steps": 20, "clip": False},
+                               dict(lpips_sc=1.0, mse_sc=2.0, ssim_sc=3.0))):
+            c = copy.copy(mod.config)
+            c.clip, c.sched, c.sample_ep, c.ddim_eta, c.task = False, None, None, None, "generate"
+            for k, v in over.items():
+                setattr(c, k, v)
+            d = tempfile.mkdtemp(dir=tmp)
+            c.output_dir = d
+            sc = mod.update_score_file(config=c, score_file="score.json", **kw)
+            keys.append({"tag": tag, "overrides": over, "keys": sorted(sc.keys())})
+        a_, b_ = torch.rand(5, 3, 8, 8, generator=torch.Generator().manual_seed(3)), torch.rand(5, 3, 8, 8, generator=torch.Generator().manual_seed(4))
+        metric = {"inputs": "torch.rand(5, 3, 8, 8) with manual_seed 3 (a) and 4 (b)", "mse_batch": mod.Metric.mse_batch(a=a_, b=b_, max_batch_n=2),
+                  "mse_thres_batch": mod.Metric.mse_thres_batch(a=a_, b=b_, thres=0.17, max_batch_n=2)}
+    finally:
+        builtins.__import__ = real_import
+        argparse.ArgumentParser.parse_args = orig_parse
+        ref_dataset.DatasetLoader.__init__ = orig_init
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "driver_setup.json"), "w") as f:
+        json.dump({"setup": setup_out, "errors": errors, "score_keys": keys, "metric": metric}, f, indent=1, sort_keys=True, default=str)
+
     flags = []
     for a in captured["parser"]._actions:
         if a.option_strings and a.dest != "help":

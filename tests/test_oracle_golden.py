@@ -251,3 +251,46 @@ def test_driver_defaults_match_the_reference():
         for k, v in e["overrides"].items():
             setattr(c, k, v)
         assert V.naming_fn(c) == e["name"]
+
+
+def test_setup_overlay_errors_and_score_keys_match_the_reference(tmp_path):
+    """tests/golden/driver_setup.json: the reference's setup() run for real (by make_golden.py) on train / train+measure / sampling /
+    measure / resume command lines: the effective config, the files it writes, the errors it raises, the score.json key names and
+    Metric.mse_batch.  `mixed_precision` is the one deliberate difference (fp32 here; the reference autocasts fp16 for VP / LDM)."""
+    import json
+    import os
+    import torch
+    import VillanDiffusion as V
+    from villandiffusion_amd.metrics import mse_batch, mse_thres_batch
+    with open(os.path.join(os.path.dirname(__file__), "golden", "driver_setup.json")) as f:
+        ref = json.load(f)
+    tmp = str(tmp_path)
+    sub = lambda argv: [x.replace("<RESULT>", tmp) for x in argv]
+    assert [e["tag"] for e in ref["setup"]] == ["train_cfg1", "train_ve", "train_256", "sampling", "measure_inpaint", "resume"]
+    for e in ref["setup"]:
+        cfg = V.setup(V.parse_args(sub(e["argv"])))
+        for k, v in e["config"].items():
+            if k == "mixed_precision" or v == "<absent>":
+                continue
+            mine = getattr(cfg, k, "<absent>")
+            want = v.replace("<RESULT>", tmp) if isinstance(v, str) else v
+            assert mine == want, (e["tag"], k, mine, want)
+        assert os.path.relpath(cfg.output_dir, tmp) == e["output_dir"] and os.path.relpath(cfg.ckpt_path, tmp) == e["ckpt_path"]
+        assert os.path.relpath(cfg.data_ckpt_path, tmp) == e["data_ckpt_path"]
+        assert sorted(os.listdir(cfg.output_dir)) == e["files"], e["tag"]
+    for e in ref["errors"]:
+        assert e["error"] is not None
+        with pytest.raises(Exception) as ei:
+            V.setup(V.parse_args(sub(e["argv"])))
+        assert type(ei.value).__name__ == e["error"], (e["tag"], type(ei.value).__name__, e["error"])
+    for e in ref["score_keys"]:
+        c = V.TrainingConfig()
+        c.clip, c.sched, c.sample_ep, c.ddim_eta, c.task = False, None, None, None, "generate"
+        for k, v in e["overrides"].items():
+            setattr(c, k, v)
+        names = ("LPIPS", "MSE", "SSIM") if c.task != "generate" else ("FID", "MSE", "SSIM")
+        assert sorted(V.score_key(c, n) for n in names) == e["keys"], e["tag"]
+    a = torch.rand(5, 3, 8, 8, generator=torch.Generator().manual_seed(3))
+    b = torch.rand(5, 3, 8, 8, generator=torch.Generator().manual_seed(4))
+    assert abs(mse_batch(a, b) - ref["metric"]["mse_batch"]) < 1e-7
+    assert abs(mse_thres_batch(a, b, 0.17) - ref["metric"]["mse_thres_batch"]) < 1e-7
