@@ -329,6 +329,57 @@ def main():
     with open(os.path.join(OUT, "driver_setup.json"), "w") as f:
         json.dump({"setup": setup_out, "errors": errors, "score_keys": keys, "metric": metric}, f, indent=1, sort_keys=True, default=str)
 
+    # --- the scheduler / pipeline factory (model.py:599-776): with diffusers mocked, every scheduler / pipeline class is a distinct
+    # MagicMock, so calling the reference's private per-SDE factories records WHICH class each --sched builds and WITH WHAT kwargs
+    DMS = ref_model.DiffuserModelSched
+    sched_cls = ["DDPMScheduler", "DDIMScheduler", "DPMSolverMultistepScheduler", "UniPCMultistepScheduler", "PNDMScheduler",
+                 "DEISMultistepScheduler", "HeunDiscreteScheduler", "LMSDiscreteScheduler", "ScoreSdeVeScheduler", "KarrasVeScheduler"]
+    pipe_cls = ["DDPMPipeline", "DDIMPipeline", "PNDMPipeline", "ScoreSdeVePipeline", "LDMPipeline", "KarrasVePipeline", "DiffusionPipeline"]
+
+    def plain(v):
+        return v if isinstance(v, (str, int, float, bool, type(None))) else repr(type(v).__name__)
+
+    def probe(fn_name, sched, **kw):
+        for n in sched_cls + pipe_cls:
+            getattr(ref_model, n).reset_mock()
+        fn = getattr(DMS, "_DiffuserModelSched__" + fn_name)
+        try:
+            model, vae, ns, get_pipeline = fn("some/ckpt", noise_sched_type=sched, **kw)
+        except Exception as e:  # noqa: BLE001
+            return {"error": type(e).__name__}
+        built = [(n, getattr(ref_model, n).call_args) for n in sched_cls if getattr(ref_model, n).call_args is not None]
+        out = {"scheduler": None, "kwargs": None, "has_vae": vae is not None}
+        if built:
+            out["scheduler"] = built[0][0]
+            out["kwargs"] = {k: plain(v) for k, v in built[0][1].kwargs.items()}
+        acc = MagicMock()
+        try:
+            get_pipeline(acc, MagicMock(), vae, ns)
+        except TypeError:      # model.py:767-768: the LDM + LMSD branch returns the 2-argument generator -> the driver's 4-argument call fails
+            out["pipeline"], out["pipeline_kwargs"] = "TypeError", None
+            return out
+        used = [(n, getattr(ref_model, n).call_args) for n in pipe_cls if getattr(ref_model, n).call_args is not None]
+        out["pipeline"] = used[0][0] if used else None
+        out["pipeline_kwargs"] = sorted(k for k in used[0][1].kwargs) if used else None
+        return out
+
+    vp_names = ["DDPM_SCHED", "DDIM_SCHED", "DPM_SOLVER_PP_O1_SCHED", "DPM_SOLVER_O1_SCHED", "DPM_SOLVER_PP_O2_SCHED", "DPM_SOLVER_O2_SCHED",
+                "DPM_SOLVER_PP_O3_SCHED", "DPM_SOLVER_O3_SCHED", "UNIPC_SCHED", "PNDM_SCHED", "DEIS_SCHED", "HEUN_SCHED", "LMSD_SCHED"]
+    ve_names = ["SCORE_SDE_VE_SCHED", "EDM_VE_SCHED", "EDM_VE_SDE_SCHED", "EDM_VE_ODE_SCHED"]
+    factory = {"vp": {}, "ldm": {}, "ve": {}}
+    for clip in (True, False):
+        for n in vp_names + [None]:
+            v = getattr(DMS, n) if n else None
+            factory["vp"][f"{v}|clip={clip}"] = probe("get_model_sched_vp", v, clip_sample=clip)
+            factory["ldm"][f"{v}|clip={clip}"] = probe("get_model_sched_ldm", v, clip_sample=clip)
+        for n in ve_names + [None]:
+            v = getattr(DMS, n) if n else None
+            factory["ve"][f"{v}|clip={clip}"] = probe("get_model_sched_ve", v, clip_sample=clip)
+    factory["vp"]["LDM-SCHED-like unknown|clip=False"] = probe("get_model_sched_vp", "NO-SUCH-SCHED", clip_sample=False)
+    factory["ve"]["DDPM-SCHED|clip=False"] = probe("get_model_sched_ve", DMS.DDPM_SCHED, clip_sample=False)
+    with open(os.path.join(OUT, "factory_table.json"), "w") as f:
+        json.dump(factory, f, indent=1, sort_keys=True)
+
     flags = []
     for a in captured["parser"]._actions:
         if a.option_strings and a.dest != "help":

@@ -294,3 +294,59 @@ def test_setup_overlay_errors_and_score_keys_match_the_reference(tmp_path):
     b = torch.rand(5, 3, 8, 8, generator=torch.Generator().manual_seed(4))
     assert abs(mse_batch(a, b) - ref["metric"]["mse_batch"]) < 1e-7
     assert abs(mse_thres_batch(a, b, 0.17) - ref["metric"]["mse_thres_batch"]) < 1e-7
+
+
+def test_factory_table_matches_the_reference():
+    """--sched -> (scheduler class, ctor kwargs, pipeline class, pipeline kwargs) for the VP / LDM / VE factories, recorded by
+    calling the reference's DiffuserModelSched.__get_model_sched_{vp,ldm,ve} with diffusers mocked (tests/golden/make_golden.py;
+    reference model.py:600-776).  Ours is held to the same table through `_get_model_sched_*(build_model=False)`."""
+    import json
+    from villandiffusion_amd.model import DiffuserModelSched as D
+    table = json.load(open(os.path.join(G, "factory_table.json")))
+    fns = {"vp": D._get_model_sched_vp, "ldm": D._get_model_sched_ldm, "ve": D._get_model_sched_ve}
+
+    class _Acc:
+        @staticmethod
+        def unwrap_model(m):
+            return m
+
+    checked = 0
+    for sde, rows in table.items():
+        for key, want in rows.items():
+            sched_name, clip_s = key.split("|clip=")
+            sched_arg = None if sched_name == "None" else sched_name
+            clip = clip_s == "True"
+            if "error" in want:
+                with pytest.raises(NotImplementedError):
+                    fns[sde]("some/ckpt", clip, noise_sched_type=sched_arg, build_model=False)
+                checked += 1
+                continue
+            model, vae, sched, get_pipeline = fns[sde]("some/ckpt", clip, noise_sched_type=sched_arg, build_model=False)
+            assert model is None and vae is None          # build_model=False: only the sampler side is built
+            if want["scheduler"] is not None:             # None = "keep the scheduler the checkpoint shipped"
+                assert type(sched).__name__ == want["scheduler"], key
+                for k, v in want["kwargs"].items():
+                    if k == "trained_betas":
+                        assert v is None
+                        continue
+                    got = getattr(sched.config, k)
+                    assert got == v, (sde, key, k, got, v)
+            assert sched.config.clip_sample == clip, key  # model.py:655-657 / 698-700 / 771-773: the override after construction
+            vq = object() if want["has_vae"] else None
+            pipe = get_pipeline(_Acc(), object(), vq, sched)
+            if want["pipeline"] == "TypeError":
+                # model.py:767-768: the reference's LDM + LMSD branch hands the driver a 2-argument generator, so its 4-argument
+                # call raises.  Ours builds the LDM pipeline like the neighbouring branches (a superset, not a divergence on
+                # any path the reference can complete).
+                assert type(pipe).__name__ == "LDMPipeline"
+            else:
+                assert type(pipe).__name__ == want["pipeline"], key
+                if "clip_sample" in want["pipeline_kwargs"]:
+                    assert pipe.clip_sample == clip, key
+                else:
+                    assert pipe.clip_sample is None, key
+                if "clip_sample_range" in want["pipeline_kwargs"]:
+                    assert pipe.clip_sample_range is not None, key
+            assert pipe.scheduler is sched and (pipe.vqvae is vq)
+            checked += 1
+    assert checked == sum(len(r) for r in table.values()) >= 60

@@ -607,7 +607,7 @@ class KarrasVeScheduler:
     def __init__(self, sigma_min=0.02, sigma_max=100.0, s_noise=1.007, s_churn=80.0, s_min=0.05, s_max=50.0,
                  num_train_timesteps=None, **extra):
         self.config = _Config(sigma_min=sigma_min, sigma_max=sigma_max, s_noise=s_noise, s_churn=s_churn, s_min=s_min, s_max=s_max,
-                              clip_sample=False)
+                              num_train_timesteps=num_train_timesteps, clip_sample=False)
         self.init_noise_sigma = sigma_max
         self.num_inference_steps = None
         self.timesteps = self.schedule = None
