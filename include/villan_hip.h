@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 2
+#define VD_ABI_VERSION 3
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -86,6 +86,12 @@ typedef struct vd_gemm_desc {
                                 [nb][C][2] from vd_groupnorm_stats; the convolution then reads silu(x*scale + shift) instead
                                 of x (GroupNorm + SiLU folded into the patch loader: inference path, nothing is saved).
                                 Needs the patch-staged kernel (OW >= 16, C % 8 == 0, C <= 1024, M >= 64)              */
+    const void* a_packed;    /* nullable.  3x3 convolutions (VD_B_CONV3 / _T / _UP at 8x8, 16x16, 32x32 outputs, C % 16 == 0,
+                                M >= 64) only: the weights pre-split into bf16 (hi, lo) pairs by vd_conv3_pack_weights.  The
+                                convolution then runs as three bf16 MFMAs per product term (hi*hi + hi*lo + lo*hi, f32
+                                accumulation; ~1e-5 relative to the exact-f32 kernel) instead of on the f32 MFMA.  A is still
+                                required (shape checks) but not read.  Problems outside that set fail with VD_EINVAL.   */
+    int32_t a_packed_mpad;   /* row count the packed operand was built with (M rounded up to 128)                      */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -94,7 +100,7 @@ int vd_gemm(const vd_gemm_desc* desc, void* stream);
 int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
 /* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4 / 6: patch-staged 3x3
  * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel, 7: direct 3x3 convolution for <= 4 output
- * channels (profiling / tests). */
+ * channels, 8: split-precision bf16 convolution (a_packed), -1: a_packed given for an unsupported problem (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):
@@ -119,6 +125,14 @@ int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);
 int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc);
 /* Tile and split count vd_conv_wgrad will use (profiling / tests). */
 int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits);
+
+/* Split-precision operand for vd_gemm_desc.a_packed: element (m, c, t) of the logical [M][C][9] matrix is read from
+ * W[m*row_stride + c*chan_stride + t] (plain weights: row_stride = C*9, chan_stride = 9; the transposed operand of the
+ * stride-1 dgrad, A'[c_in][m_out] = W[m_out][c_in]: row_stride = 9, chan_stride = C_in*9 with M = C_in, C = M_out) and stored
+ * as bf16 hi = bf16(w), lo = bf16(w - hi) in the kernel's fragment order.  `packed` holds vd_conv3_packed_bytes(M, C) bytes,
+ * 16-byte aligned; C % 16 == 0. */
+int64_t vd_conv3_packed_bytes(int M, int C);
+int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int64_t row_stride, int64_t chan_stride, void* stream);
 
 /* W[M][C][T] -> Wt[C][M][T]  (operand for the dgrad GEMMs). */
 int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* stream);

@@ -649,6 +649,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vd_gemm_desc
     }
 }
 
+#include "vd_conv_bx3.inc"
+
 // Eligibility of the patch-staged kernel for a vd_gemm problem.
 static bool patch_eligible(const vd_gemm_desc& d) {
     if (d.a_mode != VD_A_ROW || d.a_bstride != 0) return false;
@@ -1784,6 +1786,12 @@ int launch_wgrad_t(const vd_wgrad_desc& d, int splits, int kk_per, hipStream_t s
 }  // namespace
 
 extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
+    if (desc && desc->a_packed) {
+        if (!bx3_eligible(*desc)) return 0;
+        int splits, c_per;
+        bx3_plan(*desc, splits, c_per);
+        return splits > 1 ? (int64_t)splits * desc->M * desc->N : 0;
+    }
     if (!desc || !patch_eligible(*desc)) return 0;
     int splits, ks_per;
     patch_plan(*desc, splits, ks_per);
@@ -1793,6 +1801,7 @@ extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
 extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
+    if (d.a_packed) return bx3_eligible(d) ? 8 : -1;
     if (smallm_eligible(d)) return 7;                        // direct convolution for <= 4 output channels
     if (patch_eligible(d)) {
         int splits, ks_per;
@@ -1823,6 +1832,8 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         VD_REQUIRE(!d.residual && !d.rowadd && !d.d_trans && d.b_mode <= VD_B_KCONTIG && (d.N / d.NP) % d.nb2 == 0,
                    "vd_gemm: two-level batch (nb2=%d) needs plain operands, no residual/rowadd, nb %% nb2 == 0", d.nb2);
     const int tile = vd_gemm_tile(&d);
+    VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16 convolution) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 "
+                           "outputs, C %% 16 == 0, M >= 64, a_packed_mpad = M rounded up to 128");
     VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     hipStream_t st = (hipStream_t)stream;
@@ -1834,6 +1845,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 4:
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
+        case 8: rc = launch_bx3(d, st); break;
         case 5: {
             const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
             if (d.a_mode == VD_A_ROW)
@@ -1847,6 +1859,22 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     }
     if (rc) return rc;
     VD_LAUNCH_CHECK("vd_gemm");
+    return 0;
+}
+
+extern "C" int64_t vd_conv3_packed_bytes(int M, int C) {
+    if (M <= 0 || C <= 0 || C % XC != 0) return 0;
+    return (int64_t)((M + 127) / 128 * 128) * C * 9 * 4;
+}
+
+extern "C" int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int64_t row_stride, int64_t chan_stride, void* stream) {
+    VD_REQUIRE(W && packed && M > 0 && C > 0 && C % XC == 0, "vd_conv3_pack_weights: bad arguments (M=%d C=%d, C %% 16 == 0)", M, C);
+    VD_REQUIRE((((uintptr_t)packed) & 15) == 0, "vd_conv3_pack_weights: packed must be 16-byte aligned");
+    const int Mpad = (M + 127) / 128 * 128;
+    const int total = (C / XC) * 9 * 2 * Mpad;
+    hipLaunchKernelGGL(conv3_pack_kernel, dim3(vd_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       reinterpret_cast<u32x4*>(packed), M, C, Mpad, row_stride, chan_stride);
+    VD_LAUNCH_CHECK("vd_conv3_pack_weights");
     return 0;
 }
 

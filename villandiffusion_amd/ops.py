@@ -73,9 +73,11 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0, gn_ss=None):
+         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None):
     d = GemmDesc()
     d.pad = pad
+    if a_packed is not None:
+        d.a_packed, d.a_packed_mpad = a_packed.data_ptr(), (M + 127) // 128 * 128
     d.gn_ss = _p(gn_ss)
     d.nb2, d.a_b2stride, d.b_b2stride, d.d_b2stride = nb2, a_b2stride, b_b2stride, d_b2stride
     d.A, d.B, d.D = _p(A), _p(B), _p(D)
@@ -103,7 +105,11 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     e1.record()
     flops = 2.0 * M * N * K * (0.25 if b_mode == B_CONV3_DIL else 1.0)     # DIL: 3/4 of the taps are structural zeros
     tl = lib.vd_gemm_tile(C.byref(d))
-    if tl in (4, 6):     # symbol names as rocprofv3 prints them
+    if tl == 8:
+        md = 0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
+        wide = d.OW == 32 and (N // 256) * ((M + 127) // 128) % 512 == 0 and N % 256 == 0
+        name = f"conv3_bx3_kernel<{d.OW}, {md}, {4 if wide else 2}>"
+    elif tl in (4, 6):     # symbol names as rocprofv3 prints them
         tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
         name = f"conv3_patch_kernel<{tw}, {md}, {4 if tl == 6 else 2}>"
@@ -121,8 +127,28 @@ _CONV_OUT = {B_CONV3: lambda h, w: (h, w), B_CONV3_T: lambda h, w: (h, w), B_CON
              B_CONV3_UP: lambda h, w: (2 * h, 2 * w), B_CONV3_DIL: lambda h, w: (2 * h, 2 * w)}
 
 
+def conv3_pack_weights(w2d, M, Cc, transposed=False, out=None):
+    """Split-precision operand of conv3x3(a_packed=...): the [M, Cc*9] weights as bf16 (hi, lo) pairs in MFMA fragment order.
+    transposed=True packs the dgrad operand A'[c_in][m_out] straight from the forward weights w2d [m_out, c_in*9] (then
+    M = c_in, Cc = m_out)."""
+    lib = _lib()
+    nbytes = lib.vd_conv3_packed_bytes(M, Cc)
+    assert nbytes > 0, (M, Cc)
+    if out is None:
+        out = torch.empty(nbytes // 4, device=w2d.device, dtype=torch.int32)
+    assert out.numel() * out.element_size() >= nbytes and w2d.is_contiguous()
+    rs, cs = (9, M * 9) if transposed else (Cc * 9, 9)
+    L.check(lib.vd_conv3_pack_weights(_p(w2d), _p(out), M, Cc, rs, cs, _s()), "vd_conv3_pack_weights")
+    return out
+
+
+def bx3_eligible(M, Cc, OH, OW, mode) -> bool:
+    """Problems the split-precision convolution kernel takes (vd_gemm_desc.a_packed)."""
+    return mode in (B_CONV3, B_CONV3_T, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and Cc % 16 == 0 and M >= 64
+
+
 def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
-            pad=0, gn_ss=None):
+            pad=0, gn_ss=None, a_packed=None):
     """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9].
     pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1)."""
     Bn, Cc, H, W, xbs = _img(x)
@@ -138,7 +164,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
                 ldd=OH * OW, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
-                pad=pad, gn_ss=gn_ss)
+                pad=pad, gn_ss=gn_ss, a_packed=a_packed)
 
 
 def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0):
