@@ -133,6 +133,10 @@ int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits);
  * 16-byte aligned; C % 16 == 0. */
 int64_t vd_conv3_packed_bytes(int M, int C);
 int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int64_t row_stride, int64_t chan_stride, void* stream);
+/* The same for n_jobs operands in one launch (all convolutions of a network after an optimizer step).  table: DEVICE array of
+ * int64 [n_jobs][8] = {W address, packed address, M, C, row_stride, chan_stride, first workgroup of the job, 0}; job j owns
+ * ceil(Mpad_j * C_j / 8 / 256) workgroups of 256 threads, first-workgroup numbers ascending from 0; total_blocks = their sum. */
+int vd_conv3_pack_weights_multi(const int64_t* table, int n_jobs, int64_t total_blocks, void* stream);
 
 /* W[M][C][T] -> Wt[C][M][T]  (operand for the dgrad GEMMs). */
 int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* stream);

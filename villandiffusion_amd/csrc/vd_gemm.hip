@@ -1871,10 +1871,17 @@ extern "C" int vd_conv3_pack_weights(const float* W, void* packed, int M, int C,
     VD_REQUIRE(W && packed && M > 0 && C > 0 && C % XC == 0, "vd_conv3_pack_weights: bad arguments (M=%d C=%d, C %% 16 == 0)", M, C);
     VD_REQUIRE((((uintptr_t)packed) & 15) == 0, "vd_conv3_pack_weights: packed must be 16-byte aligned");
     const int Mpad = (M + 127) / 128 * 128;
-    const int total = (C / XC) * 9 * 2 * Mpad;
+    const int total = (C / XC) * 2 * Mpad;
     hipLaunchKernelGGL(conv3_pack_kernel, dim3(vd_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W,
                        reinterpret_cast<u32x4*>(packed), M, C, Mpad, row_stride, chan_stride);
     VD_LAUNCH_CHECK("vd_conv3_pack_weights");
+    return 0;
+}
+
+extern "C" int vd_conv3_pack_weights_multi(const int64_t* table, int n_jobs, int64_t total_blocks, void* stream) {
+    VD_REQUIRE(table && n_jobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "vd_conv3_pack_weights_multi: bad arguments");
+    hipLaunchKernelGGL(conv3_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_jobs);
+    VD_LAUNCH_CHECK("vd_conv3_pack_weights_multi");
     return 0;
 }
 

@@ -107,8 +107,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     tl = lib.vd_gemm_tile(C.byref(d))
     if tl == 8:
         md = 0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
-        wide = d.OW == 32 and (N // 256) * ((M + 127) // 128) % 512 == 0 and N % 256 == 0
-        name = f"conv3_bx3_kernel<{d.OW}, {md}, {4 if wide else 2}>"
+        name = f"conv3_bx3_kernel<{d.OW}, {md}, 2>"
     elif tl in (4, 6):     # symbol names as rocprofv3 prints them
         tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
@@ -140,6 +139,17 @@ def conv3_pack_weights(w2d, M, Cc, transposed=False, out=None):
     rs, cs = (9, M * 9) if transposed else (Cc * 9, 9)
     L.check(lib.vd_conv3_pack_weights(_p(w2d), _p(out), M, Cc, rs, cs, _s()), "vd_conv3_pack_weights")
     return out
+
+
+def conv3_pack_weights_multi(table, n_jobs, total_blocks):
+    """table: device int64 [n_jobs, 8] = (W address, packed address, M, C, row_stride, chan_stride, first workgroup, 0)."""
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.numel() >= 8 * n_jobs
+    L.check(_lib().vd_conv3_pack_weights_multi(_p(table), n_jobs, total_blocks, _s()), "vd_conv3_pack_weights_multi")
+
+
+# Bumped by every raw-pointer parameter update (vd_adam_step writes behind torch's version counters): caches derived from the
+# weights (packed split-precision operands) key on (flat_param._version, WEIGHTS_EPOCH).
+WEIGHTS_EPOCH = 0
 
 
 def bx3_eligible(M, Cc, OH, OW, mode) -> bool:
@@ -445,6 +455,8 @@ def l2norm_sq(g, partial, out_sq):
 
 
 def adam_step(p, g, m, v, norm_sq, max_norm, inv_scale, lr, beta1, beta2, eps, step):
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
     L.check(_lib().vd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm_sq), max_norm, inv_scale, lr, beta1, beta2,
                                 eps, step, _s()), "vd_adam_step")
 

@@ -18,6 +18,7 @@ Backward writes parameter gradients (accumulating) into the flat gradient buffer
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -44,6 +45,66 @@ def _ensure_path(root: nn.Module, parts: Sequence[str]) -> nn.Module:
 
 
 # ----------------------------------------------------------------------------------------------------------- layers
+CONV_MATH_DEFAULT = os.environ.get("VILLAN_CONV_MATH", "bf16x3")
+
+
+class _PackedConvWeights:
+    """Operands of the split-precision ("bf16x3") 3x3 convolution kernel (vd_gemm_desc.a_packed): every eligible convolution's
+    weights as bf16 (hi, lo) pairs in MFMA fragment order -- one image for the forward convolution and one (transposed) for the
+    stride-1 input gradient.  Each set is rebuilt in ONE launch when the weights have changed since it was built."""
+
+    def __init__(self, net):
+        self.net = net
+        self.off = {False: {}, True: {}}                 # bwd? -> prefix -> (offset, n) in int32 elements
+        self.jobs = {False: [], True: []}                # (prefix, M, C, row_stride, chan_stride) of the packed operand
+        self.total = 0
+        for name, shape, _ in net._layout:
+            if not (name.endswith(".weight") and len(shape) == 4 and shape[2] == 3):
+                continue
+            prefix, cout, cin = name[:-7], shape[0], shape[1]
+            for bwd, (M, Cc, rs, cs) in ((False, (cout, cin, cin * 9, 9)), (True, (cin, cout, 9, cin * 9))):
+                if Cc % 16 == 0 and M >= 64:
+                    n = (M + 127) // 128 * 128 * Cc * 9
+                    self.off[bwd][prefix] = (self.total, n)
+                    self.jobs[bwd].append((prefix, M, Cc, rs, cs))
+                    self.total += n
+        self.buf: Optional[torch.Tensor] = None
+        self.tables = {}
+        self.key = {False: None, True: None}
+
+    def view(self, prefix, bwd):
+        """Packed operand of `prefix` (None if that convolution is not eligible), fresh for the current weights."""
+        ent = self.off[bwd].get(prefix)
+        if ent is None:
+            return None
+        net = self.net
+        key = (net.flat_param._version, ops.WEIGHTS_EPOCH)
+        if self.key[bwd] != key:
+            if self.buf is None:
+                self.buf = torch.empty(self.total, device=net.flat_param.device, dtype=torch.int32)
+            if bwd not in self.tables:
+                rows, blk = [], 0
+                for pfx, M, Cc, rs, cs in self.jobs[bwd]:
+                    o, n = self.off[bwd][pfx]
+                    rows.append([net.P[pfx + ".weight"].data_ptr(), self.buf.data_ptr() + 4 * o, M, Cc, rs, cs, blk, 0])
+                    blk += ((M + 127) // 128 * 128 * (Cc // 16) * 2 + 255) // 256
+                self.tables[bwd] = (torch.tensor(rows, dtype=torch.int64).to(self.buf.device), len(rows), blk)
+            tab, nj, blk = self.tables[bwd]
+            ops.conv3_pack_weights_multi(tab, nj, blk)
+            self.key[bwd] = key
+        return self.buf[ent[0]:ent[0] + ent[1]]
+
+
+def _bx3_packed(net, prefix, bwd, M, Cc, OH, OW, mode):
+    """The packed operand to hand to ops.conv3x3 for this call, or None (exact-f32 kernels)."""
+    if getattr(net, "conv_math", "f32") != "bf16x3" or not ops.bx3_eligible(M, Cc, OH, OW, mode):
+        return None
+    pk = getattr(net, "_packed", None)
+    if pk is None:
+        pk = net._packed = _PackedConvWeights(net)
+    return pk.view(prefix, bwd)
+
+
 class _Conv:
     """3x3 convolution (mode selects the gather) with bias; weight stored [M, C, 3, 3] like diffusers."""
 
@@ -56,8 +117,10 @@ class _Conv:
         return self.net.P[self.prefix + ".weight"].view(self.cout, self.cin * 9)
 
     def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None, gn_ss=None):
+        pk = None if gn_ss is not None else _bx3_packed(self.net, self.prefix, False, self.cout, self.cin, out.shape[2], out.shape[3],
+                                                        self.mode)
         return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
-                           rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss)
+                           rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk)
 
     def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
         """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
@@ -74,13 +137,16 @@ class _Conv:
             return None
         if self.mode == B_CONV3_S2:
             return ops.conv3x3_s2_dgrad(dout, self.w2d(), dx, pad=self.pad)
-        wt = net.wt_view(self.prefix, self.cout, self.cin, 9)     # [C, M*9]
+        # split-precision dgrad reads the packed transposed operand; the f32 transposed copy is then only a shape carrier
+        pk = _bx3_packed(net, self.prefix, True, self.cin, self.cout, dout.shape[2], dout.shape[3], B_CONV3_T) \
+            if self.mode in (B_CONV3, B_CONV3_UP) else None
+        wt = net.wt_view(self.prefix, self.cout, self.cin, 9, fresh=pk is None)     # [C, M*9]
         if self.mode == B_CONV3:
-            ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T)
+            ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T, a_packed=pk)
         elif self.mode == B_CONV3_UP:
             B, _, OH, OW = dout.shape
             dU = torch.empty((B, self.cin, OH, OW), device=dout.device, dtype=torch.float32)
-            ops.conv3x3(dout, wt, None, dU, mode=B_CONV3_T)
+            ops.conv3x3(dout, wt, None, dU, mode=B_CONV3_T, a_packed=pk)
             ops.sumpool2x2(dU, dx)
         else:
             raise NotImplementedError(self.mode)
@@ -523,6 +589,11 @@ class UNet2DModel(nn.Module):
         # pay: the transform sits in the store phase of the K-step (conv 439 -> 455 us, 373 -> 393 us) and costs more than the saved
         # normalise pass (26 -> 14 us): 8.22 vs 8.30 img/s for DDPM-1000.  Kept as an opt-in.
         self.fuse_gn_inference = False
+        # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
+        # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
+        self.conv_math = CONV_MATH_DEFAULT
+        self._packed: Optional[_PackedConvWeights] = None
+        self._wt_fresh = set()
         self.reset_parameters()
 
     @torch.no_grad()
@@ -629,17 +700,19 @@ class UNet2DModel(nn.Module):
             ops.scale_(t, 0.0)
         return t
 
-    def wt_view(self, prefix, M, Cc, T):
+    def wt_view(self, prefix, M, Cc, T, fresh=True):
+        """Transposed weights [C, M*T] of `prefix` for the dgrad GEMM, transposed on first use in each backward pass
+        (fresh=False: only the shape is needed -- the split-precision kernel reads its own packed operand)."""
         off = self._wt_offs[prefix]
+        if fresh and prefix not in self._wt_fresh:
+            ops.weight_transpose(self.P[prefix + ".weight"], self._wt_buf[off:off + M * Cc * T], M, Cc, T)
+            self._wt_fresh.add(prefix)
         return self._wt_buf[off:off + M * Cc * T].view(Cc, M * T)
 
     def _prepare_backward(self, B):
         if self._wt_buf is None:
             self._wt_buf = torch.empty(self._wt_total, device=self._dev, dtype=torch.float32)
-        for prefix, off in self._wt_offs.items():
-            w = self.P[prefix + ".weight"]
-            M, Cc = w.shape[0], w.shape[1]
-            ops.weight_transpose(w, self._wt_buf[off:off + M * Cc * 9], M, Cc, 9)
+        self._wt_fresh = set()
         if self.wgrad_ws is None or getattr(self, "_ws_B", None) != B:
             need = 0
             S = self.sample_size
