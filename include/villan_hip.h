@@ -118,6 +118,8 @@ typedef struct vd_wgrad_desc {
     int32_t mode, splits, accumulate, tile;
     int64_t dy_bstride, x_bstride;
     int32_t pad;              /* VD_B_CONV3_S2 only, as in vd_gemm_desc                         */
+    int32_t math;             /* 0: exact f32 MFMA.  1: split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulation,
+                                 ~1e-5 relative): VD_B_CONV3 at 8x8 / 16x16 / 32x32, M >= 64, C >= 64; otherwise VD_EINVAL */
 } vd_wgrad_desc;
 
 int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);

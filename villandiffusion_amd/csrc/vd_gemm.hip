@@ -1359,6 +1359,8 @@ __device__ __forceinline__ void wgrad_patch_store(const vd_wgrad_desc& d, const 
         }
 }
 
+#include "vd_wgrad_bx3.inc"
+
 // Generalisation of wgrad_patch_kernel to the other image widths.  A K-step is still 32 output pixels = ROWS rows of
 // TW = 32/ROWS pixels.  Rows are numbered globally (gr = image*OH + y, OH a power of two), so a step may span images
 // (4x4 outputs: ROWS = 8 = two images); for OW >= 64 (ROWS == 1) a step is one 32-pixel segment of a row and the halo
@@ -1528,6 +1530,12 @@ static int ilog2_exact(int v) {  // log2 of a power of two, -1 otherwise
 static int wgrad_patch_kind(const vd_wgrad_desc& d) {
     if (d.T != 9 || (d.mode != VD_B_CONV3 && d.mode != VD_B_CONV3_UP)) return 0;
     if (d.NP != d.OH * d.OW || d.M < 64 || d.C < 64 || d.tile != 0) return 0;
+    if (d.math == 1) {      // split-precision kernel (explicit request): stride-1 3x3 at 8x8 / 16x16 / 32x32
+        if (d.mode == VD_B_CONV3 && d.OH == d.OW && (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.H == d.OH && d.W == d.OW &&
+            (d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0))
+            return 4;
+        return -1;
+    }
     static const bool k64 = getenv("VD_WGRAD_KPIX64") != nullptr;       // experiment: 64-pixel K-steps for the 16 / 32 px layers
     if (k64 && (d.OW == 16 || d.OW == 32) && ilog2_exact(d.OH) >= 0 && ((int64_t)d.nb * d.NP) % 64 == 0) return 3;
     if (d.OW == 16 || d.OW == 32) return d.OH % (32 / d.OW) == 0 ? 1 : 0;
@@ -1540,7 +1548,7 @@ static int wgrad_patch_kind(const vd_wgrad_desc& d) {
     if (d.OW >= 64 && d.OW % 32 == 0 && ilog2_exact(d.OW / 32) >= 0) return 2;
     return 0;
 }
-static bool wgrad_patch_eligible(const vd_wgrad_desc& d) { return wgrad_patch_kind(d) != 0; }
+static bool wgrad_patch_eligible(const vd_wgrad_desc& d) { return wgrad_patch_kind(d) > 0; }
 
 static void wgrad_patch_plan(const vd_wgrad_desc& d, int& splits, int& ks_per) {
     const int kpix = wgrad_patch_kind(d) == 3 ? 64 : 32;
@@ -1932,6 +1940,8 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
     if (d.mode == VD_B_PLAIN)
         VD_REQUIRE((d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0) && d.H * d.W == d.NP,
                    "vd_conv_wgrad: 1x1 X alignment");
+    VD_REQUIRE(d.math == 0 || wgrad_patch_kind(d) == 4, "vd_conv_wgrad: math = 1 (split-precision bf16) needs a stride-1 3x3 "
+               "convolution at 8x8 / 16x16 / 32x32 with M >= 64, C >= 64, 16-byte aligned X");
     const int Ncols = d.C * d.T;
     int tile, splits, kk_per;
     wgrad_plan(d, tile, splits, kk_per);
@@ -1942,7 +1952,11 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         case 4: {
             dim3 grid(vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3, splits);
             rc = 0;
-            if (wgrad_patch_kind(d) == 3) {
+            if (wgrad_patch_kind(d) == 4) {
+                if (d.OW == 32) hipLaunchKernelGGL((wgrad_bx3_kernel<32>), grid, dim3(NT), 0, st, d, kk_per);
+                else if (d.OW == 16) hipLaunchKernelGGL((wgrad_bx3_kernel<16>), grid, dim3(NT), 0, st, d, kk_per);
+                else hipLaunchKernelGGL((wgrad_bx3_kernel<8>), grid, dim3(NT), 0, st, d, kk_per);
+            } else if (wgrad_patch_kind(d) == 3) {
                 const int ohs = ilog2_exact(d.OH);
                 const bool up = d.mode == VD_B_CONV3_UP;
                 if (d.OW == 32) {

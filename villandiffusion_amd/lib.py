@@ -37,7 +37,7 @@ class WgradDesc(C.Structure):
                 ("M", _i32), ("C", _i32), ("T", _i32), ("nb", _i32), ("NP", _i32),
                 ("H", _i32), ("W", _i32), ("OH", _i32), ("OW", _i32),
                 ("mode", _i32), ("splits", _i32), ("accumulate", _i32), ("tile", _i32),
-                ("dy_bstride", _i64), ("x_bstride", _i64), ("pad", _i32)]
+                ("dy_bstride", _i64), ("x_bstride", _i64), ("pad", _i32), ("math", _i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/villan_hip.h

@@ -217,7 +217,7 @@ def linear_wgrad(dy, x, dw, accumulate=False):
                 accumulate=accumulate)
 
 
-def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, splits=0, tile=0, pad=0):
+def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, splits=0, tile=0, pad=0, math_mode=0):
     """dw2d[M, C*T] (+)= sum_{b,p} dy[b,m,p] * gather_mode(x)[b, c, p(+)t]."""
     Bn, M, OH, OW, dbs = _img(dy)
     Bx, Cc, H, W, xbs = _img(x)
@@ -231,6 +231,7 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     d.mode, d.splits, d.accumulate, d.tile = mode, splits, int(accumulate), tile
     d.dy_bstride, d.x_bstride = dbs, xbs
     d.pad = pad
+    d.math = math_mode
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_floats(C.byref(d))
     if need > 0:
@@ -244,7 +245,9 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     e1.record()
     tl, sp = C.c_int32(0), C.c_int32(0)
     lib.vd_conv_wgrad_plan(C.byref(d), C.byref(tl), C.byref(sp))
-    if tl.value == 4:
+    if tl.value == 4 and math_mode == 1:
+        name = f"wgrad_bx3_kernel<{OW}>(+slab_reduce)"
+    elif tl.value == 4:
         name = f"wgrad_patch_kernel<{OW}, {0 if mode == B_CONV3 else 2}>(+slab_reduce)"
     else:
         name = f"wgrad_kernel<{_TILE_NAMES[tl.value]},{_B_NAMES[mode]}>(+slab_reduce)"
@@ -252,13 +255,20 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     return dw2d
 
 
-def wgrad_ws_floats(M, Cc, T, nb, NP, OH=None, OW=None, mode=None) -> int:
+def wgrad_bx3_eligible(M, Cc, OH, OW, mode) -> bool:
+    """Problems the split-precision weight-gradient kernel takes (vd_wgrad_desc.math = 1)."""
+    return mode == B_CONV3 and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
+
+
+def wgrad_ws_floats(M, Cc, T, nb, NP, OH=None, OW=None, mode=None, math_mode=0) -> int:
     """Workspace floats vd_conv_wgrad needs (square outputs assumed when OH/OW are omitted)."""
     d = WgradDesc()
     if OH is None:
         OH = OW = int(round(math.sqrt(NP)))
     d.M, d.C, d.T, d.nb, d.NP, d.OH, d.OW = M, Cc, T, nb, NP, OH, OW
     d.mode = (B_PLAIN if T == 1 else B_CONV3) if mode is None else mode
+    if math_mode:
+        d.math, d.H, d.W = math_mode, OH, OW
     return int(L.load().vd_conv_wgrad_ws_floats(C.byref(d)))
 
 

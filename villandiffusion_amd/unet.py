@@ -125,8 +125,10 @@ class _Conv:
     def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
         """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
         net = self.net
+        bx3 = getattr(net, "conv_math", "f32") == "bf16x3" and ops.wgrad_bx3_eligible(self.cout, self.cin, dout.shape[2], dout.shape[3],
+                                                                                       self.mode) and x.stride(0) % 4 == 0
         ops.conv_wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, net.wgrad_ws,
-                       accumulate=True, pad=self.pad)
+                       accumulate=True, pad=self.pad, math_mode=int(bx3))
         if not skip_bias:
             B = dout.shape[0]
             ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
@@ -722,6 +724,9 @@ class UNet2DModel(nn.Module):
                     for hw in {(S >> k) ** 2 for k in range(len(self.config.block_out_channels))}:
                         for md in ((B_PLAIN,) if T == 1 else (B_CONV3, B_CONV3_UP, B_CONV3_S2)):
                             need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=md))
+                        side = int(round(math.sqrt(hw)))
+                        if T == 9 and ops.wgrad_bx3_eligible(M, Cc, side, side, B_CONV3):
+                            need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=B_CONV3, math_mode=1))
             for prefix, ch in self._qkv:
                 for hw in {(S >> k) ** 2 for k in range(len(self.config.block_out_channels))}:
                     need = max(need, ops.wgrad_ws_floats(3 * ch, ch, 1, B, hw), ops.wgrad_ws_floats(ch, ch, 1, B, hw))
