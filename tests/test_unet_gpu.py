@@ -13,8 +13,10 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.fixture(scope="module")
-def pair():
+@pytest.fixture(scope="module", params=["bf16x3", "f32"])
+def pair(request):
+    """Both convolution arithmetics against the same oracle and the same bounds: "bf16x3" (default: eligible 3x3 convolutions,
+    their input and weight gradients on the bf16 matrix cores as hi*hi + hi*lo + lo*hi) and "f32" (everything on the exact f32 MFMA)."""
     torch.manual_seed(0)
     ref = UNet2DModelRef()
     with torch.no_grad():                      # make norms / biases non-trivial so their gradients are exercised
@@ -23,6 +25,7 @@ def pair():
                 p.add_(0.1 * torch.randn_like(p))
     net = UNet2DModel()
     net.load_state_dict(ref.state_dict())
+    net.conv_math = request.param
     return ref, net
 
 
@@ -50,7 +53,7 @@ def test_forward_matches_oracle(pair):
         y_ref = ref(x, t)[0]
         y = net(x.cuda(), t.cuda(), return_dict=False)[0]
     e = rel(y, y_ref)
-    print(f"[parity] unet forward rel_err={e:.3e}")
+    print(f"[parity] unet forward ({net.conv_math}) rel_err={e:.3e}")
     assert e < 1e-4
     # scalar timestep broadcast (pipeline call style)
     with torch.no_grad():
@@ -80,7 +83,7 @@ def test_backward_matches_oracle(pair):
         if e > worst[0]:
             worst = (e, n)
         assert e < 1e-3, (n, e)
-    print(f"[parity] unet backward worst param-grad rel_err={worst[0]:.3e} at {worst[1]}")
+    print(f"[parity] unet backward ({net.conv_math}) worst param-grad rel_err={worst[0]:.3e} at {worst[1]}")
     gn_ref = torch.sqrt(sum((g.double() ** 2).sum() for g in gref.values()))
     gn = torch.sqrt((net.flat_grad.double() ** 2).sum()).cpu()
     assert abs(float(gn) - float(gn_ref)) <= 1e-4 * float(gn_ref)
