@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_PER_IMG = 12.444          # SURVEY.md §8d (2 x MAC), DDPM-CIFAR10-32 UNet
 TRAIN_GFLOP_PER_IMG = 3 * FWD_GFLOP_PER_IMG
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= f32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles / instruction)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--sample-images", type=int, default=128, help="per-GPU images of the DDPM sampling leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--conv-math", choices=("bf16x3", "f32"), default=None,
+                    help="arithmetic of the eligible 3x3 convolutions (default: the library default, bf16x3 split products)")
     return ap.parse_args()
 
 
@@ -126,6 +129,8 @@ def main():
     torch.manual_seed(0)
     net = UNet2DModel(in_channels=3, out_channels=3, sample_size=32, **DDPM_32_ARCH)
     net.reset_parameters(seed=0)                          # identical replicas on every rank
+    if args.conv_math:
+        net.conv_math = args.conv_math
     sched = DDPMScheduler(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, clip_sample=False)
     loss_fn = LossFn(sched, "SDE-VP", psi=1, solver_type="sde")
     loss_fn.noise_seed = 1234 + rank
@@ -168,6 +173,27 @@ def main():
     train_ips = world * B * args.steps / dt
     final_loss = float(loss)
     log(f"train: {train_ips:.1f} img/s ({1e3 * dt / args.steps:.2f} ms/step), loss {final_loss:.4f}")
+
+    # ---- the same K steps with every contraction on the exact-f32 MFMA (reported beside the headline, not as `value`) ----
+    exact = None
+    if net.conv_math != "f32":
+        mode0, net.conv_math = net.conv_math, "f32"
+        for i in range(2):
+            one_step(i)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        torch.cuda.synchronize()
+        barrier()
+        te = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        exact = {"train_images_per_sec": round(world * B * args.steps / float(te), 2), "ms_per_step": round(1e3 * float(te) / args.steps, 3),
+                 "note": "same run, net.conv_math = 'f32': all contractions on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s peak)"}
+        net.conv_math = mode0
+        log(f"exact-f32 mode: {exact}")
 
     # ---- 1000-step DDPM sampling (second half of the metric), embarrassingly parallel ----
     sample_ips, sample_s, secondary = None, None, None
@@ -236,17 +262,23 @@ def main():
             a[0] += 1
             a[1] += flops
             a[2] += e0.elapsed_time(e1)
+        def peak_of(kname):      # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
+            return PEAK_BF16_MFMA_TFLOPS if "bx3" in kname else PEAK_F32_MFMA_TFLOPS
         kernels = sorted(({"kernel": k, "launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / v[2] / 1e9, 2),
-                           "avg_us": round(1e3 * v[2] / v[0], 1)} for k, v in agg.items()), key=lambda r: -r["ms"])
+                           "avg_us": round(1e3 * v[2] / v[0], 1), "peak": peak_of(k)} for k, v in agg.items()), key=lambda r: -r["ms"])
         top = kernels[0]
+        top_peak = peak_of(top["kernel"])
         traffic = None          # HBM bytes per launch from the committed PMC pass (rocprofv3 cannot run inside this process)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 traffic = json.load(f)["kernels"].get(top["kernel"], {}).get("traffic_bytes_per_launch")
         except OSError:
             pass
-        roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": top_peak,
+                    "unit": "TFLOP/s", "frac": round(top["tflops"] / top_peak, 4), "traffic": traffic,
+                    # algorithmic FLOPs (2*M*N*K) above; a split-precision kernel EXECUTES three bf16 MFMAs per product term
+                    "executed_tflops": round(3 * top["tflops"], 2) if "bx3" in top["kernel"] else top["tflops"],
+                    "frac_executed": round((3 if "bx3" in top["kernel"] else 1) * top["tflops"] / top_peak, 4),
                     "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
                     "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
                     "all_mfma_kernels_ms": round(sum(k["ms"] for k in kernels), 2)}
@@ -263,9 +295,14 @@ def main():
             "metric": "train imgs/sec + 1000-step DDPM sample imgs/sec, CIFAR10 bs128",
             "value": round(train_ips, 2), "unit": "train images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3/f32" if net.conv_math == "bf16x3" else "f32", "data": "synthetic",
+            "dtype_note": ("f32 tensors and accumulation; 3x3 convolutions (forward, input and weight gradient at 8x8-32x32) as "
+                           "hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32; the reference trains this "
+                           "config under fp16 autocast); everything else on the f32 MFMA") if net.conv_math == "bf16x3" else
+                          "every contraction on the f32-input MFMA (exact f32)",
+            "exact_f32_mode": exact,
             "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), "
-                                   "per-GPU batch %d, fp32; + %d-step DDPM sampling of %d images/GPU" % (B, args.sample_steps, args.sample_images),
+                                   "per-GPU batch %d; + %d-step DDPM sampling of %d images/GPU" % (B, args.sample_steps, args.sample_images),
                        "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}"},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
             "sample_seconds": None if sample_s is None else round(sample_s, 2),

@@ -36,21 +36,36 @@ if os.path.exists(mp):
     d = json.load(open(mp))
     oldm = json.load(open(os.path.join(dst, f"{rnd}_pmc_mfma.json")))
     om = {"_how": oldm["_how"], "kernels": {}}
+    om["_how"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 "
+                  "SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 2 "
+                  "--sample-images 0 --no-cpu --no-roofline (its own pass, no other tracing; tools/collect_profiles.sh), reduced by "
+                  "tools/pmc_summary.py; per-dispatch averages.  Derived: executed flops = 512 * (MOPS_F32 + MOPS_BF16); a split-precision "
+                  "(bx3) kernel executes 3 bf16 MFMAs per algorithmic product term, so its algorithmic GFLOP = executed / 3; busy cycles per "
+                  "instruction: 64 for v_mfma_f32_32x32x2_f32, 32 for v_mfma_f32_32x32x16_bf16; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so "
+                  "MfmaUtil = MFMA_BUSY / (GUI_ACTIVE/8 * 256 CUs * 4 SIMDs).")
     for k, v in sorted(d.items()):
         g = v.get("GRBM_GUI_ACTIVE", {}).get("avg", 0)
         if not g:
             continue
-        mb, mops, n = v["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"], v["SQ_INSTS_VALU_MFMA_MOPS_F32"]["avg"], v["SQ_INSTS_VALU_MFMA_F32"]["avg"]
+        mb = v["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"]
+        mops32, n32 = v["SQ_INSTS_VALU_MFMA_MOPS_F32"]["avg"], v["SQ_INSTS_VALU_MFMA_F32"]["avg"]
+        mops16, n16 = v.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", {}).get("avg", 0), v.get("SQ_INSTS_VALU_MFMA_BF16", {}).get("avg", 0)
+        n = n32 + n16
+        if not n:
+            continue
+        ex = (mops32 + mops16) * 512 / 1e9
         om["kernels"][k] = {"dispatches": v["GRBM_GUI_ACTIVE"]["dispatches"], "GRBM_GUI_ACTIVE": round(g),
-                            "SQ_VALU_MFMA_BUSY_CYCLES": round(mb), "SQ_BUSY_CU_CYCLES": round(v["SQ_BUSY_CU_CYCLES"]["avg"]),
-                            "SQ_INSTS_VALU_MFMA_MOPS_F32": round(mops), "SQ_INSTS_VALU_MFMA_F32": round(n),
-                            "gflop_per_launch": round(mops * 512 / 1e9, 2), "busy_cycles_per_mfma": round(mb / n, 1),
+                            "SQ_VALU_MFMA_BUSY_CYCLES": round(mb),
+                            "SQ_INSTS_VALU_MFMA_MOPS_F32": round(mops32), "SQ_INSTS_VALU_MFMA_F32": round(n32),
+                            "SQ_INSTS_VALU_MFMA_MOPS_BF16": round(mops16), "SQ_INSTS_VALU_MFMA_BF16": round(n16),
+                            "executed_gflop_per_launch": round(ex, 2),
+                            "gflop_per_launch": round(ex / 3 if "bx3" in k else ex, 2), "busy_cycles_per_mfma": round(mb / n, 1),
                             "MfmaUtil": round(mb / (g / 8 * 1024), 4), "kernel_us_at_2.4GHz": round(g / 8 / 2400, 1)}
     json.dump(om, open(os.path.join(dst, f"{rnd}_pmc_mfma.json"), "w"), indent=1)
 
 b = json.loads(last_line(os.path.join(src, "bench_default.json")))
 r = b["roofline"]
 print(f"value {b['value']} img/s, {b['ms_per_step']} ms/step, sample {b['sample_ddpm1000_images_per_sec']} img/s ({b['sample_seconds']} s), "
-      f"train {b['train_tflops']} TF ({b['train_frac_of_f32_peak']}), sample frac {b['sample_frac_of_f32_peak']}")
-print(f"roofline {r['kernel']}: {r['achieved']} TF frac {r['frac']} avg {r['avg_launch_us']} us traffic {r['traffic']}; mfma total {r['all_mfma_kernels_ms']} ms")
+      f"train {b['train_tflops']} TF ({b['train_frac_of_f32_peak']}), sample frac {b['sample_frac_of_f32_peak']}; exact-f32 mode {b.get('exact_f32_mode')}")
+print(f"roofline {r['kernel']}: {r['achieved']} TF frac {r['frac']} (executed {r.get('frac_executed')}) avg {r['avg_launch_us']} us traffic {r['traffic']}; mfma total {r['all_mfma_kernels_ms']} ms")
 print("cpu", b["cpu_baseline"]["value"], b["cpu_baseline"]["sample_ddpm1000_images_per_sec"])
