@@ -87,8 +87,9 @@ typedef struct vd_gemm_desc {
                                 of x (GroupNorm + SiLU folded into the patch loader: inference path, nothing is saved).
                                 Needs the patch-staged kernel (OW >= 16, C % 8 == 0, C <= 1024, M >= 64)              */
     const void* a_packed;    /* nullable.  3x3 convolutions (VD_B_CONV3 / _T / _UP at 8x8, 16x16, 32x32 outputs, C % 16 == 0,
+                                M >= 64) and VD_B_PLAIN products with a shared A (1x1 convolutions: NP % 128 == 0, K % 16 == 0,
                                 M >= 64) only: the weights pre-split into bf16 (hi, lo) pairs by vd_conv3_pack_weights.  The
-                                convolution then runs as three bf16 MFMAs per product term (hi*hi + hi*lo + lo*hi, f32
+                                contraction then runs as three bf16 MFMAs per product term (hi*hi + hi*lo + lo*hi, f32
                                 accumulation; ~1e-5 relative to the exact-f32 kernel) instead of on the f32 MFMA.  A is still
                                 required (shape checks) but not read.  Problems outside that set fail with VD_EINVAL.   */
     int32_t a_packed_mpad;   /* row count the packed operand was built with (M rounded up to 128)                      */
@@ -100,7 +101,7 @@ int vd_gemm(const vd_gemm_desc* desc, void* stream);
 int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
 /* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4 / 6: patch-staged 3x3
  * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel, 7: direct 3x3 convolution for <= 4 output
- * channels, 8: split-precision bf16 convolution (a_packed), -1: a_packed given for an unsupported problem (profiling / tests). */
+ * channels, 8 / 9: split-precision bf16 3x3 convolution / plain product (a_packed), -1: a_packed given for an unsupported problem (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):
@@ -119,7 +120,8 @@ typedef struct vd_wgrad_desc {
     int64_t dy_bstride, x_bstride;
     int32_t pad;              /* VD_B_CONV3_S2 only, as in vd_gemm_desc                         */
     int32_t math;             /* 0: exact f32 MFMA.  1: split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulation,
-                                 ~1e-5 relative): VD_B_CONV3 at 8x8 / 16x16 / 32x32, M >= 64, C >= 64; otherwise VD_EINVAL */
+                                 ~1e-5 relative): VD_B_CONV3 / VD_B_CONV3_UP with 8x8 / 16x16 / 32x32 outputs, or VD_B_PLAIN (1x1) with
+                                 NP % 8 == 0; M >= 64, C >= 64; otherwise VD_EINVAL */
 } vd_wgrad_desc;
 
 int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);
@@ -128,15 +130,16 @@ int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc);
 /* Tile and split count vd_conv_wgrad will use (profiling / tests). */
 int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits);
 
-/* Split-precision operand for vd_gemm_desc.a_packed: element (m, c, t) of the logical [M][C][9] matrix is read from
- * W[m*row_stride + c*chan_stride + t] (plain weights: row_stride = C*9, chan_stride = 9; the transposed operand of the
- * stride-1 dgrad, A'[c_in][m_out] = W[m_out][c_in]: row_stride = 9, chan_stride = C_in*9 with M = C_in, C = M_out) and stored
- * as bf16 hi = bf16(w), lo = bf16(w - hi) in the kernel's fragment order.  `packed` holds vd_conv3_packed_bytes(M, C) bytes,
- * 16-byte aligned; C % 16 == 0. */
-int64_t vd_conv3_packed_bytes(int M, int C);
-int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int64_t row_stride, int64_t chan_stride, void* stream);
+/* Split-precision operand for vd_gemm_desc.a_packed.  taps = 9: element (m, c, t) of the logical [M][C][9] matrix of a 3x3
+ * convolution is read from W[m*row_stride + c*chan_stride + t] (plain weights: row_stride = C*9, chan_stride = 9; the transposed
+ * operand of the stride-1 dgrad, A'[c_in][m_out] = W[m_out][c_in]: row_stride = 9, chan_stride = C_in*9 with M = C_in, C = M_out).
+ * taps = 1: element (m, c) of a plain [M][C] matrix (1x1 convolution, attention projection) from W[m*row_stride + c*chan_stride]
+ * (row-major: (C, 1); its transpose: (1, M_out-row length)).  Stored as bf16 hi = bf16(w), lo = bf16(w - hi) in the kernel's
+ * fragment order.  `packed` holds vd_conv3_packed_bytes(M, C, taps) bytes, 16-byte aligned; C % 16 == 0. */
+int64_t vd_conv3_packed_bytes(int M, int C, int taps);
+int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int taps, int64_t row_stride, int64_t chan_stride, void* stream);
 /* The same for n_jobs operands in one launch (all convolutions of a network after an optimizer step).  table: DEVICE array of
- * int64 [n_jobs][8] = {W address, packed address, M, C, row_stride, chan_stride, first workgroup of the job, 0}; job j owns
+ * int64 [n_jobs][8] = {W address, packed address, M, C, row_stride, chan_stride, first workgroup of the job, taps}; job j owns
  * ceil(Mpad_j * C_j / 8 / 256) workgroups of 256 threads, first-workgroup numbers ascending from 0; total_blocks = their sum. */
 int vd_conv3_pack_weights_multi(const int64_t* table, int n_jobs, int64_t total_blocks, void* stream);
 

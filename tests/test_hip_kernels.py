@@ -559,28 +559,32 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
     check(dx, x.grad, BX3_TOL, f"bf16x3 dgrad {Cin}->{Cout}@{H}")
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H", [(4, 128, 128, 32), (3, 192, 64, 32), (2, 256, 256, 16), (5, 64, 200, 16), (6, 256, 128, 8),
-                                          (1, 64, 64, 8), (128, 128, 128, 8)])
-def test_split_precision_weight_gradient(B, Cin, Cout, H):
+@pytest.mark.parametrize("B,Cin,Cout,H,mode", [(4, 128, 128, 32, B_CONV3), (3, 192, 64, 32, B_CONV3), (2, 256, 256, 16, B_CONV3),
+                                               (5, 64, 200, 16, B_CONV3), (6, 256, 128, 8, B_CONV3), (1, 64, 64, 8, B_CONV3),
+                                               (128, 128, 128, 8, B_CONV3), (3, 128, 128, 16, B_CONV3_UP), (2, 256, 64, 8, B_CONV3_UP),
+                                               (5, 64, 96, 4, B_CONV3_UP)])
+def test_split_precision_weight_gradient(B, Cin, Cout, H, mode):
+    """H is the INPUT side; B_CONV3_UP: the weight gradient through the fused nearest-2x upsample (output 2H x 2H)."""
     x = torch.randn(B, Cin, H, H, generator=g(0))
     w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)).requires_grad_()
-    y = F.conv2d(x, w, None, padding=1)
+    y = ref_conv(x, w, None, mode)
     dy = torch.randn(y.shape, generator=g(2))
     y.backward(dy)
-    assert ops.wgrad_bx3_eligible(Cout, Cin, H, H, B_CONV3)
+    OH = y.shape[-1]
+    assert ops.wgrad_bx3_eligible(Cout, Cin, OH, OH, mode)
     xbuf = torch.zeros(B, Cin + 4, H, H, device=DEV)
     xbuf[:, 4:] = x.to(DEV)
-    need = ops.wgrad_ws_floats(Cout, Cin, 9, B, H * H, mode=B_CONV3, math_mode=1)
+    need = ops.wgrad_ws_floats(Cout, Cin, 9, B, OH * OH, mode=mode, math_mode=1)
     ws = torch.empty(max(need, 4), device=DEV)
     dw = torch.full((Cout, Cin * 9), 0.5, device=DEV)
-    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw, B_CONV3, ws, accumulate=True, math_mode=1)
-    check(dw - 0.5, w.grad.view(Cout, -1), BX3_TOL, f"bf16x3 wgrad {Cin}->{Cout}@{H} (ws {need})")
+    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw, mode, ws, accumulate=True, math_mode=1)
+    check(dw - 0.5, w.grad.view(Cout, -1), BX3_TOL, f"bf16x3 wgrad mode={mode} {Cin}->{Cout}@{H} (ws {need})")
     dw2 = torch.empty_like(dw)
-    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw2, B_CONV3, ws, accumulate=False, splits=1, math_mode=1)
+    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw2, mode, ws, accumulate=False, splits=1, math_mode=1)
     check(dw2, w.grad.view(Cout, -1), BX3_TOL, "bf16x3 wgrad splits=1")
     dw3 = torch.empty_like(dw)                                  # deterministic: same launch, same bits
-    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw3, B_CONV3, ws, accumulate=False, math_mode=1)
-    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw2, B_CONV3, ws, accumulate=False, math_mode=1)
+    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw3, mode, ws, accumulate=False, math_mode=1)
+    ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw2, mode, ws, accumulate=False, math_mode=1)
     assert torch.equal(dw2, dw3)
 
 
@@ -595,3 +599,44 @@ def test_split_precision_requests_outside_the_supported_set_fail_loudly():
     with pytest.raises(VillanHipError):                                      # 64x64 image: not a split-precision tile size
         ops.conv_wgrad(torch.randn(2, 64, 64, 64, device=DEV), x2, torch.empty(64, 64 * 9, device=DEV), B_CONV3,
                        torch.empty(1 << 22, device=DEV), math_mode=1)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(16, 256, 768, 16), (8, 512, 256, 16), (4, 384, 128, 32), (12, 256, 200, 16), (3, 80, 64, 32),
+                                          (5, 192, 96, 16)])
+def test_split_precision_1x1_convolution_and_its_input_gradient(B, Cin, Cout, H):
+    """gemm_bx3_kernel: W[M, C] @ x[b][C, HW] from the packed (hi, lo) weights; K = 80 / 200 exercise the tail stage (K % 64 != 0)."""
+    x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g(1)) / math.sqrt(Cin)).requires_grad_()
+    b = torch.randn(Cout, generator=g(2))
+    res = torch.randn(B, Cout, H, H, generator=g(3))
+    y0 = F.conv2d(x, w, b)
+    y_ref = y0 + res
+    assert ops.gemm_bx3_eligible(Cout, Cin, H * H)
+    wd = w.detach().to(DEV).view(Cout, Cin)
+    pk = ops.conv3_pack_weights(wd, Cout, Cin, taps=1)
+    xbuf = torch.zeros(B, Cin + 2, H, H, device=DEV)
+    xbuf[:, 2:] = x.detach().to(DEV)
+    obuf = torch.full((B, Cout + 2, H, H), 7.0, device=DEV)
+    ops.conv1x1(xbuf[:, 2:], wd, b.to(DEV), obuf[:, 1:1 + Cout], residual=res.to(DEV), a_packed=pk)
+    check(obuf[:, 1:1 + Cout], y_ref.detach(), BX3_TOL, f"bf16x3 1x1 {Cin}->{Cout}@{H}")
+    assert float((obuf[:, 0] - 7).abs().max()) == 0 and float((obuf[:, -1] - 7).abs().max()) == 0
+    if Cout % 16 != 0 or Cin < 64:
+        return
+    dy = torch.randn(y0.shape, generator=g(4))
+    y0.backward(dy)
+    pkt = ops.conv3_pack_weights(wd, Cin, Cout, transposed=True, taps=1)
+    dx = torch.empty(B, Cin, H, H, device=DEV)
+    HW = H * H
+    ops.gemm(wd, dy.to(DEV), dx, M=Cin, N=B * HW, K=Cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=Cin, ldb=HW, b_bstride=Cout * HW,
+             ldd=HW, d_bstride=Cin * HW, a_packed=pkt)
+    check(dx, x.grad, BX3_TOL, f"bf16x3 1x1 dgrad {Cin}->{Cout}@{H}")
+    # weight gradient: both operands pixel-contiguous, K-steps of 64 pixels, deterministic slab reduction
+    assert ops.wgrad_bx3_eligible(Cout, Cin, H, H, B_PLAIN)
+    need = ops.wgrad_ws_floats(Cout, Cin, 1, B, HW, mode=B_PLAIN, math_mode=1)
+    ws = torch.empty(max(need, 4), device=DEV)
+    dw = torch.full((Cout, Cin), 0.25, device=DEV)
+    ops.conv_wgrad(dy.to(DEV), xbuf[:, 2:], dw, B_PLAIN, ws, accumulate=True, math_mode=1)
+    check(dw - 0.25, w.grad.view(Cout, Cin), BX3_TOL, f"bf16x3 1x1 wgrad {Cin}->{Cout}@{H} (ws {need})")
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(dy.to(DEV), xbuf[:, 2:], dw2, B_PLAIN, ws, accumulate=False, splits=1, math_mode=1)
+    check(dw2, w.grad.view(Cout, Cin), BX3_TOL, "bf16x3 1x1 wgrad splits=1")

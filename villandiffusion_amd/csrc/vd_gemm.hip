@@ -1531,8 +1531,9 @@ static int wgrad_patch_kind(const vd_wgrad_desc& d) {
     if (d.T != 9 || (d.mode != VD_B_CONV3 && d.mode != VD_B_CONV3_UP)) return 0;
     if (d.NP != d.OH * d.OW || d.M < 64 || d.C < 64 || d.tile != 0) return 0;
     if (d.math == 1) {      // split-precision kernel (explicit request): stride-1 3x3 at 8x8 / 16x16 / 32x32
-        if (d.mode == VD_B_CONV3 && d.OH == d.OW && (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.H == d.OH && d.W == d.OW &&
-            (d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0))
+        const bool up = d.mode == VD_B_CONV3_UP;
+        if ((d.mode == VD_B_CONV3 || up) && d.OH == d.OW && (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.H * (up ? 2 : 1) == d.OH &&
+            d.W * (up ? 2 : 1) == d.OW && (d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0))
             return 4;
         return -1;
     }
@@ -1809,7 +1810,7 @@ extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
 extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
-    if (d.a_packed) return bx3_eligible(d) ? 8 : -1;
+    if (d.a_packed) return bx3_eligible(d) ? 8 : (gemm_bx3_eligible(d) ? 9 : -1);
     if (smallm_eligible(d)) return 7;                        // direct convolution for <= 4 output channels
     if (patch_eligible(d)) {
         int splits, ks_per;
@@ -1840,8 +1841,9 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         VD_REQUIRE(!d.residual && !d.rowadd && !d.d_trans && d.b_mode <= VD_B_KCONTIG && (d.N / d.NP) % d.nb2 == 0,
                    "vd_gemm: two-level batch (nb2=%d) needs plain operands, no residual/rowadd, nb %% nb2 == 0", d.nb2);
     const int tile = vd_gemm_tile(&d);
-    VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16 convolution) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 "
-                           "outputs, C %% 16 == 0, M >= 64, a_packed_mpad = M rounded up to 128");
+    VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, "
+                           "C %% 16 == 0, M >= 64, or a VD_B_PLAIN product with shared A, NP %% 128 == 0, K %% 16 == 0, M >= 64; "
+                           "a_packed_mpad = M rounded up to 128");
     VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     hipStream_t st = (hipStream_t)stream;
@@ -1854,6 +1856,10 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
         case 8: rc = launch_bx3(d, st); break;
+        case 9:
+            hipLaunchKernelGGL(gemm_bx3_kernel, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
+            rc = 0;
+            break;
         case 5: {
             const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
             if (d.a_mode == VD_A_ROW)
@@ -1870,18 +1876,20 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     return 0;
 }
 
-extern "C" int64_t vd_conv3_packed_bytes(int M, int C) {
-    if (M <= 0 || C <= 0 || C % XC != 0) return 0;
-    return (int64_t)((M + 127) / 128 * 128) * C * 9 * 4;
+extern "C" int64_t vd_conv3_packed_bytes(int M, int C, int taps) {
+    if (M <= 0 || C <= 0 || C % XC != 0 || (taps != 9 && taps != 1)) return 0;
+    return (int64_t)((M + 127) / 128 * 128) * C * taps * 4;
 }
 
-extern "C" int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int64_t row_stride, int64_t chan_stride, void* stream) {
-    VD_REQUIRE(W && packed && M > 0 && C > 0 && C % XC == 0, "vd_conv3_pack_weights: bad arguments (M=%d C=%d, C %% 16 == 0)", M, C);
+extern "C" int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int taps, int64_t row_stride, int64_t chan_stride,
+                                     void* stream) {
+    VD_REQUIRE(W && packed && M > 0 && C > 0 && C % XC == 0 && (taps == 9 || taps == 1),
+               "vd_conv3_pack_weights: bad arguments (M=%d C=%d taps=%d; C %% 16 == 0, taps 9 or 1)", M, C, taps);
     VD_REQUIRE((((uintptr_t)packed) & 15) == 0, "vd_conv3_pack_weights: packed must be 16-byte aligned");
     const int Mpad = (M + 127) / 128 * 128;
     const int total = (C / XC) * 2 * Mpad;
     hipLaunchKernelGGL(conv3_pack_kernel, dim3(vd_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W,
-                       reinterpret_cast<u32x4*>(packed), M, C, Mpad, row_stride, chan_stride);
+                       reinterpret_cast<u32x4*>(packed), M, C, Mpad, row_stride, chan_stride, taps);
     VD_LAUNCH_CHECK("vd_conv3_pack_weights");
     return 0;
 }
@@ -1894,6 +1902,11 @@ extern "C" int vd_conv3_pack_weights_multi(const int64_t* table, int n_jobs, int
 }
 
 static void wgrad_plan(const vd_wgrad_desc& d, int& tile, int& splits, int& kk_per) {
+    if (wgrad1x1_bx3_eligible(d)) {
+        tile = 5;
+        wgrad1x1_bx3_plan(d, splits, kk_per);
+        return;
+    }
     if (wgrad_patch_eligible(d)) {
         tile = 4;
         wgrad_patch_plan(d, splits, kk_per);
@@ -1940,8 +1953,9 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
     if (d.mode == VD_B_PLAIN)
         VD_REQUIRE((d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0) && d.H * d.W == d.NP,
                    "vd_conv_wgrad: 1x1 X alignment");
-    VD_REQUIRE(d.math == 0 || wgrad_patch_kind(d) == 4, "vd_conv_wgrad: math = 1 (split-precision bf16) needs a stride-1 3x3 "
-               "convolution at 8x8 / 16x16 / 32x32 with M >= 64, C >= 64, 16-byte aligned X");
+    VD_REQUIRE(d.math == 0 || wgrad_patch_kind(d) == 4 || wgrad1x1_bx3_eligible(d),
+               "vd_conv_wgrad: math = 1 (split-precision bf16) needs a stride-1 3x3 convolution with 8x8 / 16x16 / 32x32 outputs or a "
+               "1x1 convolution with NP %% 8 == 0; M >= 64, C >= 64, 16-byte aligned operands");
     const int Ncols = d.C * d.T;
     int tile, splits, kk_per;
     wgrad_plan(d, tile, splits, kk_per);
@@ -1953,9 +1967,16 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
             dim3 grid(vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3, splits);
             rc = 0;
             if (wgrad_patch_kind(d) == 4) {
-                if (d.OW == 32) hipLaunchKernelGGL((wgrad_bx3_kernel<32>), grid, dim3(NT), 0, st, d, kk_per);
-                else if (d.OW == 16) hipLaunchKernelGGL((wgrad_bx3_kernel<16>), grid, dim3(NT), 0, st, d, kk_per);
-                else hipLaunchKernelGGL((wgrad_bx3_kernel<8>), grid, dim3(NT), 0, st, d, kk_per);
+                const bool up = d.mode == VD_B_CONV3_UP;
+#define VD_WBX3(WW)                                                                                     \
+    do {                                                                                                \
+        if (up) hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 2>), grid, dim3(NT), 0, st, d, kk_per);        \
+        else hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 0>), grid, dim3(NT), 0, st, d, kk_per);           \
+    } while (0)
+                if (d.OW == 32) VD_WBX3(32);
+                else if (d.OW == 16) VD_WBX3(16);
+                else VD_WBX3(8);
+#undef VD_WBX3
             } else if (wgrad_patch_kind(d) == 3) {
                 const int ohs = ilog2_exact(d.OH);
                 const bool up = d.mode == VD_B_CONV3_UP;
@@ -1993,6 +2014,10 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
                 hipLaunchKernelGGL((wgrad_patch_kernel<16, 2>), grid, dim3(NT), 0, st, d, kk_per);
             break;
         }
+        case 5:
+            hipLaunchKernelGGL(wgrad1x1_bx3_kernel, dim3(vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128), splits), dim3(NT), 0, st, d, kk_per);
+            rc = 0;
+            break;
         case 1: rc = launch_wgrad_t<2, 2>(d, splits, kk_per, st); break;
         case 2: rc = launch_wgrad_t<1, 2>(d, splits, kk_per, st); break;
         case 3: rc = launch_wgrad_t<1, 1>(d, splits, kk_per, st); break;

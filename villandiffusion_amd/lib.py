@@ -51,8 +51,8 @@ PROTOTYPES = {
     "vd_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "vd_conv_wgrad_plan": (_i32, [C.POINTER(WgradDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),
-    "vd_conv3_packed_bytes": (_i64, [_i32, _i32]),
-    "vd_conv3_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _vp]),
+    "vd_conv3_packed_bytes": (_i64, [_i32, _i32, _i32]),
+    "vd_conv3_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_conv3_pack_weights_multi": (_i32, [_vp, _i32, _i64, _vp]),
     "vd_weight_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),

@@ -105,7 +105,9 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     e1.record()
     flops = 2.0 * M * N * K * (0.25 if b_mode == B_CONV3_DIL else 1.0)     # DIL: 3/4 of the taps are structural zeros
     tl = lib.vd_gemm_tile(C.byref(d))
-    if tl == 8:
+    if tl == 9:
+        name = "gemm_bx3_kernel"
+    elif tl == 8:
         md = 0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
         name = f"conv3_bx3_kernel<{d.OW}, {md}, 2>"
     elif tl in (4, 6):     # symbol names as rocprofv3 prints them
@@ -126,18 +128,18 @@ _CONV_OUT = {B_CONV3: lambda h, w: (h, w), B_CONV3_T: lambda h, w: (h, w), B_CON
              B_CONV3_UP: lambda h, w: (2 * h, 2 * w), B_CONV3_DIL: lambda h, w: (2 * h, 2 * w)}
 
 
-def conv3_pack_weights(w2d, M, Cc, transposed=False, out=None):
-    """Split-precision operand of conv3x3(a_packed=...): the [M, Cc*9] weights as bf16 (hi, lo) pairs in MFMA fragment order.
-    transposed=True packs the dgrad operand A'[c_in][m_out] straight from the forward weights w2d [m_out, c_in*9] (then
-    M = c_in, Cc = m_out)."""
+def conv3_pack_weights(w2d, M, Cc, transposed=False, out=None, taps=9):
+    """Split-precision operand of conv3x3 / conv1x1 (a_packed=...): the [M, Cc*taps] weights as bf16 (hi, lo) pairs in MFMA
+    fragment order.  transposed=True packs the dgrad operand A'[c_in][m_out] straight from the forward weights w2d
+    [m_out, c_in*taps] (then M = c_in, Cc = m_out)."""
     lib = _lib()
-    nbytes = lib.vd_conv3_packed_bytes(M, Cc)
-    assert nbytes > 0, (M, Cc)
+    nbytes = lib.vd_conv3_packed_bytes(M, Cc, taps)
+    assert nbytes > 0, (M, Cc, taps)
     if out is None:
         out = torch.empty(nbytes // 4, device=w2d.device, dtype=torch.int32)
     assert out.numel() * out.element_size() >= nbytes and w2d.is_contiguous()
-    rs, cs = (9, M * 9) if transposed else (Cc * 9, 9)
-    L.check(lib.vd_conv3_pack_weights(_p(w2d), _p(out), M, Cc, rs, cs, _s()), "vd_conv3_pack_weights")
+    rs, cs = (taps, M * taps) if transposed else (Cc * taps, taps)
+    L.check(lib.vd_conv3_pack_weights(_p(w2d), _p(out), M, Cc, taps, rs, cs, _s()), "vd_conv3_pack_weights")
     return out
 
 
@@ -177,7 +179,12 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
                 pad=pad, gn_ss=gn_ss, a_packed=a_packed)
 
 
-def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0):
+def gemm_bx3_eligible(M, K, NP) -> bool:
+    """1x1 convolutions / plain products the split-precision GEMM kernel takes (vd_gemm_desc.a_packed, shared A)."""
+    return NP % 128 == 0 and K % 16 == 0 and M >= 64
+
+
+def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0, a_packed=None):
     """1x1 convolution on NCHW = batched GEMM W[M,C] @ x[b][C, HW]."""
     Bn, Cc, H, W, xbs = _img(x)
     M = w2d.shape[0]
@@ -187,7 +194,7 @@ def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0):
     rbs = _img(residual)[4] if residual is not None else 0
     HW = H * W
     return gemm(w2d, x, out, M=M, N=Bn * HW, K=Cc, b_mode=B_PLAIN, NP=HW, lda=Cc, ldb=HW, b_bstride=xbs, ldd=HW,
-                d_bstride=obs, bias=bias, residual=residual, res_bstride=rbs, accumulate=accumulate, tile=tile)
+                d_bstride=obs, bias=bias, residual=residual, res_bstride=rbs, accumulate=accumulate, tile=tile, a_packed=a_packed)
 
 
 def linear(x, w, bias, out, accumulate=False):
@@ -245,8 +252,10 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     e1.record()
     tl, sp = C.c_int32(0), C.c_int32(0)
     lib.vd_conv_wgrad_plan(C.byref(d), C.byref(tl), C.byref(sp))
-    if tl.value == 4 and math_mode == 1:
-        name = f"wgrad_bx3_kernel<{OW}>(+slab_reduce)"
+    if tl.value == 5:
+        name = "wgrad1x1_bx3_kernel(+slab_reduce)"
+    elif tl.value == 4 and math_mode == 1:
+        name = f"wgrad_bx3_kernel<{OW}, {0 if mode == B_CONV3 else 2}>(+slab_reduce)"
     elif tl.value == 4:
         name = f"wgrad_patch_kernel<{OW}, {0 if mode == B_CONV3 else 2}>(+slab_reduce)"
     else:
@@ -257,7 +266,9 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
 
 def wgrad_bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision weight-gradient kernel takes (vd_wgrad_desc.math = 1)."""
-    return mode == B_CONV3 and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
+    if mode == B_PLAIN:
+        return (OH * OW) % 8 == 0 and M >= 64 and Cc >= 64
+    return mode in (B_CONV3, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
 
 
 def wgrad_ws_floats(M, Cc, T, nb, NP, OH=None, OW=None, mode=None, math_mode=0) -> int:
@@ -268,7 +279,7 @@ def wgrad_ws_floats(M, Cc, T, nb, NP, OH=None, OW=None, mode=None, math_mode=0) 
     d.M, d.C, d.T, d.nb, d.NP, d.OH, d.OW = M, Cc, T, nb, NP, OH, OW
     d.mode = (B_PLAIN if T == 1 else B_CONV3) if mode is None else mode
     if math_mode:
-        d.math, d.H, d.W = math_mode, OH, OW
+        d.math, d.H, d.W = math_mode, (OH // 2 if d.mode == B_CONV3_UP else OH), (OW // 2 if d.mode == B_CONV3_UP else OW)
     return int(L.load().vd_conv_wgrad_ws_floats(C.byref(d)))
 
 

@@ -55,18 +55,24 @@ class _PackedConvWeights:
 
     def __init__(self, net):
         self.net = net
-        self.off = {False: {}, True: {}}                 # bwd? -> prefix -> (offset, n) in int32 elements
-        self.jobs = {False: [], True: []}                # (prefix, M, C, row_stride, chan_stride) of the packed operand
+        self.off = {False: {}, True: {}}                 # bwd? -> key -> (offset, n) in int32 elements
+        self.jobs = {False: [], True: []}                # (key, source tensor getter, M, C, taps, row_stride, chan_stride)
         self.total = 0
+        cands = []                                       # (key, getter of the [cout, cin*taps] weights, cout, cin, taps)
         for name, shape, _ in net._layout:
-            if not (name.endswith(".weight") and len(shape) == 4 and shape[2] == 3):
-                continue
-            prefix, cout, cin = name[:-7], shape[0], shape[1]
-            for bwd, (M, Cc, rs, cs) in ((False, (cout, cin, cin * 9, 9)), (True, (cin, cout, 9, cin * 9))):
+            if name.endswith(".weight") and len(shape) == 4 and shape[2] == shape[3] and shape[2] in (1, 3):
+                cands.append((name[:-7], (lambda n=name: net.P[n]), shape[0], shape[1], shape[2] * shape[3]))
+        for prefix, ch in getattr(net, "_qkv", []):      # attention projections: fused q/k/v [3C, C] and to_out [C, C] (1x1 convolutions)
+            if prefix + "::qkv_w" in getattr(net, "Pq", {}):
+                cands.append((prefix + "::qkv", (lambda k=prefix + "::qkv_w": net.Pq[k]), 3 * ch, ch, 1))
+            if prefix + ".to_out.0.weight" in net.P:
+                cands.append((prefix + ".to_out.0", (lambda n=prefix + ".to_out.0.weight": net.P[n]), ch, ch, 1))
+        for key, get, cout, cin, T in cands:
+            for bwd, (M, Cc, rs, cs) in ((False, (cout, cin, cin * T, T)), (True, (cin, cout, T, cin * T))):
                 if Cc % 16 == 0 and M >= 64:
-                    n = (M + 127) // 128 * 128 * Cc * 9
-                    self.off[bwd][prefix] = (self.total, n)
-                    self.jobs[bwd].append((prefix, M, Cc, rs, cs))
+                    n = (M + 127) // 128 * 128 * Cc * T
+                    self.off[bwd][key] = (self.total, n)
+                    self.jobs[bwd].append((key, get, M, Cc, T, rs, cs))
                     self.total += n
         self.buf: Optional[torch.Tensor] = None
         self.tables = {}
@@ -84,9 +90,9 @@ class _PackedConvWeights:
                 self.buf = torch.empty(self.total, device=net.flat_param.device, dtype=torch.int32)
             if bwd not in self.tables:
                 rows, blk = [], 0
-                for pfx, M, Cc, rs, cs in self.jobs[bwd]:
-                    o, n = self.off[bwd][pfx]
-                    rows.append([net.P[pfx + ".weight"].data_ptr(), self.buf.data_ptr() + 4 * o, M, Cc, rs, cs, blk, 0])
+                for k, get, M, Cc, T, rs, cs in self.jobs[bwd]:
+                    o, n = self.off[bwd][k]
+                    rows.append([get().data_ptr(), self.buf.data_ptr() + 4 * o, M, Cc, rs, cs, blk, T])
                     blk += ((M + 127) // 128 * 128 * (Cc // 16) * 2 + 255) // 256
                 self.tables[bwd] = (torch.tensor(rows, dtype=torch.int64).to(self.buf.device), len(rows), blk)
             tab, nj, blk = self.tables[bwd]
@@ -103,6 +109,23 @@ def _bx3_packed(net, prefix, bwd, M, Cc, OH, OW, mode):
     if pk is None:
         pk = net._packed = _PackedConvWeights(net)
     return pk.view(prefix, bwd)
+
+
+def _bx3_packed_1x1(net, key, bwd, M, K, NP):
+    """Packed operand of a 1x1 convolution / projection for ops.conv1x1 / ops.gemm(a_packed=...), or None (exact-f32 kernels)."""
+    if getattr(net, "conv_math", "f32") != "bf16x3" or not ops.gemm_bx3_eligible(M, K, NP):
+        return None
+    pk = getattr(net, "_packed", None)
+    if pk is None:
+        pk = net._packed = _PackedConvWeights(net)
+    return pk.view(key, bwd)
+
+
+def _wgrad1x1_math(net, dy, x) -> int:
+    """vd_wgrad_desc.math for a 1x1 weight gradient dW[M, C] = sum dy x^T."""
+    ok = getattr(net, "conv_math", "f32") == "bf16x3" and ops.wgrad_bx3_eligible(dy.shape[1], x.shape[1], dy.shape[2], dy.shape[3], B_PLAIN) \
+        and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0
+    return int(ok)
 
 
 class _Conv:
@@ -220,7 +243,8 @@ class _Resnet:
             ss2 = self.norm2.stats(h1)
             if self.has_sc:
                 ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
-                            net.P[self.prefix + ".conv_shortcut.bias"], out)
+                            net.P[self.prefix + ".conv_shortcut.bias"], out,
+                            a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W))
                 self.conv2.fwd(h1, out, residual=out, gn_ss=ss2)
             else:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
@@ -233,7 +257,8 @@ class _Resnet:
         m2, r2 = self.norm2.fwd(h1, a2)
         if self.has_sc:
             ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
-                        net.P[self.prefix + ".conv_shortcut.bias"], out)
+                        net.P[self.prefix + ".conv_shortcut.bias"], out,
+                        a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W))
             self.conv2.fwd(a2, out, residual=out)
         else:
             self.conv2.fwd(a2, out, residual=x)
@@ -261,12 +286,13 @@ class _Resnet:
         if self.has_sc:
             wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
             ops.conv_wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
-                           net.wgrad_ws, accumulate=True)
+                           net.wgrad_ws, accumulate=True, math_mode=_wgrad1x1_math(net, dout, x))
             net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout)
             dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
             HW = H * W
             ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
-                     ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW)
+                     ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
+                     a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW))
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc)
         else:
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dout)
@@ -296,7 +322,7 @@ class _Attn:
         g = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         mean, rstd = self.norm.fwd(x, g)
         qkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
-        ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv)
+        ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", False, 3 * Cc, Cc, N))
         o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
         P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
@@ -324,7 +350,8 @@ class _Attn:
             # o[c][i] = sum_j v[c][j] P[j][i]
             ops.gemm(v, P, o, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
                      b_bstride=N * N, ldd=N, d_bstride=Cc * N)
-        ops.conv1x1(o, net.P[self.prefix + ".to_out.0.weight"], net.P[self.prefix + ".to_out.0.bias"], out, residual=x)
+        ops.conv1x1(o, net.P[self.prefix + ".to_out.0.weight"], net.P[self.prefix + ".to_out.0.bias"], out, residual=x,
+                    a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", False, Cc, Cc, N))
         if save:
             return (x, mean, rstd, g, qkv, P, o)
         return None
@@ -336,13 +363,14 @@ class _Attn:
         N = H * W
         dev = x.device
         wo = net.P[self.prefix + ".to_out.0.weight"]
-        ops.conv_wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, net.wgrad_ws, accumulate=True)
+        ops.conv_wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, net.wgrad_ws, accumulate=True,
+                       math_mode=_wgrad1x1_math(net, dout, o))
         bias_ws = net.scratch_bc(B, Cc)
         ops.rowsum(dout, bias_ws)
         net.colsum_later(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc)
         do = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(wo, dout, do, M=Cc, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
-                 b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N)
+                 b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N))
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
         if nh > 1:
@@ -383,13 +411,13 @@ class _Attn:
             # dk[c][j] = sum_i q[c][i] dS[j][i]
             ops.gemm(q, dP, dk, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=bs, ldb=N,
                      b_bstride=N * N, ldd=N, d_bstride=bs)
-        ops.conv_wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, net.wgrad_ws, accumulate=True)
+        ops.conv_wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, net.wgrad_ws, accumulate=True, math_mode=_wgrad1x1_math(net, dqkv, g))
         ws3 = net.scratch_bc(B, 3 * Cc)
         ops.rowsum(dqkv, ws3)
         net.colsum_later(ws3, net.Gq[self.qkv_b], B, 3 * Cc)
         dg = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(net.Pq[self.qkv_w], dqkv, dg, M=Cc, N=B * N, K=3 * Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
-                 b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N)
+                 b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", True, Cc, 3 * Cc, N))
         self.norm.bwd(dg, x, mean, rstd, dx, extra=dout)
         return dx
 
@@ -725,11 +753,17 @@ class UNet2DModel(nn.Module):
                         for md in ((B_PLAIN,) if T == 1 else (B_CONV3, B_CONV3_UP, B_CONV3_S2)):
                             need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=md))
                         side = int(round(math.sqrt(hw)))
-                        if T == 9 and ops.wgrad_bx3_eligible(M, Cc, side, side, B_CONV3):
-                            need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=B_CONV3, math_mode=1))
+                        for md in (B_CONV3, B_CONV3_UP):
+                            if T == 9 and ops.wgrad_bx3_eligible(M, Cc, side, side, md):
+                                need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=md, math_mode=1))
+                        if T == 1 and ops.wgrad_bx3_eligible(M, Cc, side, side, B_PLAIN):
+                            need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=B_PLAIN, math_mode=1))
             for prefix, ch in self._qkv:
                 for hw in {(S >> k) ** 2 for k in range(len(self.config.block_out_channels))}:
                     need = max(need, ops.wgrad_ws_floats(3 * ch, ch, 1, B, hw), ops.wgrad_ws_floats(ch, ch, 1, B, hw))
+                    if hw % 8 == 0 and ch >= 64:
+                        need = max(need, ops.wgrad_ws_floats(3 * ch, ch, 1, B, hw, mode=B_PLAIN, math_mode=1),
+                                   ops.wgrad_ws_floats(ch, ch, 1, B, hw, mode=B_PLAIN, math_mode=1))
             self.wgrad_ws = torch.empty(max(need, 4), device=self._dev, dtype=torch.float32)
             self._ws_B = B
 
