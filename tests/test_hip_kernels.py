@@ -520,6 +520,7 @@ BX3_CASES = [
     (4, 128, 128, 32, B_CONV3), (2, 256, 128, 32, B_CONV3), (3, 384, 192, 32, B_CONV3), (2, 256, 256, 16, B_CONV3), (3, 512, 200, 16, B_CONV3),
     (5, 256, 256, 8, B_CONV3), (1, 64, 64, 8, B_CONV3), (7, 16, 64, 8, B_CONV3),          # 8x8: two images per tile (ragged) + split-K
     (2, 128, 128, 16, B_CONV3_UP), (2, 256, 96, 8, B_CONV3_UP), (3, 64, 128, 4, B_CONV3_UP),
+    (128, 256, 256, 4, B_CONV3), (5, 64, 96, 4, B_CONV3), (20, 512, 256, 4, B_CONV3),   # 4x4: eight images per tile (ragged) + split-K
 ]
 
 

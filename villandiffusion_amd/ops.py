@@ -156,7 +156,9 @@ WEIGHTS_EPOCH = 0
 
 def bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision convolution kernel takes (vd_gemm_desc.a_packed)."""
-    return mode in (B_CONV3, B_CONV3_T, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and Cc % 16 == 0 and M >= 64
+    if OW == 4 and mode == B_CONV3_UP:
+        return False
+    return mode in (B_CONV3, B_CONV3_T, B_CONV3_UP) and OH == OW and OW in (4, 8, 16, 32) and Cc % 16 == 0 and M >= 64
 
 
 def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
