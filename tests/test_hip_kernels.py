@@ -521,6 +521,8 @@ BX3_CASES = [
     (5, 256, 256, 8, B_CONV3), (1, 64, 64, 8, B_CONV3), (7, 16, 64, 8, B_CONV3),          # 8x8: two images per tile (ragged) + split-K
     (2, 128, 128, 16, B_CONV3_UP), (2, 256, 96, 8, B_CONV3_UP), (3, 64, 128, 4, B_CONV3_UP),
     (128, 256, 256, 4, B_CONV3), (5, 64, 96, 4, B_CONV3), (20, 512, 256, 4, B_CONV3),   # 4x4: eight images per tile (ragged) + split-K
+    # images wider than 32 px: two 64-pixel rows / one 128-pixel row segment per tile
+    (2, 64, 128, 64, B_CONV3), (1, 80, 64, 128, B_CONV3), (1, 64, 64, 256, B_CONV3), (1, 64, 96, 64, B_CONV3_UP), (1, 64, 64, 32, B_CONV3_UP),
 ]
 
 

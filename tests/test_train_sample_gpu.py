@@ -40,13 +40,17 @@ def nets():
     return ref, net
 
 
-def test_training_steps_match_oracle(nets):
-    """3 optimiser steps with gradient accumulation 2 (6 micro-batches of 4): loss per micro-step, LR, parameters."""
+@pytest.mark.parametrize("conv_math", ["bf16x3", "f32"])
+def test_training_steps_match_oracle(nets, conv_math):
+    """3 optimiser steps with gradient accumulation 2 (6 micro-batches of 4): loss per micro-step, LR, parameters -- in both
+    convolution arithmetics (split-precision bf16 products, the default, and exact f32)."""
     ref, _ = nets
     import copy
     ref = copy.deepcopy(ref)
     net = UNet2DModel()
     net.load_state_dict(ref.state_dict())
+    net.conv_math = conv_math
+    theta0 = {k: v.clone() for k, v in ref.state_dict().items()}
     G, lr, warm, total = 2, 2e-4, 2, 10
     opt = torch.optim.Adam(ref.parameters(), lr=lr)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: R.cosine_with_warmup_lambda(s, warm, total))
@@ -72,8 +76,16 @@ def test_training_steps_match_oracle(nets):
             sched.step()
             opt.zero_grad()
     worst = max(rel(net.state_dict()[k], v) for k, v in ref.state_dict().items())
-    print(f"[parity] parameters after 3 optimiser steps: worst rel_err {worst:.3e}")
-    assert worst < 1e-3      # early Adam steps are ~lr*sign(g): elements with rounding-level gradients may differ by O(lr)
+    # the trajectory as a whole: the 3-step update of all 35.7 M parameters against the oracle's, in L2
+    num = sum(float(((net.state_dict()[k].cpu().double() - v.double()) ** 2).sum()) for k, v in ref.state_dict().items())
+    den = sum(float(((v.double() - theta0[k].double()) ** 2).sum()) for k, v in ref.state_dict().items())
+    upd = (num / den) ** 0.5
+    print(f"[parity] parameters after 3 optimiser steps ({conv_math}): worst rel_err {worst:.3e}, update L2 error {upd:.3e}")
+    # Early Adam steps are ~lr*sign(g): an element whose gradient is at rounding level may move by up to 2*lr per step the other way,
+    # i.e. O(lr / max|w|) ~ 1e-3 in this per-tensor metric whatever the arithmetic; the split-precision gradients (5e-5 of scale
+    # instead of 2e-5) put a few more elements in that band.
+    assert worst < (2e-3 if conv_math == "bf16x3" else 1e-3)
+    assert upd < 1e-3          # measured 6e-5 (bf16x3) / 1.2e-5 (f32)
     assert tr.sched_step == 3 and tr.opt.step_count == 3
 
 

@@ -109,7 +109,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = "gemm_bx3_kernel"
     elif tl == 8:
         md = 0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
-        name = f"conv3_bx3_kernel<{d.OW}, {md}, 2>"
+        name = f"conv3_bx3_kernel<{d.OW if d.OW <= 64 else 128}, {md}, 2>"
     elif tl in (4, 6):     # symbol names as rocprofv3 prints them
         tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
@@ -156,9 +156,11 @@ WEIGHTS_EPOCH = 0
 
 def bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision convolution kernel takes (vd_gemm_desc.a_packed)."""
-    if OW == 4 and mode == B_CONV3_UP:
+    if mode not in (B_CONV3, B_CONV3_T, B_CONV3_UP) or Cc % 16 != 0 or M < 64 or (OW == 4 and mode == B_CONV3_UP):
         return False
-    return mode in (B_CONV3, B_CONV3_T, B_CONV3_UP) and OH == OW and OW in (4, 8, 16, 32) and Cc % 16 == 0 and M >= 64
+    if OW == 64 or (OW >= 128 and OW % 128 == 0):           # row-segment tiles of wide images
+        return (OH * OW) % 128 == 0
+    return OH == OW and OW in (4, 8, 16, 32)
 
 
 def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
