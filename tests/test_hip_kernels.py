@@ -565,7 +565,9 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
 @pytest.mark.parametrize("B,Cin,Cout,H,mode", [(4, 128, 128, 32, B_CONV3), (3, 192, 64, 32, B_CONV3), (2, 256, 256, 16, B_CONV3),
                                                (5, 64, 200, 16, B_CONV3), (6, 256, 128, 8, B_CONV3), (1, 64, 64, 8, B_CONV3),
                                                (128, 128, 128, 8, B_CONV3), (3, 128, 128, 16, B_CONV3_UP), (2, 256, 64, 8, B_CONV3_UP),
-                                               (5, 64, 96, 4, B_CONV3_UP)])
+                                               (5, 64, 96, 4, B_CONV3_UP),
+                                               # wide images: 32-pixel row segments, halo pixels from the neighbouring segments
+                                               (2, 64, 128, 64, B_CONV3), (1, 72, 64, 128, B_CONV3), (1, 64, 64, 96, B_CONV3)])
 def test_split_precision_weight_gradient(B, Cin, Cout, H, mode):
     """H is the INPUT side; B_CONV3_UP: the weight gradient through the fused nearest-2x upsample (output 2H x 2H)."""
     x = torch.randn(B, Cin, H, H, generator=g(0))
@@ -598,9 +600,9 @@ def test_split_precision_requests_outside_the_supported_set_fail_loudly():
     pk = torch.zeros(128 * 32 * 9, device=DEV, dtype=torch.int32)
     with pytest.raises(VillanHipError):                                      # C % 16 != 0
         ops.conv3x3(x, w, None, torch.empty(2, 64, 16, 16, device=DEV), a_packed=pk)
-    x2 = torch.randn(2, 64, 64, 64, device=DEV)
-    with pytest.raises(VillanHipError):                                      # 64x64 image: not a split-precision tile size
-        ops.conv_wgrad(torch.randn(2, 64, 64, 64, device=DEV), x2, torch.empty(64, 64 * 9, device=DEV), B_CONV3,
+    x2 = torch.randn(2, 64, 24, 24, device=DEV)
+    with pytest.raises(VillanHipError):                                      # 24x24 image: not a split-precision tile size
+        ops.conv_wgrad(torch.randn(2, 64, 24, 24, device=DEV), x2, torch.empty(64, 64 * 9, device=DEV), B_CONV3,
                        torch.empty(1 << 22, device=DEV), math_mode=1)
 
 

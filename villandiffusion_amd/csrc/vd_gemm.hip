@@ -1535,6 +1535,9 @@ static int wgrad_patch_kind(const vd_wgrad_desc& d) {
         if ((d.mode == VD_B_CONV3 || up) && d.OH == d.OW && (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.H * (up ? 2 : 1) == d.OH &&
             d.W * (up ? 2 : 1) == d.OW && (d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0))
             return 4;
+        if (d.mode == VD_B_CONV3 && d.OW >= 64 && d.OW % 32 == 0 && d.H == d.OH && d.W == d.OW && (d.x_bstride & 3) == 0 &&
+            ((((uintptr_t)d.X) & 15) == 0))
+            return 4;                           // wide images: 32-pixel row segments
         return -1;
     }
     static const bool k64 = getenv("VD_WGRAD_KPIX64") != nullptr;       // experiment: 64-pixel K-steps for the 16 / 32 px layers
@@ -1973,7 +1976,8 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         if (up) hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 2>), grid, dim3(NT), 0, st, d, kk_per);        \
         else hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 0>), grid, dim3(NT), 0, st, d, kk_per);           \
     } while (0)
-                if (d.OW == 32) VD_WBX3(32);
+                if (d.OW >= 64) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 0, true>), grid, dim3(NT), 0, st, d, kk_per);
+                else if (d.OW == 32) VD_WBX3(32);
                 else if (d.OW == 16) VD_WBX3(16);
                 else VD_WBX3(8);
 #undef VD_WBX3

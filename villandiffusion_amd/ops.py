@@ -259,7 +259,7 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     if tl.value == 5:
         name = "wgrad1x1_bx3_kernel(+slab_reduce)"
     elif tl.value == 4 and math_mode == 1:
-        name = f"wgrad_bx3_kernel<{OW}, {0 if mode == B_CONV3 else 2}>(+slab_reduce)"
+        name = f"wgrad_bx3_kernel<{min(OW, 32)}, {0 if mode == B_CONV3 else 2}{', wide' if OW > 32 else ''}>(+slab_reduce)"
     elif tl.value == 4:
         name = f"wgrad_patch_kernel<{OW}, {0 if mode == B_CONV3 else 2}>(+slab_reduce)"
     else:
@@ -272,6 +272,8 @@ def wgrad_bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision weight-gradient kernel takes (vd_wgrad_desc.math = 1)."""
     if mode == B_PLAIN:
         return (OH * OW) % 8 == 0 and M >= 64 and Cc >= 64
+    if mode == B_CONV3 and OW >= 64 and OW % 32 == 0:       # wide images: 32-pixel row segments
+        return M >= 64 and Cc >= 64
     return mode in (B_CONV3, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
 
 
