@@ -308,6 +308,8 @@ def main():
             "sample_seconds": None if sample_s is None else round(sample_s, 2),
             "sample_secondary_images_per_sec": secondary,
             "train_tflops": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
+            "train_frac_of_bf16_peak": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
+            # > 1 in the split-precision arithmetic: the whole step runs faster than the f32-input MFMA could do its contractions
             "train_frac_of_f32_peak": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "sample_frac_of_f32_peak": None if sample_ips is None else round(
                 sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),

@@ -41,5 +41,8 @@ def test_roofline_kernel_agrees_with_rocprof_summary():
         assert name in json.load(f)["kernels"]
     with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")) as f:
         k = json.load(f)["kernels"][name]
-    # MFMA-busy counter == executed flops / peak (a split-precision kernel executes 3 bf16 MFMAs per algorithmic product term)
-    assert abs(k["MfmaUtil"] - d["roofline"].get("frac_executed", d["roofline"]["frac"])) < 0.04
+    # MFMA-busy counter == executed flops / peak (a split-precision kernel executes 3 bf16 MFMAs per algorithmic product term).
+    # The counter ratio is per CYCLE, the bench's fraction per SECOND against the 2.4 GHz peak: under the bf16 matrix load the chip
+    # clocks below 2.4 GHz (the kernel's GRBM cycles / 2.4 GHz is shorter than its measured duration), so convert with that ratio.
+    util_time = k["MfmaUtil"] * k["kernel_us_at_2.4GHz"] / prof_us
+    assert abs(util_time - d["roofline"].get("frac_executed", d["roofline"]["frac"])) < 0.03, (k["MfmaUtil"], util_time)
