@@ -94,6 +94,10 @@ typedef struct vd_gemm_desc {
                                 accumulation; ~1e-5 relative to the exact-f32 kernel) instead of on the f32 MFMA.  A is still
                                 required (shape checks) but not read.  Problems outside that set fail with VD_EINVAL.   */
     int32_t a_packed_mpad;   /* row count the packed operand was built with (M rounded up to 128)                      */
+    int32_t math;            /* 0: exact f32 MFMA (or a_packed).  1: split-precision product of two ACTIVATION matrices (attention
+                                scores / values and their gradients): per-batch A (a_bstride != 0), VD_B_PLAIN or VD_B_KCONTIG,
+                                NP % 128 == 0, K % 16 == 0, K >= 64, M >= 64, 16-byte aligned operands and strides; both operands
+                                are split into bf16 (hi, lo) inside the kernel.  Anything else fails with VD_EINVAL.           */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -102,7 +106,7 @@ int vd_gemm(const vd_gemm_desc* desc, void* stream);
 int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
 /* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4 / 6: patch-staged 3x3
  * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel, 7: direct 3x3 convolution for <= 4 output
- * channels, 8 / 9: split-precision bf16 3x3 convolution / plain product (a_packed), -1: a_packed given for an unsupported problem (profiling / tests). */
+ * channels, 8 / 9 / 10: split-precision bf16 3x3 convolution / plain product (a_packed) / activation product (math = 1), -1: a_packed given for an unsupported problem (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):

@@ -645,3 +645,27 @@ def test_split_precision_1x1_convolution_and_its_input_gradient(B, Cin, Cout, H)
     dw2 = torch.empty_like(dw)
     ops.conv_wgrad(dy.to(DEV), xbuf[:, 2:], dw2, B_PLAIN, ws, accumulate=False, splits=1, math_mode=1)
     check(dw2, w.grad.view(Cout, Cin), BX3_TOL, "bf16x3 1x1 wgrad splits=1")
+
+
+@pytest.mark.parametrize("a_row,b_kc", [(False, False), (True, False), (True, True), (False, True)])
+def test_split_precision_activation_products(a_row, b_kc):
+    """gemm_bx3_act_kernel: D[b] = alpha * A_b @ B_b with both operands split inside the kernel -- the four operand layouts of the
+    attention contractions (scores: A m-contiguous, B n-contiguous; values: A k-contiguous; dv / dk: B k-contiguous), K = 80
+    exercises the tail stage, per-batch strides larger than the matrices (q / k / v are channel slices of one tensor)."""
+    nb, M, Nn, K = 5, 192, 256, 80 if not (a_row and b_kc) else 256
+    gA = torch.randn(nb, 3, M * K, generator=g(0))          # operand = slice 1 of a wider buffer
+    gB = torch.randn(nb, 2, K * Nn, generator=g(1))
+    A = gA[:, 1].reshape(nb, M, K) if a_row else gA[:, 1].reshape(nb, K, M).transpose(1, 2)      # logical [nb, M, K]
+    Bm = gB[:, 1].reshape(nb, Nn, K).transpose(1, 2) if b_kc else gB[:, 1].reshape(nb, K, Nn)    # logical [nb, K, Nn]
+    ref = 0.37 * torch.bmm(A.double(), Bm.double()).float()
+    dA, dB = gA.to(DEV), gB.to(DEV)
+    D = torch.empty(nb, M, Nn, device=DEV)
+    assert ops.gemm_bx3_act_eligible(M, K, Nn)
+    ops.gemm(dA[:, 1], dB[:, 1], D, M=M, N=nb * Nn, K=K, a_mode=A_ROW if a_row else A_COL, b_mode=B_KCONTIG if b_kc else B_PLAIN, NP=Nn,
+             lda=K if a_row else M, a_bstride=3 * M * K, ldb=K if b_kc else Nn, b_bstride=2 * K * Nn, ldd=Nn, d_bstride=M * Nn, alpha=0.37,
+             math_mode=1)
+    check(D, ref, BX3_TOL, f"bf16x3 activation product a_row={a_row} b_kcontig={b_kc}")
+    D32 = torch.empty_like(D)
+    ops.gemm(dA[:, 1], dB[:, 1], D32, M=M, N=nb * Nn, K=K, a_mode=A_ROW if a_row else A_COL, b_mode=B_KCONTIG if b_kc else B_PLAIN, NP=Nn,
+             lda=K if a_row else M, a_bstride=3 * M * K, ldb=K if b_kc else Nn, b_bstride=2 * K * Nn, ldd=Nn, d_bstride=M * Nn, alpha=0.37)
+    assert float((D - D32).abs().max()) <= 5e-5 * float(D32.std())

@@ -1814,6 +1814,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
     if (d.a_packed) return bx3_eligible(d) ? 8 : (gemm_bx3_eligible(d) ? 9 : -1);
+    if (d.math == 1) return gemm_bx3_act_eligible(d) ? 10 : -1;
     if (smallm_eligible(d)) return 7;                        // direct convolution for <= 4 output channels
     if (patch_eligible(d)) {
         int splits, ks_per;
@@ -1846,7 +1847,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     const int tile = vd_gemm_tile(&d);
     VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, "
                            "C %% 16 == 0, M >= 64, or a VD_B_PLAIN product with shared A, NP %% 128 == 0, K %% 16 == 0, M >= 64; "
-                           "a_packed_mpad = M rounded up to 128");
+                           "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 64, M >= 64");
     VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     hipStream_t st = (hipStream_t)stream;
@@ -1859,6 +1860,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
         case 8: rc = launch_bx3(d, st); break;
+        case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 9:
             hipLaunchKernelGGL(gemm_bx3_kernel, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
             rc = 0;

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("debug", _i32), ("alpha", _f32),
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32), ("nb2", _i32),
-                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32)]
+                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32)]
 
 
 class WgradDesc(C.Structure):

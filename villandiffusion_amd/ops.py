@@ -73,9 +73,10 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None):
+         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0):
     d = GemmDesc()
     d.pad = pad
+    d.math = math_mode
     if a_packed is not None:
         d.a_packed, d.a_packed_mpad = a_packed.data_ptr(), (M + 127) // 128 * 128
     d.gn_ss = _p(gn_ss)
@@ -105,7 +106,9 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     e1.record()
     flops = 2.0 * M * N * K * (0.25 if b_mode == B_CONV3_DIL else 1.0)     # DIL: 3/4 of the taps are structural zeros
     tl = lib.vd_gemm_tile(C.byref(d))
-    if tl == 9:
+    if tl == 10:
+        name = f"gemm_bx3_act_kernel<{int(a_mode == A_ROW)}, {int(b_mode == B_KCONTIG)}>"
+    elif tl == 9:
         name = "gemm_bx3_kernel"
     elif tl == 8:
         md = 0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
@@ -181,6 +184,11 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
                 ldd=OH * OW, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
                 pad=pad, gn_ss=gn_ss, a_packed=a_packed)
+
+
+def gemm_bx3_act_eligible(M, K, NP) -> bool:
+    """Products of two activation matrices (attention) the split-precision kernel takes (vd_gemm_desc.math = 1)."""
+    return NP % 128 == 0 and K % 16 == 0 and K >= 64 and M >= 64 and M % 4 == 0
 
 
 def gemm_bx3_eligible(M, K, NP) -> bool:

@@ -121,6 +121,11 @@ def _bx3_packed_1x1(net, key, bwd, M, K, NP):
     return pk.view(key, bwd)
 
 
+def _amath(net, M, K, NP) -> int:
+    """vd_gemm_desc.math for a product of two activation matrices (attention scores / values and their gradients)."""
+    return int(getattr(net, "conv_math", "f32") == "bf16x3" and ops.gemm_bx3_act_eligible(M, K, NP))
+
+
 def _wgrad1x1_math(net, dy, x) -> int:
     """vd_wgrad_desc.math for a 1x1 weight gradient dW[M, C] = sum dy x^T."""
     ok = getattr(net, "conv_math", "f32") == "bf16x3" and ops.wgrad_bx3_eligible(dy.shape[1], x.shape[1], dy.shape[2], dy.shape[3], B_PLAIN) \
@@ -334,10 +339,10 @@ class _Attn:
             q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
             two = dict(nb2=nh, NP=N)
             ops.gemm(k, q, P, M=N, N=B * nh * N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
-                     b_bstride=bs, b_b2stride=hs, ldd=N, d_bstride=nh * N * N, d_b2stride=N * N, alpha=self.scale, **two)
+                     b_bstride=bs, b_b2stride=hs, ldd=N, d_bstride=nh * N * N, d_b2stride=N * N, alpha=self.scale, **two, math_mode=_amath(net, N, dh, N))
             ops.softmax_col_fwd(P, B * nh, N)
             ops.gemm(v, P, o, M=dh, N=B * nh * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
-                     b_bstride=nh * N * N, b_b2stride=N * N, ldd=N, d_bstride=Cc * N, d_b2stride=hs, **two)
+                     b_bstride=nh * N * N, b_b2stride=N * N, ldd=N, d_bstride=Cc * N, d_b2stride=hs, **two, math_mode=_amath(net, dh, N, N))
         elif N < 64 or (N == 64 and B >= 64):     # one workgroup per image: needs a batch that fills the chip
             ops.attn_small_fwd(qkv, o, P, Cc, N, self.scale)
         else:
@@ -345,11 +350,11 @@ class _Attn:
             bs = 3 * Cc * N
             # St[j][i] = scale * sum_c k[c][j] q[c][i]
             ops.gemm(k, q, P, M=N, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
-                     b_bstride=bs, ldd=N, d_bstride=N * N, alpha=self.scale)
+                     b_bstride=bs, ldd=N, d_bstride=N * N, alpha=self.scale, math_mode=_amath(net, N, Cc, N))
             ops.softmax_col_fwd(P, B, N)
             # o[c][i] = sum_j v[c][j] P[j][i]
             ops.gemm(v, P, o, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
-                     b_bstride=N * N, ldd=N, d_bstride=Cc * N)
+                     b_bstride=N * N, ldd=N, d_bstride=Cc * N, math_mode=_amath(net, Cc, N, N))
         ops.conv1x1(o, net.P[self.prefix + ".to_out.0.weight"], net.P[self.prefix + ".to_out.0.bias"], out, residual=x,
                     a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", False, Cc, Cc, N))
         if save:
@@ -381,16 +386,16 @@ class _Attn:
             two = dict(nb2=nh, NP=N, N=B * nh * N)
             # dv[c][j] = sum_i do[c][i] P[j][i]
             ops.gemm(do, P, dv, M=dh, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, lda=N, a_bstride=Cc * N, a_b2stride=hs, ldb=N,
-                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
+                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two, math_mode=_amath(net, dh, N, N))
             # dP[j][i] = sum_c v[c][j] do[c][i]
             ops.gemm(v, do, dP, M=N, K=dh, a_mode=A_COL, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
-                     b_bstride=Cc * N, b_b2stride=hs, ldd=N, d_bstride=pbs, d_b2stride=NN, **two)
+                     b_bstride=Cc * N, b_b2stride=hs, ldd=N, d_bstride=pbs, d_b2stride=NN, **two, math_mode=_amath(net, N, dh, N))
             ops.softmax_col_bwd(P, dP, B * nh, N, self.scale)
             # dq[c][i] = sum_j k[c][j] dS[j][i] ;  dk[c][j] = sum_i q[c][i] dS[j][i]
             ops.gemm(k, dP, dq, M=dh, K=N, a_mode=A_ROW, b_mode=B_PLAIN, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
-                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
+                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two, math_mode=_amath(net, dh, N, N))
             ops.gemm(q, dP, dk, M=dh, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, lda=N, a_bstride=bs, a_b2stride=hs, ldb=N,
-                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two)
+                     b_bstride=pbs, b_b2stride=NN, ldd=N, d_bstride=bs, d_b2stride=hs, **two, math_mode=_amath(net, dh, N, N))
         elif N < 64 or (N == 64 and B >= 64):
             ops.attn_small_bwd(qkv, P, do, dqkv, Cc, N, self.scale)
         else:
@@ -399,18 +404,18 @@ class _Attn:
             bs = 3 * Cc * N
             # dv[c][j] = sum_i do[c][i] P[j][i]
             ops.gemm(do, P, dv, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=Cc * N, ldb=N,
-                     b_bstride=N * N, ldd=N, d_bstride=bs)
+                     b_bstride=N * N, ldd=N, d_bstride=bs, math_mode=_amath(net, Cc, N, N))
             # dP[j][i] = sum_c v[c][j] do[c][i]
             dP = torch.empty((B, N, N), device=dev, dtype=torch.float32)
             ops.gemm(v, do, dP, M=N, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
-                     b_bstride=Cc * N, ldd=N, d_bstride=N * N)
+                     b_bstride=Cc * N, ldd=N, d_bstride=N * N, math_mode=_amath(net, N, Cc, N))
             ops.softmax_col_bwd(P, dP, B, N, self.scale)           # dP -> dS (scaled)
             # dq[c][i] = sum_j k[c][j] dS[j][i]
             ops.gemm(k, dP, dq, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
-                     b_bstride=N * N, ldd=N, d_bstride=bs)
+                     b_bstride=N * N, ldd=N, d_bstride=bs, math_mode=_amath(net, Cc, N, N))
             # dk[c][j] = sum_i q[c][i] dS[j][i]
             ops.gemm(q, dP, dk, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=bs, ldb=N,
-                     b_bstride=N * N, ldd=N, d_bstride=bs)
+                     b_bstride=N * N, ldd=N, d_bstride=bs, math_mode=_amath(net, Cc, N, N))
         ops.conv_wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, net.wgrad_ws, accumulate=True, math_mode=_wgrad1x1_math(net, dqkv, g))
         ws3 = net.scratch_bc(B, 3 * Cc)
         ops.rowsum(dqkv, ws3)
