@@ -88,7 +88,7 @@ typedef struct vd_gemm_desc {
                                 Needs the patch-staged kernel (OW >= 16, C % 8 == 0, C <= 1024, M >= 64)              */
     const void* a_packed;    /* nullable.  3x3 convolutions (VD_B_CONV3 / _T at 4x4 ... 32x32, _UP at 8x8 ... 32x32, any of them on 64-wide or
                                 128k-wide outputs; C % 16 == 0,
-                                M >= 64) and VD_B_PLAIN products with a shared A (1x1 convolutions: NP % 128 == 0, K % 16 == 0,
+                                M >= 64) and VD_B_PLAIN products with a shared A (1x1 convolutions: NP % 128 == 0 or 128 % NP == 0, N % 128 == 0, K % 16 == 0,
                                 M >= 64) only: the weights pre-split into bf16 (hi, lo) pairs by vd_conv3_pack_weights.  The
                                 contraction then runs as three bf16 MFMAs per product term (hi*hi + hi*lo + lo*hi, f32
                                 accumulation; ~1e-5 relative to the exact-f32 kernel) instead of on the f32 MFMA.  A is still

@@ -567,7 +567,9 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
                                                (128, 128, 128, 8, B_CONV3), (3, 128, 128, 16, B_CONV3_UP), (2, 256, 64, 8, B_CONV3_UP),
                                                (5, 64, 96, 4, B_CONV3_UP),
                                                # wide images: 32-pixel row segments, halo pixels from the neighbouring segments
-                                               (2, 64, 128, 64, B_CONV3), (1, 72, 64, 128, B_CONV3), (1, 64, 64, 96, B_CONV3)])
+                                               (2, 64, 128, 64, B_CONV3), (1, 72, 64, 128, B_CONV3), (1, 64, 64, 96, B_CONV3),
+                                               # 4x4: two whole images per K-step (odd batch: the last step is half empty)
+                                               (128, 256, 256, 4, B_CONV3), (7, 64, 96, 4, B_CONV3), (1, 128, 64, 4, B_CONV3)])
 def test_split_precision_weight_gradient(B, Cin, Cout, H, mode):
     """H is the INPUT side; B_CONV3_UP: the weight gradient through the fused nearest-2x upsample (output 2H x 2H)."""
     x = torch.randn(B, Cin, H, H, generator=g(0))
@@ -607,7 +609,7 @@ def test_split_precision_requests_outside_the_supported_set_fail_loudly():
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H", [(16, 256, 768, 16), (8, 512, 256, 16), (4, 384, 128, 32), (12, 256, 200, 16), (3, 80, 64, 32),
-                                          (5, 192, 96, 16)])
+                                          (5, 192, 96, 16), (6, 256, 128, 8), (16, 512, 256, 4)])   # 8x8 / 4x4: 2 / 8 whole images per tile
 def test_split_precision_1x1_convolution_and_its_input_gradient(B, Cin, Cout, H):
     """gemm_bx3_kernel: W[M, C] @ x[b][C, HW] from the packed (hi, lo) weights; K = 80 / 200 exercise the tail stage (K % 64 != 0)."""
     x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
@@ -616,7 +618,7 @@ def test_split_precision_1x1_convolution_and_its_input_gradient(B, Cin, Cout, H)
     res = torch.randn(B, Cout, H, H, generator=g(3))
     y0 = F.conv2d(x, w, b)
     y_ref = y0 + res
-    assert ops.gemm_bx3_eligible(Cout, Cin, H * H)
+    assert ops.gemm_bx3_eligible(Cout, Cin, H * H, B)
     wd = w.detach().to(DEV).view(Cout, Cin)
     pk = ops.conv3_pack_weights(wd, Cout, Cin, taps=1)
     xbuf = torch.zeros(B, Cin + 2, H, H, device=DEV)

@@ -1535,6 +1535,9 @@ static int wgrad_patch_kind(const vd_wgrad_desc& d) {
         if ((d.mode == VD_B_CONV3 || up) && d.OH == d.OW && (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.H * (up ? 2 : 1) == d.OH &&
             d.W * (up ? 2 : 1) == d.OW && (d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0))
             return 4;
+        if (d.mode == VD_B_CONV3 && d.OW == 4 && d.OH == 4 && d.H == 4 && d.W == 4 && (d.x_bstride & 3) == 0 && (d.dy_bstride & 3) == 0 &&
+            ((((uintptr_t)d.X) & 15) == 0))
+            return 4;                           // 4x4 outputs: two whole images per K-step
         if (d.mode == VD_B_CONV3 && d.OW >= 64 && d.OW % 32 == 0 && d.H == d.OH && d.W == d.OW && (d.x_bstride & 3) == 0 &&
             ((((uintptr_t)d.X) & 15) == 0))
             return 4;                           // wide images: 32-pixel row segments
@@ -1556,7 +1559,7 @@ static bool wgrad_patch_eligible(const vd_wgrad_desc& d) { return wgrad_patch_ki
 
 static void wgrad_patch_plan(const vd_wgrad_desc& d, int& splits, int& ks_per) {
     const int kpix = wgrad_patch_kind(d) == 3 ? 64 : 32;
-    const int ks_total = (int)(((int64_t)d.nb * d.NP) / kpix);      // K-step = 32 (64) output pixels
+    const int ks_total = (int)(((int64_t)d.nb * d.NP + kpix - 1) / kpix);      // K-step = 32 (64) output pixels (4x4: two images, the last may be half empty)
     const int base = vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
     splits = d.splits;
     if (splits <= 0) {  // ~3 workgroups per CU, at least 8 K-steps per split
@@ -1979,6 +1982,7 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         else hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 0>), grid, dim3(NT), 0, st, d, kk_per);           \
     } while (0)
                 if (d.OW >= 64) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 0, true>), grid, dim3(NT), 0, st, d, kk_per);
+                else if (d.OW == 4) hipLaunchKernelGGL((wgrad_bx3_kernel<4, 0>), grid, dim3(NT), 0, st, d, kk_per);
                 else if (d.OW == 32) VD_WBX3(32);
                 else if (d.OW == 16) VD_WBX3(16);
                 else VD_WBX3(8);

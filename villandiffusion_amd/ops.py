@@ -191,9 +191,11 @@ def gemm_bx3_act_eligible(M, K, NP) -> bool:
     return NP % 128 == 0 and K % 16 == 0 and K >= 64 and M >= 64 and M % 4 == 0
 
 
-def gemm_bx3_eligible(M, K, NP) -> bool:
-    """1x1 convolutions / plain products the split-precision GEMM kernel takes (vd_gemm_desc.a_packed, shared A)."""
-    return NP % 128 == 0 and K % 16 == 0 and M >= 64
+def gemm_bx3_eligible(M, K, NP, nb=None) -> bool:
+    """1x1 convolutions / plain products the split-precision GEMM kernel takes (vd_gemm_desc.a_packed, shared A); nb = batch items."""
+    if K % 16 != 0 or M < 64:
+        return False
+    return NP % 128 == 0 or (128 % NP == 0 and nb is not None and (nb * NP) % 128 == 0)
 
 
 def conv1x1(x, w2d, bias, out, residual=None, accumulate=False, tile=0, a_packed=None):
@@ -280,7 +282,7 @@ def wgrad_bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision weight-gradient kernel takes (vd_wgrad_desc.math = 1)."""
     if mode == B_PLAIN:
         return (OH * OW) % 8 == 0 and M >= 64 and Cc >= 64
-    if mode == B_CONV3 and OW >= 64 and OW % 32 == 0:       # wide images: 32-pixel row segments
+    if mode == B_CONV3 and ((OW >= 64 and OW % 32 == 0) or (OW == 4 and OH == 4)):       # wide images: 32-pixel row segments; 4x4: two images per K-step
         return M >= 64 and Cc >= 64
     return mode in (B_CONV3, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
 

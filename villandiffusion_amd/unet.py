@@ -111,9 +111,9 @@ def _bx3_packed(net, prefix, bwd, M, Cc, OH, OW, mode):
     return pk.view(prefix, bwd)
 
 
-def _bx3_packed_1x1(net, key, bwd, M, K, NP):
+def _bx3_packed_1x1(net, key, bwd, M, K, NP, nb=None):
     """Packed operand of a 1x1 convolution / projection for ops.conv1x1 / ops.gemm(a_packed=...), or None (exact-f32 kernels)."""
-    if getattr(net, "conv_math", "f32") != "bf16x3" or not ops.gemm_bx3_eligible(M, K, NP):
+    if getattr(net, "conv_math", "f32") != "bf16x3" or not ops.gemm_bx3_eligible(M, K, NP, nb):
         return None
     pk = getattr(net, "_packed", None)
     if pk is None:
@@ -249,7 +249,7 @@ class _Resnet:
             if self.has_sc:
                 ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
                             net.P[self.prefix + ".conv_shortcut.bias"], out,
-                            a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W))
+                            a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W, B))
                 self.conv2.fwd(h1, out, residual=out, gn_ss=ss2)
             else:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
@@ -263,7 +263,7 @@ class _Resnet:
         if self.has_sc:
             ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
                         net.P[self.prefix + ".conv_shortcut.bias"], out,
-                        a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W))
+                        a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W, B))
             self.conv2.fwd(a2, out, residual=out)
         else:
             self.conv2.fwd(a2, out, residual=x)
@@ -297,7 +297,7 @@ class _Resnet:
             HW = H * W
             ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
                      ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
-                     a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW))
+                     a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc)
         else:
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dout)
@@ -327,7 +327,7 @@ class _Attn:
         g = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         mean, rstd = self.norm.fwd(x, g)
         qkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
-        ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", False, 3 * Cc, Cc, N))
+        ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", False, 3 * Cc, Cc, N, B))
         o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
         P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
@@ -356,7 +356,7 @@ class _Attn:
             ops.gemm(v, P, o, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_PLAIN, NP=N, lda=N, a_bstride=bs, ldb=N,
                      b_bstride=N * N, ldd=N, d_bstride=Cc * N, math_mode=_amath(net, Cc, N, N))
         ops.conv1x1(o, net.P[self.prefix + ".to_out.0.weight"], net.P[self.prefix + ".to_out.0.bias"], out, residual=x,
-                    a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", False, Cc, Cc, N))
+                    a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", False, Cc, Cc, N, B))
         if save:
             return (x, mean, rstd, g, qkv, P, o)
         return None
@@ -375,7 +375,7 @@ class _Attn:
         net.colsum_later(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc)
         do = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(wo, dout, do, M=Cc, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
-                 b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N))
+                 b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N, B))
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
         if nh > 1:
@@ -422,7 +422,7 @@ class _Attn:
         net.colsum_later(ws3, net.Gq[self.qkv_b], B, 3 * Cc)
         dg = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(net.Pq[self.qkv_w], dqkv, dg, M=Cc, N=B * N, K=3 * Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
-                 b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", True, Cc, 3 * Cc, N))
+                 b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", True, Cc, 3 * Cc, N, B))
         self.norm.bwd(dg, x, mean, rstd, dx, extra=dout)
         return dx
 
