@@ -509,6 +509,14 @@ def test_conv3x3_with_groupnorm_silu_folded_into_the_loader(B, Cin, Cout, H):
     assert torch.equal(out, out2), float((out - out2).abs().max())
     with pytest.raises(Exception):                          # not honoured silently on the kernels that cannot do it
         ops.conv3x3(xd[:, :, :8, :8].contiguous(), w.to(DEV).view(Cout, -1), b.to(DEV), torch.empty(B, Cout, 8, 8, device=DEV), gn_ss=ss)
+    # the split-precision kernel's folded loader: bit-identical to its own two-kernel path (same per-element expression)
+    if Cin % 16 == 0:
+        pk = ops.conv3_pack_weights(w.to(DEV).view(Cout, -1), Cout, Cin)
+        o3, o4 = torch.empty_like(out), torch.empty_like(out)
+        ops.conv3x3(xd, w.to(DEV).view(Cout, -1), b.to(DEV), o3, rowadd=temb.to(DEV), rowadd_bstride=Cout, residual=res.to(DEV), gn_ss=ss, a_packed=pk)
+        ops.conv3x3(a, w.to(DEV).view(Cout, -1), b.to(DEV), o4, rowadd=temb.to(DEV), rowadd_bstride=Cout, residual=res.to(DEV), a_packed=pk)
+        check(o3, y_ref, 1e-4, f"GN+SiLU folded split-precision conv {Cin}->{Cout}@{H}")
+        assert torch.equal(o3, o4), float((o3 - o4).abs().max())
 
 
 # ---- split-precision ("bf16x3") kernels: bf16 hi/lo operands, three MFMAs per product term, f32 accumulation --------------------

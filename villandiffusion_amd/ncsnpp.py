@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import ops
 from .lib import A_COL, B_CONV3, B_PLAIN
-from .unet import UNet2DModel, _Attn, _Conv, _Norm
+from .unet import UNet2DModel, _Attn, _Conv, _Norm, _bx3_packed_1x1, _wgrad1x1_math
 
 SQRT2 = math.sqrt(2.0)
 
@@ -67,7 +67,9 @@ class _ResnetPP:
         out = torch.empty_like(h1)
         if self.has_sc:
             ops.conv1x1(xs, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
-                        net.P[self.prefix + ".conv_shortcut.bias"], out)
+                        net.P[self.prefix + ".conv_shortcut.bias"], out,
+                        a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin,
+                                                 xs.shape[2] * xs.shape[3], xs.shape[0]))
             self.conv2.fwd(a2, out, residual=out)
         else:
             self.conv2.fwd(a2, out, residual=xs)
@@ -96,12 +98,13 @@ class _ResnetPP:
         if self.has_sc:
             wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
             ops.conv_wgrad(dsum, xs, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN, net.wgrad_ws,
-                           accumulate=True)
+                           accumulate=True, math_mode=_wgrad1x1_math(net, dsum, xs))
             net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout)
             dxs = torch.empty_like(xs)
             HW = xs.shape[2] * xs.shape[3]
             ops.gemm(wsc, dsum, dxs, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin, ldb=HW,
-                     b_bstride=self.cout * HW, ldd=HW, d_bstride=self.cin * HW)
+                     b_bstride=self.cout * HW, ldd=HW, d_bstride=self.cin * HW,
+                     a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
         else:
             dxs = dsum
         if self.up or self.down:

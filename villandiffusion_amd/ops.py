@@ -111,7 +111,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     elif tl == 9:
         name = "gemm_bx3_kernel"
     elif tl == 8:
-        md = 0 if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
+        md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
         name = f"conv3_bx3_kernel<{d.OW if d.OW <= 64 else 128}, {md}, 2>"
     elif tl in (4, 6):     # symbol names as rocprofv3 prints them
         tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images

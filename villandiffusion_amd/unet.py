@@ -145,8 +145,9 @@ class _Conv:
         return self.net.P[self.prefix + ".weight"].view(self.cout, self.cin * 9)
 
     def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None, gn_ss=None):
-        pk = None if gn_ss is not None else _bx3_packed(self.net, self.prefix, False, self.cout, self.cin, out.shape[2], out.shape[3],
-                                                        self.mode)
+        pk = _bx3_packed(self.net, self.prefix, False, self.cout, self.cin, out.shape[2], out.shape[3], self.mode)
+        if gn_ss is not None and (out.shape[3] not in (16, 32) or self.mode != B_CONV3):
+            pk = None                                      # the folded-GroupNorm loader of the split-precision kernel: 16x16 / 32x32 only
         return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
                            rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk)
 
@@ -239,7 +240,8 @@ class _Resnet:
         net = self.net
         B, _, H, W = x.shape
         dev = x.device
-        if not save and net.fuse_gn_inference and ops.gn_fusable(x, self.cout) and self.cin * H * W // net.groups <= 12288 \
+        fuse = net.fuse_gn_inference if net.fuse_gn_inference is not None else (net.conv_math == "bf16x3")
+        if not save and fuse and ops.gn_fusable(x, self.cout) and self.cin * H * W // net.groups <= 12288 \
                 and self.cout * H * W // net.groups <= 12288:
             # inference: GroupNorm + SiLU folded into the convolutions' patch loaders -- a statistics pass (one read) replaces the
             # normalise pass (read + write) and the normalised activations never reach HBM
@@ -621,9 +623,10 @@ class UNet2DModel(nn.Module):
         self.grad_buckets = [(o_up, total), (o_mid, o_up), (o_in, o_mid), (0, o_in)]
         self.bucket_ready_hook = None
         # no-grad forward: fold GroupNorm + SiLU into the 3x3 convolutions' loaders (vd_gemm gn_ss).  Measured on MI355X it does NOT
-        # pay: the transform sits in the store phase of the K-step (conv 439 -> 455 us, 373 -> 393 us) and costs more than the saved
-        # normalise pass (26 -> 14 us): 8.22 vs 8.30 img/s for DDPM-1000.  Kept as an opt-in.
-        self.fuse_gn_inference = False
+        # pay on the exact-f32 kernels: the transform sits in the store phase of the K-step (conv 439 -> 455 us, 373 -> 393 us) and costs
+        # more than the saved normalise pass (26 -> 14 us): 8.22 vs 8.30 img/s for DDPM-1000.  On the split-precision kernels the patch
+        # is stored once per 16 channels x 9 taps and the fold pays (7.39 -> 7.22 ms per sampler step).  None = on for "bf16x3" only.
+        self.fuse_gn_inference = None
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
