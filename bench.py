@@ -265,8 +265,11 @@ def main():
         def peak_of(kname):      # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
             return PEAK_BF16_MFMA_TFLOPS if "bx3" in kname else PEAK_F32_MFMA_TFLOPS
         kernels = sorted(({"kernel": k, "launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / v[2] / 1e9, 2),
-                           "avg_us": round(1e3 * v[2] / v[0], 1), "peak": peak_of(k)} for k, v in agg.items()), key=lambda r: -r["ms"])
-        top = kernels[0]
+                           "avg_us": round(1e3 * v[2] / v[0], 1), "peak": peak_of(k), "gflop_per_step": round(v[1] / 1e9, 1)}
+                          for k, v in agg.items()), key=lambda r: -r["ms"])
+        # dominant kernel = the symbol that carries the largest share of the step's algorithmic FLOPs (by summed time the many short
+        # 1x1 launches can edge ahead under per-launch event timing; they carry a fifth of the work of the 32x32 convolutions)
+        top = max(kernels, key=lambda r: r["gflop_per_step"])
         top_peak = peak_of(top["kernel"])
         traffic = None          # HBM bytes per launch from the committed PMC pass (rocprofv3 cannot run inside this process)
         try:
