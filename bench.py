@@ -299,9 +299,10 @@ def main():
             "value": round(train_ips, 2), "unit": "train images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3/f32" if net.conv_math == "bf16x3" else "f32", "data": "synthetic",
-            "dtype_note": ("f32 tensors and accumulation; 3x3 convolutions (forward, input and weight gradient at 8x8-32x32) as "
-                           "hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32; the reference trains this "
-                           "config under fp16 autocast); everything else on the f32 MFMA") if net.conv_math == "bf16x3" else
+            "dtype_note": ("f32 tensors and accumulation; 3x3 / 1x1 convolutions and the attention contractions (forward, input and weight "
+                           "gradients) as hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32 per contraction; the "
+                           "reference trains this config under fp16 autocast); stride-2 convolutions, linears, conv_in / conv_out on the "
+                           "exact f32 MFMA") if net.conv_math == "bf16x3" else
                           "every contraction on the f32-input MFMA (exact f32)",
             "exact_f32_mode": exact,
             "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), "
