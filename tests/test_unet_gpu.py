@@ -221,3 +221,34 @@ def test_full_size_batch128_properties():
     print(f"[parity] batch-128 rows vs 4-image forward {e_sub:.3e}; 4-image forward vs oracle {e_ref:.3e}")
     assert e_sub < 2e-5 and e_ref < 1e-4
     assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+
+
+def test_packed_operands_follow_the_weights():
+    """The split-precision operands are a cache of the weights: they must follow load_state_dict, in-place torch updates of a
+    parameter, the raw-pointer Adam step (tests/test_train_sample_gpu.py) and, after `.data` writes, an explicit weights_changed()."""
+    torch.manual_seed(1)
+    ref = UNet2DModelRef()
+    net = UNet2DModel()
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(4))
+    t = torch.tensor([10, 900])
+    with torch.no_grad():
+        y0 = net(x.cuda(), t.cuda())[0].clone()
+        # (1) load_state_dict with scaled conv weights
+        sd = {k: (v * 1.25 if k.endswith("conv1.weight") else v) for k, v in ref.state_dict().items()}
+        net.load_state_dict(sd)
+        ref.load_state_dict(sd)
+        y1, y1_ref = net(x.cuda(), t.cuda())[0], ref(x, t)[0]
+        assert rel(y1, y1_ref) < 1e-4 and rel(y1, y0) > 1e-3
+        # (2) in-place torch op on a parameter (shares the flat buffer's version counter)
+        p = dict(net.named_parameters())["mid_block.resnets.0.conv2.weight"]
+        p.mul_(0.5)
+        dict(ref.named_parameters())["mid_block.resnets.0.conv2.weight"].mul_(0.5)
+        y2, y2_ref = net(x.cuda(), t.cuda())[0], ref(x, t)[0]
+        assert rel(y2, y2_ref) < 1e-4
+        # (3) a write through .data is invisible to every counter: weights_changed() is the documented way
+        p.data.mul_(2.0)
+        dict(ref.named_parameters())["mid_block.resnets.0.conv2.weight"].mul_(2.0)
+        net.weights_changed()
+        y3, y3_ref = net(x.cuda(), t.cuda())[0], ref(x, t)[0]
+        assert rel(y3, y3_ref) < 1e-4

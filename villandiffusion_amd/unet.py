@@ -671,7 +671,15 @@ class UNet2DModel(nn.Module):
                     off, n, shape = self._offs[k]
                     assert tuple(v.shape) == tuple(shape) or v.numel() == n, (k, v.shape, shape)
                     self.flat_param[off:off + n].copy_(v.reshape(-1).to(torch.float32))
+        self.weights_changed()
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def weights_changed(self):
+        """Drop the packed split-precision operands.  They are rebuilt automatically after optimiser steps, `load_state_dict`,
+        `reset_parameters` and any in-place torch op on a parameter (keyed on the flat buffer's version counter); call this after
+        writing parameters behind autograd's back (`p.data.copy_(...)`, raw pointers), which no counter sees."""
+        if self._packed is not None:
+            self._packed.key = {False: None, True: None}
 
     def to(self, *args, **kwargs):          # parameters are views of one flat device buffer: never re-materialise
         return self
