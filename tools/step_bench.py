@@ -69,5 +69,5 @@ for nm, fl, a, b in rec:
     d[0] += 1; d[1] += fl; d[2] += a.elapsed_time(b)
 tot = sum(v[2] for v in agg.values())
 print(f"MFMA kernels: {tot:.1f} ms, {sum(v[1] for v in agg.values()) / tot / 1e9:.1f} TF avg")
-for nm, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:14]:
+for nm, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:int(os.environ.get("STEP_BENCH_TOP", 14))]:
     print(f"  {nm:55s} n={v[0]:3d} {v[2]:8.2f} ms {v[1] / v[2] / 1e9:6.1f} TF")

@@ -266,7 +266,9 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     e1.record()
     tl, sp = C.c_int32(0), C.c_int32(0)
     lib.vd_conv_wgrad_plan(C.byref(d), C.byref(tl), C.byref(sp))
-    if tl.value == 5:
+    if tl.value == 6:
+        name = f"wgrad_small_kernel<{'true' if M <= 4 else 'false'}>(+colsum)"
+    elif tl.value == 5:
         name = "wgrad1x1_bx3_kernel(+slab_reduce)"
     elif tl.value == 4 and math_mode == 1:
         name = f"wgrad_bx3_kernel<{min(OW, 32)}, {0 if mode == B_CONV3 else 2}{', wide' if OW > 32 else ''}>(+slab_reduce)"
@@ -294,8 +296,9 @@ def wgrad_ws_floats(M, Cc, T, nb, NP, OH=None, OW=None, mode=None, math_mode=0) 
         OH = OW = int(round(math.sqrt(NP)))
     d.M, d.C, d.T, d.nb, d.NP, d.OH, d.OW = M, Cc, T, nb, NP, OH, OW
     d.mode = (B_PLAIN if T == 1 else B_CONV3) if mode is None else mode
-    if math_mode:
-        d.math, d.H, d.W = math_mode, (OH // 2 if d.mode == B_CONV3_UP else OH), (OW // 2 if d.mode == B_CONV3_UP else OW)
+    d.math = math_mode
+    scale = {B_CONV3_UP: (1, 2), B_CONV3_S2: (2, 1)}.get(d.mode, (1, 1))          # source dims of the gather
+    d.H, d.W = OH * scale[0] // scale[1], OW * scale[0] // scale[1]
     return int(L.load().vd_conv_wgrad_ws_floats(C.byref(d)))
 
 
