@@ -36,7 +36,11 @@ def test_roofline_kernel_agrees_with_rocprof_summary():
         rows = [r for r in csv.DictReader(f) if name + "(" in r["Name"]]
     assert len(rows) == 1, name
     prof_us = float(rows[0]["AverageNs"]) / 1e3
-    assert abs(prof_us - avg_us) / prof_us < 0.05, (prof_us, avg_us)
+    # HIP-event average of the plain run (the bench line the driver parses) vs rocprofv3's own average for the same command: 5 %;
+    # the events recorded UNDER the profiler carry its per-launch overhead (~10 us on a 180 us kernel): 10 %
+    plain = _line("r01_bench_default.json")["roofline"]
+    assert plain["kernel"] == name and abs(prof_us - plain["avg_launch_us"]) / prof_us < 0.05, (prof_us, plain["avg_launch_us"])
+    assert abs(prof_us - avg_us) / prof_us < 0.10, (prof_us, avg_us)
     with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
         assert name in json.load(f)["kernels"]
     with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")) as f:
