@@ -90,7 +90,8 @@ def test_conv3x3_forward_epilogue(B, Cin, Cout, H, mode, tile):
                                                (2, 128, 128, 32, B_CONV3), (2, 200, 128, 32, B_CONV3), (2, 128, 128, 16, B_CONV3_UP),
                                                (2, 64, 96, 8, B_CONV3_UP), (2, 3, 128, 32, B_CONV3), (2, 128, 3, 32, B_CONV3),
                                                # direct kernel for a <= 4-channel side (conv_in / conv_out), ragged channel counts, 16x16, one image
-                                               (5, 3, 72, 32, B_CONV3), (3, 100, 4, 16, B_CONV3), (1, 1, 32, 32, B_CONV3)])
+                                               (5, 3, 72, 32, B_CONV3), (3, 100, 4, 16, B_CONV3), (1, 1, 32, 32, B_CONV3),
+                                               (2, 3, 64, 80, B_CONV3), (1, 96, 3, 48, B_CONV3)])         # larger images: 32 x 32 tiles, ragged edges
 def test_conv3x3_backward(B, Cin, Cout, H, mode):
     x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)).requires_grad_()

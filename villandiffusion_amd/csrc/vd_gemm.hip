@@ -1723,8 +1723,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ w
 // An MFMA tile would be > 90 % padding (measured: 231 us for 0.9 GFLOP on the generic kernel); the work is one pass over the BIG
 // operand (67 MB at B = 128).  A workgroup owns one image and 32 channels of the big side; the small side's image (<= 4 channels,
 // zero halo) sits in LDS.  Lane = column x, 8 channel slots per workgroup: a thread reads big[c][y][x] once (coalesced rows) and
-// updates its 9 x CS accumulators from LDS; a 32-lane shuffle tree finishes each channel.  Per-image partials go to
-// ws[b][M*C*9] in the weight layout and are summed over the images in fixed order by colsum_kernel (deterministic).
+// updates its 9 x CS accumulators from LDS; a 32-lane shuffle tree finishes each channel.  Images larger than 32 x 32 are cut
+// into 32 x 32 pixel tiles (one workgroup each).  Per-(image, tile) partials go to ws[part][M*C*9] in the weight layout and are
+// summed in fixed order by colsum_kernel (deterministic).
 //   BIG_IS_X:  big = X (C channels), small = dY (M <= 4):  dW[m][c][r][s] += X[c][y][x] * dY[m][y - r + 1][x - s + 1]
 //   otherwise: big = dY (M channels), small = X (C <= 4):  dW[m][c][r][s] += dY[m][y][x] * X[c][y + r - 1][x + s - 1]
 template <bool BIG_IS_X>
@@ -1732,21 +1733,27 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const vd_wgrad_desc d)
     constexpr int MAXS = 4, PWM = 34;
     __shared__ float S[MAXS * PWM * PWM];
     const int CB = BIG_IS_X ? d.C : d.M, CS = BIG_IS_X ? d.M : d.C;
-    const int H = d.OH, W = d.OW, HW = H * W, PW = W + 2, PHW = (H + 2) * PW;
-    const int cb_blocks = (CB + 31) / 32;
-    const int b = blockIdx.x / cb_blocks, cb0 = (blockIdx.x - b * cb_blocks) * 32;
+    const int H = d.OH, W = d.OW, HW = H * W;
+    constexpr int PW = PWM, PHW = PWM * PWM;                      // a 32 x 32 pixel tile of the image + halo
+    const int cb_blocks = (CB + 31) / 32, tiles_x = (W + 31) / 32, tiles = tiles_x * ((H + 31) / 32);
+    int rest = blockIdx.x;
+    const int cb0 = (rest % cb_blocks) * 32;
+    rest /= cb_blocks;
+    const int tile = rest % tiles, b = rest / tiles;
+    const int y0 = (tile / tiles_x) * 32, x0 = (tile - (tile / tiles_x) * tiles_x) * 32;
+    const int TH = min(32, H - y0), TW = min(32, W - x0);
     const float* __restrict__ big = (BIG_IS_X ? d.X + (int64_t)b * d.x_bstride : d.dY + (int64_t)b * d.dy_bstride);
     const float* __restrict__ sml = (BIG_IS_X ? d.dY + (int64_t)b * d.dy_bstride : d.X + (int64_t)b * d.x_bstride);
     for (int i = threadIdx.x; i < CS * PHW; i += 256) {
         const int cs = i / PHW, rem = i - cs * PHW;
-        const int yy = rem / PW - 1, xx = rem - (rem / PW) * PW - 1;
+        const int yy = y0 + rem / PW - 1, xx = x0 + rem - (rem / PW) * PW - 1;
         const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
         S[i] = ok ? sml[(int64_t)cs * HW + yy * W + xx] : 0.f;
     }
     __syncthreads();
     const int x = threadIdx.x & 31, slot = threadIdx.x >> 5;
     const int Ncols = d.C * 9;
-    float* __restrict__ part = d.ws + (int64_t)b * d.M * Ncols;
+    float* __restrict__ part = d.ws + ((int64_t)b * tiles + tile) * d.M * Ncols;
     for (int k = 0; k < 4; ++k) {
         const int cb = cb0 + slot + 8 * k;                       // uniform per 32-lane group
         if (cb >= CB) continue;
@@ -1755,9 +1762,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const vd_wgrad_desc d)
         for (int cs = 0; cs < MAXS; ++cs)
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[cs][t] = 0.f;
-        if (x < W) {
-            const float* __restrict__ src = big + (int64_t)cb * HW + x;
-            for (int y = 0; y < H; ++y) {
+        if (x < TW) {
+            const float* __restrict__ src = big + (int64_t)cb * HW + (int64_t)y0 * W + x0 + x;
+            for (int y = 0; y < TH; ++y) {
                 const float v = src[y * W];
 #pragma unroll
                 for (int cs = 0; cs < MAXS; ++cs) {
@@ -1793,10 +1800,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const vd_wgrad_desc d)
 
 static bool wgrad_small_eligible(const vd_wgrad_desc& d) {
     if (d.T != 9 || d.mode != VD_B_CONV3 || d.tile != 0 || d.math != 0) return false;
-    if (d.H != d.OH || d.W != d.OW || d.OH * d.OW != d.NP || d.OW > 32 || d.OH > 32) return false;
+    if (d.H != d.OH || d.W != d.OW || d.OH * d.OW != d.NP) return false;
     const bool small_m = d.M <= 4 && d.C >= 32, small_c = d.C <= 4 && d.M >= 32;
     return (small_m || small_c) && d.nb >= 1;
 }
+static int wgrad_small_parts(const vd_wgrad_desc& d) { return d.nb * vd_cdiv(d.OW, 32) * vd_cdiv(d.OH, 32); }
 
 // Many column sums in ONE launch (the ~180 bias / GroupNorm-parameter gradient reductions of a backward pass): workgroup i
 // reads its job from a device table {ws address, out address, columns (<= 64), ld} and does exactly what colsum_kernel does
@@ -1991,7 +1999,7 @@ extern "C" int vd_conv3_pack_weights_multi(const int64_t* table, int n_jobs, int
 static void wgrad_plan(const vd_wgrad_desc& d, int& tile, int& splits, int& kk_per) {
     if (wgrad_small_eligible(d)) {          // direct kernel: one partial image of dW per batch item
         tile = 6;
-        splits = d.nb > 1 ? d.nb : 2;       // (>= 2 so that the workspace is always requested)
+        splits = wgrad_small_parts(d) > 1 ? wgrad_small_parts(d) : 2;       // one partial dW per (image, 32 x 32 tile); >= 2: workspace always requested
         kk_per = 1;
         return;
     }
@@ -2110,11 +2118,12 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
             break;
         }
         case 6: {
-            const dim3 grid(d.nb * vd_cdiv(d.M <= 4 ? d.C : d.M, 32));
+            const int parts = wgrad_small_parts(d);
+            const dim3 grid(parts * vd_cdiv(d.M <= 4 ? d.C : d.M, 32));
             if (d.M <= 4) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, st, d);
             VD_LAUNCH_CHECK("vd_conv_wgrad/direct");
-            hipLaunchKernelGGL(colsum_kernel, dim3(vd_cdiv(d.M * Ncols, 64)), dim3(256), 0, st, d.ws, d.dW, d.nb, d.M * Ncols,
+            hipLaunchKernelGGL(colsum_kernel, dim3(vd_cdiv(d.M * Ncols, 64)), dim3(256), 0, st, d.ws, d.dW, parts, d.M * Ncols,
                                (int64_t)d.M * Ncols, d.accumulate);
             VD_LAUNCH_CHECK("vd_conv_wgrad/direct-reduce");
             return 0;

@@ -46,6 +46,8 @@ def _ensure_path(root: nn.Module, parts: Sequence[str]) -> nn.Module:
 
 # ----------------------------------------------------------------------------------------------------------- layers
 CONV_MATH_DEFAULT = os.environ.get("VILLAN_CONV_MATH", "bf16x3")
+if CONV_MATH_DEFAULT not in ("bf16x3", "f32"):
+    raise ValueError(f"VILLAN_CONV_MATH must be 'bf16x3' or 'f32', got {CONV_MATH_DEFAULT!r}")
 
 
 class _PackedConvWeights:
