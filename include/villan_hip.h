@@ -125,8 +125,8 @@ typedef struct vd_wgrad_desc {
     int64_t dy_bstride, x_bstride;
     int32_t pad;              /* VD_B_CONV3_S2 only, as in vd_gemm_desc                         */
     int32_t math;             /* 0: exact f32 MFMA.  1: split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulation,
-                                 ~1e-5 relative): VD_B_CONV3 / VD_B_CONV3_UP with 8x8 / 16x16 / 32x32 outputs, VD_B_CONV3 on images whose
-                                 width is a multiple of 32 from 64 up, or VD_B_PLAIN (1x1) with
+                                 ~1e-5 relative): VD_B_CONV3 / VD_B_CONV3_UP with 8x8 / 16x16 / 32x32 outputs, either of them on images whose
+                                 width is a multiple of 32 from 64 up, VD_B_CONV3 at 4x4, or VD_B_PLAIN (1x1) with
                                  NP % 8 == 0; M >= 64, C >= 64; otherwise VD_EINVAL */
 } vd_wgrad_desc;
 

@@ -578,7 +578,7 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
                                                (128, 128, 128, 8, B_CONV3), (3, 128, 128, 16, B_CONV3_UP), (2, 256, 64, 8, B_CONV3_UP),
                                                (5, 64, 96, 4, B_CONV3_UP),
                                                # wide images: 32-pixel row segments, halo pixels from the neighbouring segments
-                                               (2, 64, 128, 64, B_CONV3), (1, 72, 64, 128, B_CONV3), (1, 64, 64, 96, B_CONV3),
+                                               (2, 64, 128, 64, B_CONV3), (1, 72, 64, 128, B_CONV3), (1, 64, 64, 96, B_CONV3), (2, 64, 64, 32, B_CONV3_UP), (1, 80, 64, 64, B_CONV3_UP),
                                                # 4x4: two whole images per K-step (odd batch: the last step is half empty)
                                                (128, 256, 256, 4, B_CONV3), (7, 64, 96, 4, B_CONV3), (1, 128, 64, 4, B_CONV3)])
 def test_split_precision_weight_gradient(B, Cin, Cout, H, mode):

@@ -1538,8 +1538,8 @@ static int wgrad_patch_kind(const vd_wgrad_desc& d) {
         if (d.mode == VD_B_CONV3 && d.OW == 4 && d.OH == 4 && d.H == 4 && d.W == 4 && (d.x_bstride & 3) == 0 && (d.dy_bstride & 3) == 0 &&
             ((((uintptr_t)d.X) & 15) == 0))
             return 4;                           // 4x4 outputs: two whole images per K-step
-        if (d.mode == VD_B_CONV3 && d.OW >= 64 && d.OW % 32 == 0 && d.H == d.OH && d.W == d.OW && (d.x_bstride & 3) == 0 &&
-            ((((uintptr_t)d.X) & 15) == 0))
+        if ((d.mode == VD_B_CONV3 || up) && d.OW >= 64 && d.OW % 32 == 0 && d.H * (up ? 2 : 1) == d.OH && d.W * (up ? 2 : 1) == d.OW &&
+            (d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0))
             return 4;                           // wide images: 32-pixel row segments
         return -1;
     }
@@ -2074,7 +2074,8 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         if (up) hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 2>), grid, dim3(NT), 0, st, d, kk_per);        \
         else hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 0>), grid, dim3(NT), 0, st, d, kk_per);           \
     } while (0)
-                if (d.OW >= 64) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 0, true>), grid, dim3(NT), 0, st, d, kk_per);
+                if (d.OW >= 64 && up) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 2, true>), grid, dim3(NT), 0, st, d, kk_per);
+                else if (d.OW >= 64) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 0, true>), grid, dim3(NT), 0, st, d, kk_per);
                 else if (d.OW == 4) hipLaunchKernelGGL((wgrad_bx3_kernel<4, 0>), grid, dim3(NT), 0, st, d, kk_per);
                 else if (d.OW == 32) VD_WBX3(32);
                 else if (d.OW == 16) VD_WBX3(16);

@@ -284,8 +284,8 @@ def wgrad_bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision weight-gradient kernel takes (vd_wgrad_desc.math = 1)."""
     if mode == B_PLAIN:
         return (OH * OW) % 8 == 0 and M >= 64 and Cc >= 64
-    if mode == B_CONV3 and ((OW >= 64 and OW % 32 == 0) or (OW == 4 and OH == 4)):       # wide images: 32-pixel row segments; 4x4: two images per K-step
-        return M >= 64 and Cc >= 64
+    if (mode == B_CONV3 and OW == 4 and OH == 4) or (mode in (B_CONV3, B_CONV3_UP) and OW >= 64 and OW % 32 == 0):
+        return M >= 64 and Cc >= 64      # 4x4: two images per K-step; wide images: 32-pixel row segments
     return mode in (B_CONV3, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
 
 
