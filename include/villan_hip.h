@@ -96,7 +96,7 @@ typedef struct vd_gemm_desc {
     int32_t a_packed_mpad;   /* row count the packed operand was built with (M rounded up to 128)                      */
     int32_t math;            /* 0: exact f32 MFMA (or a_packed).  1: split-precision product of two ACTIVATION matrices (attention
                                 scores / values and their gradients): per-batch A (a_bstride != 0), VD_B_PLAIN or VD_B_KCONTIG,
-                                NP % 128 == 0, K % 16 == 0, K >= 64, M >= 64, 16-byte aligned operands and strides; both operands
+                                NP % 128 == 0, K % 16 == 0, K >= 32, M >= 64, 16-byte aligned operands and strides; both operands
                                 are split into bf16 (hi, lo) inside the kernel.  Anything else fails with VD_EINVAL.           */
 } vd_gemm_desc;
 

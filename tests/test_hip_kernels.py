@@ -665,7 +665,7 @@ def test_split_precision_activation_products(a_row, b_kc):
     """gemm_bx3_act_kernel: D[b] = alpha * A_b @ B_b with both operands split inside the kernel -- the four operand layouts of the
     attention contractions (scores: A m-contiguous, B n-contiguous; values: A k-contiguous; dv / dk: B k-contiguous), K = 80
     exercises the tail stage, per-batch strides larger than the matrices (q / k / v are channel slices of one tensor)."""
-    nb, M, Nn, K = 5, 192, 256, 80 if not (a_row and b_kc) else 256
+    nb, M, Nn, K = 5, 192, 256, (32 if a_row else 80) if not (a_row and b_kc) else 256        # K = 32: a multi-head score product (head_dim 32)
     gA = torch.randn(nb, 3, M * K, generator=g(0))          # operand = slice 1 of a wider buffer
     gB = torch.randn(nb, 2, K * Nn, generator=g(1))
     A = gA[:, 1].reshape(nb, M, K) if a_row else gA[:, 1].reshape(nb, K, M).transpose(1, 2)      # logical [nb, M, K]

@@ -1937,7 +1937,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     const int tile = vd_gemm_tile(&d);
     VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, "
                            "C %% 16 == 0, M >= 64, or a VD_B_PLAIN product with shared A, NP %% 128 == 0, K %% 16 == 0, M >= 64; "
-                           "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 64, M >= 64");
+                           "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 32, M >= 64");
     VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     hipStream_t st = (hipStream_t)stream;

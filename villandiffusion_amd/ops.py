@@ -188,7 +188,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
 
 def gemm_bx3_act_eligible(M, K, NP) -> bool:
     """Products of two activation matrices (attention) the split-precision kernel takes (vd_gemm_desc.math = 1)."""
-    return NP % 128 == 0 and K % 16 == 0 and K >= 64 and M >= 64 and M % 4 == 0
+    return NP % 128 == 0 and K % 16 == 0 and K >= 32 and M >= 64 and M % 4 == 0
 
 
 def gemm_bx3_eligible(M, K, NP, nb=None) -> bool:
