@@ -35,7 +35,10 @@ def _worker(rank, world, port, out):
 def test_sharding_and_flat_allreduce_world2():
     mgr = mp.Manager()
     out = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                 # a port the OS says is free right now (a fixed one can be left in TIME_WAIT by an earlier test)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: True, 1: True}
 
