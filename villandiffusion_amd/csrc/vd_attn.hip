@@ -41,6 +41,79 @@ __global__ __launch_bounds__(256) void softmax_col_fwd_kernel(float* __restrict_
     }
 }
 
+// N <= 256: the wave's N/4 <= 64 rows of a column stay in registers -- one read, one exp and one write per score (the general
+// kernel above re-reads the tile and evaluates three exponentials per element).
+template <int R>   // rows per wave = ceil(N / 4) <= R
+__global__ __launch_bounds__(256) void softmax_col_fwd_reg_kernel(float* __restrict__ S, int N) {
+    __shared__ float smax[4][64], ssum[4][64];
+    const int chunks = (N + 63) / 64;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = ch * 64 + lane;
+    const bool col = i < N;
+    float* __restrict__ Sb = S + (int64_t)b * N * N + (col ? i : 0);
+    float v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int j = w + 4 * k;
+        v[k] = (col && j < N) ? Sb[(int64_t)j * N] : -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < R; ++k) m = fmaxf(m, v[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        v[k] = (m == -INFINITY) ? 0.f : __expf(v[k] - m);
+        s += v[k];
+    }
+    smax[w][lane] = m;
+    ssum[w][lane] = s;
+    __syncthreads();
+    const float M = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
+    float Z = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Z += (smax[k][lane] == -INFINITY) ? 0.f : ssum[k][lane] * __expf(smax[k][lane] - M);
+    const float f = (m == -INFINITY) ? 0.f : __expf(m - M) / Z;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int j = w + 4 * k;
+        if (col && j < N) Sb[(int64_t)j * N] = v[k] * f;
+    }
+}
+
+// dS = scale * P * (dP - sum_j P*dP), in place on dP; P and dP held in registers (N <= 256).
+template <int R>
+__global__ __launch_bounds__(256) void softmax_col_bwd_reg_kernel(const float* __restrict__ P, float* __restrict__ dP, int N, float scale) {
+    __shared__ float sdot[4][64];
+    const int chunks = (N + 63) / 64;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = ch * 64 + lane;
+    const bool col = i < N;
+    const float* __restrict__ Pb = P + (int64_t)b * N * N + (col ? i : 0);
+    float* __restrict__ Db = dP + (int64_t)b * N * N + (col ? i : 0);
+    float p[R], g[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int j = w + 4 * k;
+        const bool ok = col && j < N;
+        p[k] = ok ? Pb[(int64_t)j * N] : 0.f;
+        g[k] = ok ? Db[(int64_t)j * N] : 0.f;
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int k = 0; k < R; ++k) d += p[k] * g[k];
+    sdot[w][lane] = d;
+    __syncthreads();
+    const float dot = (sdot[0][lane] + sdot[1][lane]) + (sdot[2][lane] + sdot[3][lane]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int j = w + 4 * k;
+        if (col && j < N) Db[(int64_t)j * N] = scale * p[k] * (g[k] - dot);
+    }
+}
+
 // dS = scale * P * (dP - sum_j P*dP), in place on dP.
 __global__ __launch_bounds__(256) void softmax_col_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int N,
                                                               float scale) {
@@ -157,14 +230,21 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
 
 extern "C" int vd_softmax_col_fwd(float* S, int nb, int N, void* stream) {
     VD_REQUIRE(S && nb > 0 && N > 0, "vd_softmax_col_fwd: bad args");
-    hipLaunchKernelGGL(softmax_col_fwd_kernel, dim3(nb * ((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, S, N);
+    const dim3 grid(nb * ((N + 63) / 64));
+    if (N <= 64) hipLaunchKernelGGL((softmax_col_fwd_reg_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, S, N);
+    else if (N <= 256) hipLaunchKernelGGL((softmax_col_fwd_reg_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, S, N);
+    else hipLaunchKernelGGL(softmax_col_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, N);
     VD_LAUNCH_CHECK("vd_softmax_col_fwd");
     return 0;
 }
 
 extern "C" int vd_softmax_col_bwd(const float* P, float* dP, int nb, int N, float scale, void* stream) {
     VD_REQUIRE(P && dP && nb > 0 && N > 0, "vd_softmax_col_bwd: bad args");
-    hipLaunchKernelGGL(softmax_col_bwd_kernel, dim3(nb * ((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, P, dP, N, scale);
+    const dim3 grid(nb * ((N + 63) / 64));
+    if (N <= 64) hipLaunchKernelGGL((softmax_col_bwd_reg_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, P, dP, N, scale);
+    else if (N <= 128) hipLaunchKernelGGL((softmax_col_bwd_reg_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, P, dP, N, scale);
+    else if (N <= 256) hipLaunchKernelGGL((softmax_col_bwd_reg_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, P, dP, N, scale);
+    else hipLaunchKernelGGL(softmax_col_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, dP, N, scale);
     VD_LAUNCH_CHECK("vd_softmax_col_bwd");
     return 0;
 }
