@@ -58,3 +58,62 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(lib.VillanHipError, match="no CPU fallback"):
         lib.load()
+
+
+def test_split_precision_planner_agrees_with_the_python_side_eligibility():
+    """vd_gemm_tile / vd_conv_wgrad_plan are pure host functions: the kernels the library would pick must match the predicates the
+    host side (ops.*_eligible) uses to decide whether to hand over packed operands / math = 1 -- a mismatch would surface as
+    VD_EINVAL at run time on some exotic layer shape.  No compute calls, no GPU."""
+    import ctypes as C
+    from villandiffusion_amd import lib, ops
+    from villandiffusion_amd.lib import (A_COL, A_ROW, B_CONV3, B_CONV3_S2, B_CONV3_T, B_CONV3_UP, B_KCONTIG, B_PLAIN, GemmDesc,
+                                         WgradDesc)
+    h = lib.load()
+    FAKE = 0x10000                                   # 16-byte aligned dummy addresses: the planners only look at alignment
+    for mode in (B_CONV3, B_CONV3_T, B_CONV3_UP, B_CONV3_S2):
+        for OW in (2, 4, 8, 16, 24, 32, 64, 96, 128, 256):
+            for (M, Cc) in ((128, 128), (64, 16), (200, 384), (32, 128), (128, 24), (3, 128), (128, 3)):
+                for nb in (1, 3, 128):
+                    OH = OW
+                    H = OH // 2 if mode == B_CONV3_UP else (2 * OH if mode == B_CONV3_S2 else OH)
+                    if H < 1:
+                        continue
+                    d = GemmDesc()
+                    d.A, d.B, d.D, d.a_packed = FAKE, FAKE, FAKE, FAKE
+                    d.a_packed_mpad = (M + 127) // 128 * 128
+                    d.M, d.N, d.K, d.NP = M, nb * OH * OW, Cc * 9, OH * OW
+                    d.a_mode, d.b_mode = A_ROW, mode
+                    d.C, d.H, d.W, d.OH, d.OW = Cc, H, H, OH, OW
+                    d.lda, d.b_bstride, d.ldd, d.d_bstride, d.alpha = Cc * 9, Cc * H * H, OH * OW, M * OH * OW, 1.0
+                    want = ops.bx3_eligible(M, Cc, OH, OW, mode)
+                    got = h.vd_gemm_tile(C.byref(d))
+                    assert (got == 8) == want and got in (8, -1), (mode, OW, M, Cc, nb, got, want)
+                    if mode in (B_CONV3, B_CONV3_UP):
+                        w = WgradDesc()
+                        w.dY, w.X, w.dW = FAKE, FAKE, FAKE
+                        w.M, w.C, w.T, w.nb, w.NP = M, Cc, 9, nb, OH * OW
+                        w.H, w.W, w.OH, w.OW, w.mode, w.math = H, H, OH, OW, mode, 1
+                        w.dy_bstride, w.x_bstride = M * OH * OW, Cc * H * H
+                        tile, splits = C.c_int32(0), C.c_int32(0)
+                        assert h.vd_conv_wgrad_plan(C.byref(w), C.byref(tile), C.byref(splits)) == 0
+                        assert (tile.value == 4) == ops.wgrad_bx3_eligible(M, Cc, OH, OW, mode), (mode, OW, M, Cc, nb, tile.value)
+    # 1x1 convolutions (shared packed A) and activation products (math = 1)
+    for NP in (16, 64, 100, 256, 1024):
+        for (M, K) in ((256, 512), (64, 16), (200, 80), (32, 256), (256, 24)):
+            for nb in (1, 2, 8, 128):
+                d = GemmDesc()
+                d.A, d.B, d.D, d.a_packed = FAKE, FAKE, FAKE, FAKE
+                d.a_packed_mpad = (M + 127) // 128 * 128
+                d.M, d.N, d.K, d.NP = M, nb * NP, K, NP
+                d.a_mode, d.b_mode = A_ROW, B_PLAIN
+                d.lda, d.ldb, d.b_bstride, d.ldd, d.d_bstride, d.alpha = K, NP, K * NP, NP, M * NP, 1.0
+                assert (h.vd_gemm_tile(C.byref(d)) == 9) == ops.gemm_bx3_eligible(M, K, NP, nb), (NP, M, K, nb)
+                for a_mode, b_mode in ((A_COL, B_PLAIN), (A_ROW, B_PLAIN), (A_ROW, B_KCONTIG)):
+                    e = GemmDesc()
+                    e.A, e.B, e.D, e.math = FAKE, FAKE, FAKE, 1
+                    e.M, e.N, e.K, e.NP = M, nb * NP, K, NP
+                    e.a_mode, e.b_mode = a_mode, b_mode
+                    e.lda = K if a_mode == A_ROW else M
+                    e.ldb = K if b_mode == B_KCONTIG else NP
+                    e.a_bstride, e.b_bstride, e.ldd, e.d_bstride, e.alpha = M * K, K * NP, NP, M * NP, 1.0
+                    assert (h.vd_gemm_tile(C.byref(e)) == 10) == ops.gemm_bx3_act_eligible(M, K, NP), (NP, M, K, nb, a_mode, b_mode)
