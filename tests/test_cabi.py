@@ -97,6 +97,22 @@ def test_split_precision_planner_agrees_with_the_python_side_eligibility():
                         tile, splits = C.c_int32(0), C.c_int32(0)
                         assert h.vd_conv_wgrad_plan(C.byref(w), C.byref(tile), C.byref(splits)) == 0
                         assert (tile.value == 4) == ops.wgrad_bx3_eligible(M, Cc, OH, OW, mode), (mode, OW, M, Cc, nb, tile.value)
+    # non-square images: only the row-segment (wide) tiles take them
+    for (OH, OW) in ((16, 64), (3, 128), (10, 256), (48, 96), (16, 32), (8, 16)):
+        for mode in (B_CONV3, B_CONV3_T):
+            d = GemmDesc()
+            d.A, d.B, d.D, d.a_packed, d.a_packed_mpad = FAKE, FAKE, FAKE, FAKE, 128
+            d.M, d.N, d.K, d.NP, d.a_mode, d.b_mode = 128, 2 * OH * OW, 64 * 9, OH * OW, A_ROW, mode
+            d.C, d.H, d.W, d.OH, d.OW = 64, OH, OW, OH, OW
+            d.lda, d.b_bstride, d.ldd, d.d_bstride, d.alpha = 64 * 9, 64 * OH * OW, OH * OW, 128 * OH * OW, 1.0
+            assert (h.vd_gemm_tile(C.byref(d)) == 8) == ops.bx3_eligible(128, 64, OH, OW, mode), (OH, OW, mode)
+        w = WgradDesc()
+        w.dY, w.X, w.dW = FAKE, FAKE, FAKE
+        w.M, w.C, w.T, w.nb, w.NP, w.H, w.W, w.OH, w.OW, w.mode, w.math = 128, 64, 9, 2, OH * OW, OH, OW, OH, OW, B_CONV3, 1
+        w.dy_bstride, w.x_bstride = 128 * OH * OW, 64 * OH * OW
+        tile, splits = C.c_int32(0), C.c_int32(0)
+        h.vd_conv_wgrad_plan(C.byref(w), C.byref(tile), C.byref(splits))
+        assert (tile.value == 4) == ops.wgrad_bx3_eligible(128, 64, OH, OW, B_CONV3), (OH, OW, tile.value)
     # 1x1 convolutions (shared packed A) and activation products (math = 1)
     for NP in (16, 64, 100, 256, 1024):
         for (M, K) in ((256, 512), (64, 16), (200, 80), (32, 256), (256, 24)):
