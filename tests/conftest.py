@@ -19,7 +19,7 @@ def pytest_collection_modifyitems(config, items):
         return
     for it in items:
         if it.get_closest_marker("timeout") is None:
-            it.add_marker(pytest.mark.timeout(300))
+            it.add_marker(pytest.mark.timeout(480))
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
