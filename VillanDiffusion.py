@@ -141,21 +141,27 @@ def setup(args: argparse.Namespace) -> TrainingConfig:
     if bs < cfg.batch:
         raise ValueError(f"batch size {cfg.batch} should be smaller or equal to {bs} for dataset {cfg.dataset}")
     cfg.gradient_accumulation_steps = int(bs // cfg.batch)
+    # One process per GPU (torchrun): every rank computes the same config, but the existing-directory check, the directory
+    # creation and the JSON side files belong to rank 0 alone -- main() puts a barrier behind it.  (The reference is a single
+    # process driving nn.DataParallel, :440, so it has no such distinction.)
+    rank0 = int(os.environ.get("RANK", "0")) == 0
     if mode in (MODE_TRAIN, MODE_TRAIN_MEASURE):
         cfg.output_dir = os.path.join(cfg.result, naming_fn(cfg))
-        if os.path.isdir(cfg.output_dir) and not cfg.overwrite:
-            raise ValueError(f"Output directory: {cfg.output_dir} has already been created, please set overwrite flag --overwrite or -o")
-        os.makedirs(cfg.output_dir, exist_ok=True)
-        with open(os.path.join(cfg.output_dir, "args.json"), "w") as f:
-            json.dump({k: v for k, v in vars(args).items()}, f, indent=2)
-        with open(os.path.join(cfg.output_dir, "config.json"), "w") as f:
-            json.dump({k: v for k, v in vars(cfg).items() if k != "extra"}, f, indent=2)
-    elif mode in (MODE_SAMPLING, MODE_MEASURE):                        # :303-306 sampling.json / measure.json = the effective config
+        if rank0:
+            if os.path.isdir(cfg.output_dir) and not cfg.overwrite:
+                raise ValueError(f"Output directory: {cfg.output_dir} has already been created, please set overwrite flag --overwrite or -o")
+            os.makedirs(cfg.output_dir, exist_ok=True)
+            with open(os.path.join(cfg.output_dir, "args.json"), "w") as f:
+                json.dump({k: v for k, v in vars(args).items()}, f, indent=2)
+            with open(os.path.join(cfg.output_dir, "config.json"), "w") as f:
+                json.dump({k: v for k, v in vars(cfg).items() if k != "extra"}, f, indent=2)
+    elif mode in (MODE_SAMPLING, MODE_MEASURE) and rank0:              # :303-306 sampling.json / measure.json = the effective config
         with open(os.path.join(cfg.output_dir, f"{mode}.json"), "w") as f:
             json.dump({k: v for k, v in vars(cfg).items() if k != "extra"}, f, indent=2)
     cfg.ckpt_path = os.path.join(cfg.output_dir, cfg.ckpt_dir)
     cfg.data_ckpt_path = os.path.join(cfg.output_dir, cfg.data_ckpt_dir)
-    os.makedirs(cfg.ckpt_path, exist_ok=True)                          # :312-315
+    if rank0:
+        os.makedirs(cfg.ckpt_path, exist_ok=True)                      # :312-315
     return cfg
 
 
@@ -363,13 +369,21 @@ TARGET_LATENT_KEY = "target"
 
 
 def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
+    """reference :1117-1196.  Kept as written there: grids and checkpoints carry the 0-based epoch index (`sampling(config, epoch,
+    ...)`, `checkpoint(cur_epoch=epoch)`), a grid `0000.png` is sampled before the first step (on resume too), training ends with a
+    checkpoint and the `final` grid, and --mode resume restarts AT the recorded epoch (`range(start_epoch, epoch)` with the epoch
+    index the last checkpoint stored, :457-461) with the model taken from the run directory.  Not kept: the reference swallows
+    training exceptions (:1189-1191); here they propagate."""
     import torch
     from loss import LossFn
     from model import DiffuserModelSched
     from villandiffusion_amd.trainer import Trainer
+    if cfg.mode == MODE_RESUME:                                        # the run directory setup() resolved (reference: config.ckpt IS that path)
+        src = cfg.output_dir
+    else:
+        src = cfg.ckpt if cfg.ckpt is not None else DiffuserModelSched.MODEL_DEFAULT
     model, vae, noise_sched, get_pipeline = DiffuserModelSched.get_model_sched(
-        image_size=dsl.image_size, channels=dsl.channel, ckpt=cfg.ckpt if cfg.ckpt is not None else DiffuserModelSched.MODEL_DEFAULT,
-        sde_type=cfg.sde_type, clip_sample=cfg.clip, noise_sched_type=cfg.sched)
+        image_size=dsl.image_size, channels=dsl.channel, ckpt=src, sde_type=cfg.sde_type, clip_sample=cfg.clip, noise_sched_type=cfg.sched)
     if world > 1:                                                      # identical replicas
         torch.distributed.broadcast(model.flat_param, src=0)
     loss_fn = LossFn(noise_sched=noise_sched, sde_type=cfg.sde_type, loss_type="l2", psi=cfg.psi, solver_type=cfg.solver_type,
@@ -381,11 +395,12 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
     if cfg.mode == MODE_RESUME:
         trainer.load_state_dict(torch.load(os.path.join(cfg.ckpt_path, "trainer.pt"), map_location=model.device))
         d = torch.load(cfg.data_ckpt_path)
-        start_epoch, step = d["epoch"], d["step"]
+        start_epoch, step = int(d["epoch"]), int(d["step"])
     pipeline = get_pipeline(None, model, vae, noise_sched)
     if rank == 0:
         sampling(cfg, 0, pipeline, dsl)
     T = noise_sched.config.num_train_timesteps
+    epoch = start_epoch
     for epoch in range(start_epoch, cfg.epoch):
         loader = dsl.get_dataloader(rank=rank, world=world, epoch=epoch, full=False)
         nb = len(loader)
@@ -398,9 +413,12 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
                 print(f"epoch {epoch} step {step} loss {float(loss):.5f} lr {trainer.lr:.3e}", flush=True)
         if rank == 0:
             if (epoch + 1) % cfg.save_image_epochs == 0 or epoch == cfg.epoch - 1:
-                sampling(cfg, epoch + 1, pipeline, dsl)
+                sampling(cfg, epoch, pipeline, dsl)
             if (epoch + 1) % cfg.save_model_epochs == 0 or epoch == cfg.epoch - 1:
-                checkpoint(cfg, trainer, pipeline, epoch + 1, step)
+                checkpoint(cfg, trainer, pipeline, epoch, step)
+    if rank == 0:                                                      # reference :1192-1195
+        checkpoint(cfg, trainer, pipeline, epoch, step)
+        sampling(cfg, "final", pipeline, dsl)
     return pipeline
 
 
@@ -408,6 +426,9 @@ def main(argv: Optional[List[str]] = None):
     args = parse_args(argv)
     cfg = setup(args)
     rank, world, _ = _dist()
+    if world > 1:                                                      # rank 0 has created the run directory and its side files
+        import torch.distributed as dist
+        dist.barrier()
     dsl = get_data_loader(cfg)
     if cfg.mode in (MODE_TRAIN, MODE_RESUME, MODE_TRAIN_MEASURE):
         pipeline = train_loop(cfg, dsl, rank, world)

@@ -229,6 +229,13 @@ int vd_qsample_backdoor(const float* x0, const float* R, const float* eps, const
 /* loss = mean((y - pred*pscale[b])^2); dpred = 2*(pred*pscale-y)*pscale/n * gscale.  partial: >= 1024 floats. */
 int vd_mse_fwd_bwd(const float* pred, const float* y, const float* pscale, float* dpred, float* loss,
                    float* partial, int B, int64_t chw, float gscale, void* stream);
+/* The same with the reference's selectable norm (loss.py:849-858, picked at loss.py:994,1003): kind VD_LOSS_L2 = F.mse_loss,
+ * VD_LOSS_L1 = F.l1_loss (gradient sign(d), 0 at d == 0), VD_LOSS_HUBER = F.smooth_l1_loss (beta 1); all reduced by the mean. */
+#define VD_LOSS_L2 0
+#define VD_LOSS_L1 1
+#define VD_LOSS_HUBER 2
+int vd_loss_fwd_bwd(const float* pred, const float* y, const float* pscale, float* dpred, float* loss,
+                    float* partial, int B, int64_t chw, float gscale, int kind, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9 -- global grad-norm clip + Adam on flat buffers (VillanDiffusion.py:445,1165-1169).

@@ -86,7 +86,7 @@ def R_coef_ve(sigmas, rhos_hat_w: float = 1.0, psi: float = 1, solver_type: str 
 
 
 class LossFnRef:
-    """loss.py:825-1006 (l2 only: the driver hard-codes "l2", VillanDiffusion.py:1128)."""
+    """loss.py:825-1006; loss_type l1 / l2 / huber as loss.py:849-858 (the driver passes "l2", VillanDiffusion.py:1128)."""
 
     def __init__(self, noise_sched, sde_type: str, loss_type: str = "l2", psi: float = 1, solver_type: str = "sde",
                  vp_scale: float = 1.0, ve_scale: float = 1.0, rhos_hat_w: float = 1.0, rhos_hat_b: float = 0.0):
@@ -100,6 +100,18 @@ class LossFnRef:
         else:
             raise NotImplementedError(f"sde_type: {sde_type} isn't implemented")
         self._hs = None
+        if loss_type not in ("l1", "l2", "huber"):
+            raise NotImplementedError()
+
+    def norm(self, pred, target):
+        """loss.py:849-858: elementwise F.l1_loss / F.mse_loss / F.smooth_l1_loss (reduction 'none'); the caller takes .mean()."""
+        d = pred - target
+        if self.loss_type == "l1":
+            return d.abs()
+        if self.loss_type == "l2":
+            return d ** 2
+        a = d.abs()
+        return torch.where(a < 1.0, 0.5 * d * d, a - 0.5)
 
     def tables(self, dtype=torch.float32):
         """loss.py:860-907."""
@@ -133,11 +145,11 @@ class LossFnRef:
         x_noisy, target = self.inputs_targets(x_start, R, timesteps, noise)
         if self.sde_type in (SDE_VP, SDE_LDM):
             pred = model(x_noisy.contiguous(), timesteps.contiguous(), return_dict=False)[0]
-            return ((target - pred) ** 2).mean()
+            return self.norm(pred, target).mean()
         sig = self.sigmas[timesteps]
         pred = model(x_noisy.contiguous(), sig.contiguous(), return_dict=False)[0]
         shp = (len(x_start),) + (1,) * (x_start.dim() - 1)
-        return ((target - (-pred * sig.reshape(shp))) ** 2).mean()
+        return self.norm(-pred * sig.reshape(shp), target).mean()
 
     def p_loss_by_keys(self, batch, model, target_latent_key, poison_latent_key, timesteps, noise=None, **_):
         """loss.py:972-976 (vae=None path: latents are precomputed, VillanDiffusion.py:1159)."""

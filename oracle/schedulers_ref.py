@@ -58,7 +58,26 @@ class _VPBase:
 
 
 class DDPMSchedulerRef(_VPBase):
-    """S1.  fixed_small variance, epsilon prediction."""
+    """S1.  [UPSTREAM diffusers ~0.16 DDPMScheduler._get_variance / step] epsilon prediction; variance_type fixed_small (posterior
+    variance clamped at 1e-20), fixed_small_log (exp(0.5 * log(clamp))), fixed_large (beta_t; what google/ddpm-cifar10-32 ships).
+    fixed_large_log takes sqrt(log(beta)) upstream (NaN), learned / learned_range need a 2C-channel network: rejected."""
+    VARIANCE_TYPES = ("fixed_small", "fixed_small_log", "fixed_large")
+
+    def __init__(self, *a, variance_type="fixed_small", **k):
+        super().__init__(*a, **k)
+        if variance_type not in self.VARIANCE_TYPES:
+            raise NotImplementedError(f"variance_type {variance_type}")
+        self.config.variance_type = variance_type
+
+    def noise_scale(self, a_t, a_prev, cur_beta):
+        """The factor of z in the reverse step (std, not variance)."""
+        vt = self.config.variance_type
+        if vt == "fixed_large":
+            return cur_beta ** 0.5
+        var = torch.clamp((1 - a_prev) / (1 - a_t) * cur_beta, min=1e-20)
+        if vt == "fixed_small_log":
+            return torch.exp(0.5 * torch.log(var))
+        return var ** 0.5
 
     def set_timesteps(self, n: int):
         T = self.config.num_train_timesteps
@@ -84,8 +103,7 @@ class DDPMSchedulerRef(_VPBase):
         prev = c_x0 * x0 + c_xt * sample
         if t > 0:
             z = noise if noise is not None else _randn(model_output.shape, generator, model_output.device, model_output.dtype)
-            var = torch.clamp((1 - a_prev) / (1 - a_t) * cur_beta, min=1e-20)
-            prev = prev + (var ** 0.5) * z
+            prev = prev + self.noise_scale(a_t, a_prev, cur_beta) * z
         return SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
 
 

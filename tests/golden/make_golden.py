@@ -11,7 +11,7 @@ used here (R-coefficient tables, LossFn with a fake scheduler object and an
 analytic stand-in model, box triggers / box targets / masks).  Only numbers
 produced by the reference's own arithmetic are stored; no reference source.
 
-Outputs (committed): loss_tables.npz, loss_batch.npz, backdoor_boxes.npz.
+Outputs (committed): loss_tables.npz, loss_batch.npz, noise_scheduler.npz, backdoor_boxes.npz, ... (see main()).
 """
 import os
 import sys
@@ -114,6 +114,21 @@ def main():
                 batch[key + "/x_t"], batch[key + "/y"] = xt.numpy(), y.numpy()
                 batch[key + "/loss"] = np.float32(loss.item())
     np.savez_compressed(os.path.join(OUT, "loss_batch.npz"), **batch)
+
+    # the reference's own NoiseScheduler (loss.py:62-160) and forward-diffusion samplers q_sample_clean / q_sample_backdoor
+    # (loss.py:175-196): beta / alpha-bar / posterior-variance / R_coef tables for its four beta schedules, and (x_t, target) on the
+    # seeded batch above.  Pins the oracle's DDPM variance table, `add_noise` and the psi = 1 (BadDiffusion) correction.
+    ns = {}
+    for tag, kind in (("linear", "SC_LIN"), ("quadratic", "SC_QUAD"), ("cosine", "SC_COS"), ("sigmoid", "SC_SIGM")):
+        sch = ref_loss.NoiseScheduler(timesteps=1000, scheduler=kind)
+        for attr in ("betas", "alphas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas", "sqrt_alphas_cumprod",
+                     "sqrt_one_minus_alphas_cumprod", "R_coef", "posterior_variance"):
+            ns[f"{tag}/{attr}"] = getattr(sch, attr).numpy()
+        if tag in ("linear", "quadratic"):
+            xc, _ = ref_loss.q_sample_clean(sch, x0, t_vp, noise=eps)
+            xb, yb = ref_loss.q_sample_backdoor(sch, x0, R, t_vp, noise=eps)
+            ns[f"{tag}/q_sample_clean"], ns[f"{tag}/q_sample_backdoor_x"], ns[f"{tag}/q_sample_backdoor_y"] = xc.numpy(), xb.numpy(), yb.numpy()
+    np.savez_compressed(os.path.join(OUT, "noise_scheduler.npz"), **ns)
 
     # box triggers / targets / masks from dataset.Backdoor
     Backdoor = ref_dataset.Backdoor

@@ -334,6 +334,32 @@ def test_qsample_backdoor_bit_exact_and_mse(sde):
     check(dpred, pred.grad, 1e-5, "mse dpred")
 
 
+@pytest.mark.parametrize("kind", ["l2", "l1", "huber"])
+@pytest.mark.parametrize("sde", ["vp", "ve"])
+def test_loss_norms_match_oracle_and_torch(kind, sde):
+    """loss.py:849-858: F.mse_loss / F.l1_loss / F.smooth_l1_loss, mean-reduced; VE feeds -pred * sigma_t (loss.py:1003)."""
+    from oracle import loss_ref as L
+    from oracle.schedulers_ref import DDPMSchedulerRef
+    B = 8
+    lf = L.LossFnRef(DDPMSchedulerRef(), L.SDE_VP, loss_type=kind)
+    y = torch.randn(B, 3, 32, 32, generator=g(0)) * 1.5
+    pred = (torch.randn(B, 3, 32, 32, generator=g(1)) * 1.5).requires_grad_(True)
+    with torch.no_grad():
+        pred[0, 0, 0, :4] = y[0, 0, 0, :4]                     # d == 0: sign(0) = 0 for l1
+    ps = -(torch.rand(B, generator=g(2)) * 3 + 0.1) if sde == "ve" else None
+    pr = pred * ps.view(-1, 1, 1, 1) if ps is not None else pred
+    loss_ref = lf.norm(pr, y).mean()
+    fn = {"l2": F.mse_loss, "l1": F.l1_loss, "huber": F.smooth_l1_loss}[kind]
+    assert torch.equal(loss_ref, fn(input=pr, target=y, reduction="none").mean())
+    loss_ref.backward()
+    dpred, loss, partial = torch.empty(B, 3, 32, 32, device=DEV), torch.empty(1, device=DEV), torch.empty(1024, device=DEV)
+    ops.mse_fwd_bwd(pred.detach().to(DEV), y.to(DEV), dpred, loss, partial, pscale=None if ps is None else ps.to(DEV), gscale=0.5, kind=kind)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    check(dpred, 0.5 * pred.grad, 1e-5, f"{kind} dpred")
+    with pytest.raises(KeyError):
+        ops.mse_fwd_bwd(pred.detach().to(DEV), y.to(DEV), dpred, loss, partial, kind="l3")
+
+
 def test_adam_clip_matches_torch():
     n = 100003
     p0 = torch.randn(n, generator=g(0))

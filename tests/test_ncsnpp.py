@@ -154,7 +154,7 @@ def test_cli_sde_ve_ncsnpp_train_and_sample(tmp_path):
     cfg = json.load(open(os.path.join(run, "unet", "config.json")))
     assert cfg["time_embedding_type"] == "fourier" and cfg["down_block_types"][0] == "SkipDownBlock2D"
     assert json.load(open(os.path.join(run, "model_index.json")))["_class_name"] == "ScoreSdeVePipeline"
-    assert os.path.exists(os.path.join(run, "samples", "0001.png")) and os.path.exists(os.path.join(run, "backdoor_samples", "0001.png"))
+    assert os.path.exists(os.path.join(run, "samples", "0000.png")) and os.path.exists(os.path.join(run, "backdoor_samples", "final.png"))
     # sampling mode takes sde_type from the run's args.json (the reference's mode whitelist rejects --sde_type here)
     argv2 = ["--mode", "sampling", "--ckpt", run, "--sched", "SCORE-SDE-VE-SCHED", "--infer_steps", "4"]
     out = subprocess.run([sys.executable, "-c", code % (argv2,)], cwd=root, env=env, capture_output=True, text=True, timeout=900)

@@ -186,3 +186,74 @@ def test_pndm_timestep_table_and_next_row_sampler_convergence():
                       (R.HeunDiscreteSchedulerRef, exact_sigma), (R.LMSDiscreteSchedulerRef, exact_sigma)]:
         errs = [float((run(mk(), n, x.clone()) - exact).abs().max() / exact.abs().max()) for n in (20, 80)]
         assert errs[1] < errs[0] and errs[1] < 6e-3, (mk.__name__, errs)
+
+
+# ---- pinned by the reference's own loss.NoiseScheduler / q_sample_clean / q_sample_backdoor (loss.py:62-196), which import and run
+# ---- in the build container: tests/golden/noise_scheduler.npz (generated by tests/golden/make_golden.py)
+def _ns():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "noise_scheduler.npz"))
+
+
+def test_beta_tables_match_reference_noise_scheduler():
+    """beta / alpha / alpha-bar of the oracle AND the product schedulers == the reference's tables, bit for bit (linear is the VP
+    recipe, model.py:606-608; the reference's 'quadratic' schedule is diffusers' scaled_linear rule at the same end points)."""
+    from villandiffusion_amd import schedulers as S
+    ns = _ns()
+    for tag, kw in (("linear", dict(beta_schedule="linear")), ("quadratic", dict(beta_schedule="scaled_linear"))):
+        for mk in (DDPMSchedulerRef, S.DDPMScheduler, S.DPMSolverMultistepScheduler, S.UniPCMultistepScheduler):
+            s = mk(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, **kw)
+            assert np.array_equal(s.betas.numpy(), ns[f"{tag}/betas"]), (tag, mk)
+            assert np.array_equal(s.alphas.numpy(), ns[f"{tag}/alphas"])
+            assert np.array_equal(s.alphas_cumprod.numpy(), ns[f"{tag}/alphas_cumprod"])
+
+
+def test_ddpm_variance_table_matches_reference_posterior_variance():
+    """The reference's posterior variance is beta_t (1 - abar_{t-1}) / (1 - abar_t); upstream DDPMScheduler (restated by the oracle and
+    the product) takes beta_t as 1 - abar_t / abar_{t-1}, which carries the fp32 rounding of the abar ratio: relative 6e-8 / beta_t,
+    i.e. up to ~6e-4 at the small-beta end.  Held to 2e-3 relative over all 1000 steps; t = 0 is exactly 0 in both."""
+    from villandiffusion_amd import schedulers as S
+    ns = _ns()
+    pv = ns["linear/posterior_variance"].astype(np.float64)
+    for s in (DDPMSchedulerRef(), S.DDPMScheduler()):
+        ac, one = s.alphas_cumprod, torch.tensor(1.0)
+        var = []
+        for t in range(1000):
+            a_t, a_prev = ac[t], (ac[t - 1] if t > 0 else one)
+            var.append(float((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)))
+        var = np.array(var)
+        assert var[0] == 0.0 and pv[0] == 0.0
+        assert np.abs(var[1:] - pv[1:]).max() / 1.0 <= 1e-6 and (np.abs(var[1:] - pv[1:]) / pv[1:]).max() <= 2e-3
+        # fixed_small noise scale of the scheduler under test == sqrt of that table (clamped at 1e-20), fixed_large == sqrt(beta_t)
+    d_small, d_large = DDPMSchedulerRef(), DDPMSchedulerRef(variance_type="fixed_large")
+    p_small, p_large = S.DDPMScheduler(), S.DDPMScheduler(variance_type="fixed_large")
+    for t in (1, 2, 10, 500, 999):
+        a_t, a_prev = d_small.alphas_cumprod[t], d_small.alphas_cumprod[t - 1]
+        cb = 1 - a_t / a_prev
+        assert abs(float(d_small.noise_scale(a_t, a_prev, cb)) - pv[t] ** 0.5) <= 1e-3 * pv[t] ** 0.5
+        assert abs(float(d_large.noise_scale(a_t, a_prev, cb)) - float(ns["linear/betas"][t]) ** 0.5) <= 1e-3 * float(ns["linear/betas"][t]) ** 0.5
+        assert p_small._noise_scale(a_t, a_prev, cb) == float(d_small.noise_scale(a_t, a_prev, cb))
+        assert p_large._noise_scale(a_t, a_prev, cb) == float(d_large.noise_scale(a_t, a_prev, cb))
+    assert abs(float(d_small.noise_scale(torch.tensor(0.5), torch.tensor(1.0), torch.tensor(0.5))) - 1e-10) < 1e-16        # the 1e-20 clamp
+
+
+def test_add_noise_and_backdoor_qsample_match_reference():
+    """`add_noise` (oracle and product) == loss.q_sample_clean; the psi = 1 / 'sde' inputs and targets of the oracle's LossFnRef ==
+    loss.q_sample_backdoor, on the seeded batch of tests/golden/loss_batch.npz (t = 0, 10, 500, 999).  The reference gathers
+    torch.sqrt tables, the schedulers raise to 0.5 and the loss builds 1 - sqrt(abar) differently: equal to 1 ulp of the terms."""
+    import os
+    from oracle.loss_ref import LossFnRef, SDE_VP
+    from villandiffusion_amd import schedulers as S
+    ns = _ns()
+    b = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_batch.npz"))
+    x0, Rr, eps, t = (torch.from_numpy(b[k]) for k in ("x0", "R", "eps", "t_vp"))
+    for tag, kw in (("linear", dict(beta_schedule="linear")), ("quadratic", dict(beta_schedule="scaled_linear"))):
+        clean = torch.from_numpy(ns[f"{tag}/q_sample_clean"])
+        for s in (DDPMSchedulerRef(**kw), S.DDPMScheduler(**kw), S.DDIMScheduler(**kw)):
+            assert torch.allclose(s.add_noise(x0, eps, t), clean, rtol=0, atol=5e-7), tag
+        lf = LossFnRef(DDPMSchedulerRef(**kw), SDE_VP, psi=1, solver_type="sde")
+        xt, y = lf.inputs_targets(x0, Rr, t, eps)
+        assert torch.allclose(xt, torch.from_numpy(ns[f"{tag}/q_sample_backdoor_x"]), rtol=0, atol=1e-6)
+        assert torch.allclose(y, torch.from_numpy(ns[f"{tag}/q_sample_backdoor_y"]), rtol=0, atol=1e-6)
+        step, coef = lf.tables()
+        assert np.abs(coef.numpy() - ns[f"{tag}/R_coef"]).max() <= 1e-6          # BadDiffusion R coefficient (loss.py:103)

@@ -173,5 +173,5 @@ def test_cli_sde_ldm_on_latent_dataset(tmp_path):
     run = [d for d, _, files in os.walk(res) if "model_index.json" in files][0]
     idx = json.load(open(os.path.join(run, "model_index.json")))
     assert idx["_class_name"] == "LDMPipeline" and "vqvae" in idx
-    for f in ("vqvae/config.json", "vqvae/diffusion_pytorch_model.safetensors", "unet/config.json", "samples/0001.png", "backdoor_samples/0001.png"):
+    for f in ("vqvae/config.json", "vqvae/diffusion_pytorch_model.safetensors", "unet/config.json", "samples/0000.png", "backdoor_samples/final.png"):
         assert os.path.exists(os.path.join(run, f)), f

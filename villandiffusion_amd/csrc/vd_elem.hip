@@ -103,7 +103,10 @@ __global__ void qsample_kernel(const float* __restrict__ x0, const float* __rest
     }
 }
 
-// partial[block] = sum over the block's elements of (y - pred*ps)^2 ; also writes dpred.
+// partial[block] = sum over the block's elements of norm(pred*ps - y); also writes dpred = gcoef * norm'(d) * ps.
+// KIND 0: F.mse_loss (d^2; gcoef carries the factor 2), 1: F.l1_loss (|d|, gradient sign(d) with sign(0) = 0),
+// 2: F.smooth_l1_loss with beta = 1 (0.5 d^2 inside |d| < 1, |d| - 0.5 outside)  -- loss.py:849-858.
+template <int KIND>
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ y,
                                                   const float* __restrict__ pscale, float* __restrict__ dpred,
                                                   float* __restrict__ partial, int B, int64_t chw, float gcoef) {
@@ -112,8 +115,20 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
     GRID_STRIDE(i, (int64_t)B * chw) {
         const float ps = pscale ? pscale[i / chw] : 1.0f;
         const float d = pred[i] * ps - y[i];
-        s += d * d;
-        if (dpred) dpred[i] = gcoef * d * ps;
+        float v, g;
+        if (KIND == 0) {
+            v = d * d;
+            g = d;
+        } else if (KIND == 1) {
+            v = fabsf(d);
+            g = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        } else {
+            const float a = fabsf(d);
+            v = (a < 1.f) ? 0.5f * d * d : a - 0.5f;
+            g = (a < 1.f) ? d : ((d > 0.f) ? 1.f : -1.f);
+        }
+        s += v;
+        if (dpred) dpred[i] = gcoef * g * ps;
     }
     s = block_sum_256(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -377,17 +392,28 @@ extern "C" int vd_qsample_backdoor(const float* x0, const float* R, const float*
     return 0;
 }
 
-extern "C" int vd_mse_fwd_bwd(const float* pred, const float* y, const float* pscale, float* dpred, float* loss, float* partial,
-                              int B, int64_t chw, float gscale, void* stream) {
-    VD_REQUIRE(pred && y && loss && partial && B > 0 && chw > 0, "vd_mse_fwd_bwd: bad args");
+extern "C" int vd_loss_fwd_bwd(const float* pred, const float* y, const float* pscale, float* dpred, float* loss, float* partial,
+                               int B, int64_t chw, float gscale, int kind, void* stream) {
+    VD_REQUIRE(pred && y && loss && partial && B > 0 && chw > 0, "vd_loss_fwd_bwd: bad args");
+    VD_REQUIRE(kind >= VD_LOSS_L2 && kind <= VD_LOSS_HUBER, "vd_loss_fwd_bwd: kind %d (0 = l2, 1 = l1, 2 = huber)", kind);
     const int64_t n = (int64_t)B * chw;
     int grid = egrid(n);
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, ST, pred, y, pscale, dpred, partial, B, chw,
-                       2.0f * gscale / (float)n);
+    const float gcoef = (kind == VD_LOSS_L2 ? 2.0f : 1.0f) * gscale / (float)n;
+    if (kind == VD_LOSS_L2)
+        hipLaunchKernelGGL(mse_kernel<0>, dim3(grid), dim3(256), 0, ST, pred, y, pscale, dpred, partial, B, chw, gcoef);
+    else if (kind == VD_LOSS_L1)
+        hipLaunchKernelGGL(mse_kernel<1>, dim3(grid), dim3(256), 0, ST, pred, y, pscale, dpred, partial, B, chw, gcoef);
+    else
+        hipLaunchKernelGGL(mse_kernel<2>, dim3(grid), dim3(256), 0, ST, pred, y, pscale, dpred, partial, B, chw, gcoef);
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, ST, partial, grid, 1.0f / (float)n, loss);
-    VD_LAUNCH_CHECK("vd_mse_fwd_bwd");
+    VD_LAUNCH_CHECK("vd_loss_fwd_bwd");
     return 0;
+}
+
+extern "C" int vd_mse_fwd_bwd(const float* pred, const float* y, const float* pscale, float* dpred, float* loss, float* partial,
+                              int B, int64_t chw, float gscale, void* stream) {
+    return vd_loss_fwd_bwd(pred, y, pscale, dpred, loss, partial, B, chw, gscale, VD_LOSS_L2, stream);
 }
 
 extern "C" int vd_l2norm_sq(const float* g, int64_t n, float* partial, float* out_sq, void* stream) {

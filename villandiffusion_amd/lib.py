@@ -76,6 +76,7 @@ PROTOTYPES = {
     "vd_lincomb": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_f32), _i32, _i64, _vp]),
     "vd_qsample_backdoor": (_i32, [_vp] * 10 + [_i32, _i64, _vp]),
     "vd_mse_fwd_bwd": (_i32, [_vp] * 6 + [_i32, _i64, _f32, _vp]),
+    "vd_loss_fwd_bwd": (_i32, [_vp] * 6 + [_i32, _i64, _f32, _i32, _vp]),
     "vd_l2norm_sq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "vd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "vd_sched_step": (_i32, [_vp] * 5 + [_i64] + [_f32] * 7 + [C.c_uint64, C.c_uint64, _vp]),

@@ -91,17 +91,17 @@ def get_R_coef_gen_ve_reduce(sigmas, hs=None, rhos_hat_w: float = 1.0, psi: floa
 # ---------------------------------------------------------------------------------------------- fused MSE
 class _MSE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, y, pscale, gscale, partial):
+    def forward(ctx, pred, y, pscale, gscale, partial, kind="l2"):
         dpred = torch.empty_like(pred)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
-        ops.mse_fwd_bwd(pred.contiguous(), y, dpred, loss, partial, pscale=pscale, gscale=gscale)
+        ops.mse_fwd_bwd(pred.contiguous(), y, dpred, loss, partial, pscale=pscale, gscale=gscale, kind=kind)
         ctx.save_for_backward(dpred)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return dpred * g, None, None, None, None
+        return dpred * g, None, None, None, None, None
 
 
 class LossFn:
@@ -112,9 +112,9 @@ class LossFn:
                  vp_scale: float = 1.0, ve_scale: float = 1.0, rhos_hat_w: float = 1.0, rhos_hat_b: float = 0.0):
         if sde_type not in (SDE_VP, SDE_VE, SDE_LDM):
             raise NotImplementedError(f"sde_type: {sde_type} isn't implemented")
-        if loss_type != "l2":
-            raise NotImplementedError("only loss_type='l2' is implemented natively (the driver hard-codes it, "
-                                      "VillanDiffusion.py:1128)")
+        if loss_type not in ops.LOSS_KINDS:       # loss.py:849-858: l1 / l2 / huber, anything else raises
+            raise NotImplementedError(f"loss_type: {loss_type} isn't implemented")
+        self._loss_type = loss_type
         self._sched, self._sde, self._psi, self._solver = noise_sched, sde_type, psi, solver_type
         # the schedule is captured HERE like the reference does (loss.py:829-834): a VE pipeline's set_sigmas(n) later
         # replaces noise_sched.sigmas by the n-step inference table, which must not shrink the training tables
@@ -181,10 +181,10 @@ class LossFn:
         x_t, y = self.get_inputs_targets(x_start, R, timesteps, noise.to(dev))
         if self._sde in (SDE_VP, SDE_LDM):
             pred = model(x_t, timesteps.contiguous(), return_dict=False)[0]
-            return _MSE.apply(pred, y, None, self.grad_scale, self._partial)
+            return _MSE.apply(pred, y, None, self.grad_scale, self._partial, self._loss_type)
         sig_t = self._dev_tabs[3][timesteps]
         pred = model(x_t, sig_t.contiguous(), return_dict=False)[0]
-        return _MSE.apply(pred, y, (-sig_t).contiguous(), self.grad_scale, self._partial)
+        return _MSE.apply(pred, y, (-sig_t).contiguous(), self.grad_scale, self._partial, self._loss_type)
 
     def p_loss_by_keys(self, batch, model, target_latent_key, poison_latent_key, timesteps, vae=None, noise=None,
                        weight_dtype=None, scaling_factor=None):

@@ -153,7 +153,10 @@ class DiffuserModelSched:
             pipe = DDPMPipeline.from_pretrained(d)
             model, loaded_sched = pipe.unet, pipe.scheduler
         if noise_sched_type is None:
-            noise_sched = loaded_sched if loaded_sched is not None else DDPMScheduler(clip_sample=clip, **beta)
+            # model.py:654 keeps the checkpoint's own scheduler; for the from-scratch ids that is the scheduler of
+            # google/ddpm-cifar10-32 (model.py:813), whose scheduler_config.json [UPSTREAM, from memory: not fetchable here] is
+            # {linear 1e-4..0.02, T 1000, clip_sample true, variance_type "fixed_large"}
+            noise_sched = loaded_sched if loaded_sched is not None else DDPMScheduler(clip_sample=True, variance_type="fixed_large", **beta)
             pipe_cls = DDPMPipeline
         else:
             noise_sched, pipe_cls = cls._make_sched(noise_sched_type, clip, clip_range, beta)

@@ -479,12 +479,16 @@ def qsample_backdoor(x0, R, eps, t, tab_a, tab_s, tab_step, tab_coef, x_t, y):
     return x_t, y
 
 
-def mse_fwd_bwd(pred, y, dpred, loss, partial, pscale=None, gscale=1.0):
+LOSS_KINDS = {"l2": 0, "l1": 1, "huber": 2}
+
+
+def mse_fwd_bwd(pred, y, dpred, loss, partial, pscale=None, gscale=1.0, kind="l2"):
+    """loss = mean(norm(pred * pscale[b] - y)) and its gradient in one pass; kind = the reference's loss_type (loss.py:849-858)."""
     Bn = pred.shape[0]
     chw = pred.numel() // Bn
     assert pred.is_contiguous() and y.is_contiguous() and partial.numel() >= 1024
-    L.check(_lib().vd_mse_fwd_bwd(_p(pred), _p(y), _p(pscale), _p(dpred), _p(loss), _p(partial), Bn, chw, gscale, _s()),
-            "vd_mse_fwd_bwd")
+    L.check(_lib().vd_loss_fwd_bwd(_p(pred), _p(y), _p(pscale), _p(dpred), _p(loss), _p(partial), Bn, chw, gscale,
+                                   LOSS_KINDS[kind], _s()), "vd_loss_fwd_bwd")
     return loss
 
 

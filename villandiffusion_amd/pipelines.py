@@ -152,8 +152,10 @@ class DiffusionPipeline:
         with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
             scfg = json.load(f)
         name = scfg.pop("_class_name", "DDPMScheduler")
-        scfg = {k: v for k, v in scfg.items() if not k.startswith("_") and k != "prediction_type"}
-        sched = SCHEDULER_CLASSES.get(name, DDPMScheduler)(**scfg)
+        scfg = {k: v for k, v in scfg.items() if not k.startswith("_")}
+        if name not in SCHEDULER_CLASSES:
+            raise NotImplementedError(f"{path}: scheduler class '{name}' (implemented: {sorted(SCHEDULER_CLASSES)})")
+        sched = SCHEDULER_CLASSES[name](**scfg)       # unsupported variance_type / prediction_type raise in the constructor
         vdir = os.path.join(path, "vqvae")
         if os.path.isdir(vdir):
             from .vqmodel import VQModel

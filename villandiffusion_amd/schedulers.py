@@ -49,7 +49,9 @@ class SchedulerBase:
     order = 1
 
     def __init__(self, num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, beta_schedule="linear",
-                 clip_sample=True, clip_sample_range=1.0, trained_betas=None, **extra):
+                 clip_sample=True, clip_sample_range=1.0, trained_betas=None, prediction_type="epsilon", **extra):
+        if prediction_type != "epsilon":     # the reference only ever builds epsilon-prediction schedulers (model.py:606-652)
+            raise NotImplementedError(f"{type(self).__name__}: prediction_type '{prediction_type}' (only 'epsilon' is implemented)")
         self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                               beta_schedule=beta_schedule, clip_sample=clip_sample, clip_sample_range=clip_sample_range,
                               trained_betas=trained_betas, prediction_type="epsilon", **extra)
@@ -95,11 +97,27 @@ class SchedulerBase:
 
 
 class DDPMScheduler(SchedulerBase):
-    """S1 -- [UPSTREAM] DDPMScheduler, fixed_small variance, epsilon prediction."""
+    """S1 -- [UPSTREAM] DDPMScheduler, epsilon prediction.  variance_type as diffusers ~0.16 `_get_variance`: fixed_small (the
+    posterior variance clamped at 1e-20; what the reference's --sched DDPM-SCHED builds, model.py:615), fixed_small_log, and
+    fixed_large (beta_t: what the hub checkpoint google/ddpm-cifar10-32 ships, i.e. what `--sched` unset samples with,
+    model.py:654).  fixed_large_log / learned / learned_range raise: the first is sqrt(log(beta)) = NaN upstream, the others need
+    a network that predicts the variance."""
     _class_name = "DDPMScheduler"
+    VARIANCE_TYPES = ("fixed_small", "fixed_small_log", "fixed_large")
 
     def __init__(self, *a, variance_type="fixed_small", **k):
+        if variance_type not in self.VARIANCE_TYPES:
+            raise NotImplementedError(f"DDPMScheduler: variance_type '{variance_type}' (implemented: {self.VARIANCE_TYPES})")
         super().__init__(*a, variance_type=variance_type, **k)
+
+    def _noise_scale(self, a_t, a_prev, cur_beta) -> float:
+        vt = self.config.variance_type
+        if vt == "fixed_large":
+            return float(cur_beta ** 0.5)
+        var = torch.clamp((1 - a_prev) / (1 - a_t) * cur_beta, min=1e-20)
+        if vt == "fixed_small_log":
+            return float(torch.exp(0.5 * torch.log(var)))
+        return float(var ** 0.5)
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         T = self.config.num_train_timesteps
@@ -121,7 +139,7 @@ class DDPMScheduler(SchedulerBase):
         c_xt = cur_alpha ** 0.5 * b_prev / b_t
         c_z = 0.0
         if t > 0:
-            c_z = float(torch.clamp((1 - a_prev) / (1 - a_t) * cur_beta, min=1e-20) ** 0.5)
+            c_z = self._noise_scale(a_t, a_prev, cur_beta)
         z, seed, off = self._noise_args(sample, generator, noise, t > 0)
         out, x0 = torch.empty_like(sample), torch.empty_like(sample)
         ops.sched_step(sample.contiguous(), model_output.contiguous(), out, c_eps=float(b_t ** 0.5), c_div=float(a_t ** 0.5),

@@ -128,7 +128,7 @@ class Trainer:
                                            timesteps=timesteps, noise=noise)
         if torch.is_tensor(loss):
             loss.backward()
-        self.micro += 1
+        self.micro = 0 if last_batch else self.micro + 1          # accelerate `_do_sync`: the counter restarts at end_of_dataloader
         if sync:
             if self._sync_now and self._pending:
                 for w in self._pending:                           # bucketed all-reduces were launched during backward
