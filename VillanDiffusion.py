@@ -96,8 +96,9 @@ def naming_fn(c: TrainingConfig) -> str:
             f"{c.trigger}-{c.target}_psi{c.psi}_lr{c.learning_rate}_vp{c.vp_scale}_ve{c.ve_scale}{add_on}")
 
 
-def setup(args: argparse.Namespace) -> TrainingConfig:
-    """Config overlay of reference :200-321."""
+def setup(args: argparse.Namespace, preflight: bool = False) -> TrainingConfig:
+    """Config overlay of reference :200-321.  preflight (what main() passes): a --dataset that cannot be read from local files fails
+    before the run directory and its side files are created (the reference would download it instead)."""
     cfg = TrainingConfig()
     for k, v in json.loads(os.environ.get("VILLAN_CFG_OVERRIDES", "{}")).items():     # test hook: shrink e.g. measure_sample_n (10000)
         setattr(cfg, k, v)
@@ -147,6 +148,9 @@ def setup(args: argparse.Namespace) -> TrainingConfig:
     rank0 = int(os.environ.get("RANK", "0")) == 0
     if mode in (MODE_TRAIN, MODE_TRAIN_MEASURE):
         cfg.output_dir = os.path.join(cfg.result, naming_fn(cfg))
+        if rank0 and preflight:
+            from dataset import DatasetLoader
+            DatasetLoader.check_available(cfg.dataset, cfg.dataset_path)
         if rank0:
             if os.path.isdir(cfg.output_dir) and not cfg.overwrite:
                 raise ValueError(f"Output directory: {cfg.output_dir} has already been created, please set overwrite flag --overwrite or -o")
@@ -424,7 +428,7 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
 
 def main(argv: Optional[List[str]] = None):
     args = parse_args(argv)
-    cfg = setup(args)
+    cfg = setup(args, preflight=True)
     rank, world, _ = _dist()
     if world > 1:                                                      # rank 0 has created the run directory and its side files
         import torch.distributed as dist

@@ -282,3 +282,147 @@ def test_frechet_distance_known_answers():
     a, b = np.array([1.0, 4.0, 9.0]), np.array([4.0, 1.0, 16.0])
     want = float(((np.sqrt(a) - np.sqrt(b)) ** 2).sum())
     assert abs(frechet_distance(np.zeros(3), np.diag(a), np.zeros(3), np.diag(b)) - want) < 1e-8
+
+
+def _write_idx(path, arr, gz=False):
+    import gzip
+    import struct
+    arr = np.asarray(arr, dtype=np.uint8)
+    head = struct.pack(">I", 2051 if arr.ndim == 3 else 2049) + b"".join(struct.pack(">I", d) for d in arr.shape)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with (gzip.open(path + ".gz", "wb") if gz else open(path, "wb")) as f:
+        f.write(head + arr.tobytes())
+
+
+def test_image_folder_dataset_with_resize_and_channel_conversion(tmp_path):
+    """D4 (dataset.py:118-122, 160-176): CELEBA-HQ / CELEBA from a local image folder; RGB conversion + Resize([S, S]) (PIL bilinear)
+    applied once at load time.  (torchvision is absent here, so the transform's PIL restatement is the comparison.)"""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    root = tmp_path / "datasets"
+    d = root / "celeba_hq_256" / "sub"
+    d.mkdir(parents=True)
+    srcs = []
+    for i, (h, w, mode) in enumerate([(300, 200, "RGB"), (64, 64, "RGB"), (100, 130, "L"), (90, 90, "RGBA")]):
+        a = rng.integers(0, 256, size=(h, w) + ({"RGB": (3,), "L": (), "RGBA": (4,)}[mode]), dtype=np.uint8)
+        im = Image.fromarray(a, mode=mode)
+        im.save(d / f"{i:03d}.png")
+        srcs.append(im)
+    (d / "notes.txt").write_text("not an image")
+    dsl = D.DatasetLoader(name="CELEBA-HQ", root=str(root), image_size=64, device="cpu")
+    assert dsl._images.shape == (4, 64, 64, 3) and dsl._images.dtype == np.uint8 and dsl.image_size == 64 and dsl.channel == 3
+    for i, im in enumerate(srcs):
+        want = np.asarray(im.convert("RGB").resize((64, 64), Image.BILINEAR))
+        assert np.array_equal(dsl._images[i], want), i
+    assert np.array_equal(dsl._images[1], np.asarray(srcs[1]))              # already at the training size: untouched
+    assert D.DatasetLoader(name="CELEBA-HQ", root=str(root), device="cpu")._images.shape == (4, 256, 256, 3)       # dataset.py:143-147 defaults
+    g1 = D.DatasetLoader(name="CELEBA-HQ", root=str(root), image_size=32, channel=1, device="cpu")
+    assert np.array_equal(g1._images[0, ..., 0], np.asarray(srcs[0].convert("L").resize((32, 32), Image.BILINEAR)))
+    # the same set stored as an array file, and the 64-pixel CelebA default
+    np.savez(root / "celeba.npz", images=dsl._images)
+    c = D.DatasetLoader(name="CELEBA", root=str(root), device="cpu")
+    assert c.image_size == 64 and np.array_equal(c._images, dsl._images)
+    c.set_poison("STOP_SIGN_14", "CAT", poison_rate=0.5).prepare_dataset(mode="FIXED")
+    assert len(c) == 4 and int((c._flags & 1).sum()) == 2 and c.trigger.shape == (3, 64, 64)
+    with pytest.raises(FileNotFoundError):
+        D.DatasetLoader(name="CELEBA-HQ", root=str(tmp_path / "nowhere"), device="cpu")
+    for name in ("LSUN-CHURCH", "LSUN-BEDROOM", "CELEBA-HQ-LATENT_PR05", "IMAGENET"):     # the reference has no loader for these either
+        with pytest.raises(NotImplementedError):
+            D.DatasetLoader(name=name, root=str(root), device="cpu")
+
+
+def test_mnist_from_idx_files_and_idx_derived_triggers(tmp_path):
+    """MNIST = train + test from local idx files, 28x28 'L' -> Resize([32, 32]) -> 1 channel (dataset.py:111-114, 131-149); the
+    FASHION / MNIST triggers and the SHOE target read torchvision's raw-file layout (dataset.py:791-812, 947-951)."""
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    root = str(tmp_path / "datasets")
+    tr, te = rng.integers(0, 256, size=(150, 28, 28), dtype=np.uint8), rng.integers(0, 256, size=(7, 28, 28), dtype=np.uint8)
+    _write_idx(os.path.join(root, "MNIST", "raw", "train-images-idx3-ubyte"), tr)
+    _write_idx(os.path.join(root, "MNIST", "raw", "t10k-images-idx3-ubyte"), te, gz=True)
+    _write_idx(os.path.join(root, "MNIST", "raw", "train-labels-idx1-ubyte"), np.arange(150) % 10)
+    _write_idx(os.path.join(root, "MNIST", "raw", "t10k-labels-idx1-ubyte"), np.arange(7) % 10, gz=True)
+    _write_idx(os.path.join(root, "FashionMNIST", "raw", "train-images-idx3-ubyte"), tr[::-1].copy(), gz=True)
+    dsl = D.DatasetLoader(name="MNIST", root=root, device="cpu")
+    assert dsl._images.shape == (157, 32, 32, 1) and dsl.channel == 1 and dsl.image_size == 32
+    assert np.array_equal(dsl._images[150, ..., 0], np.asarray(Image.fromarray(te[0], "L").resize((32, 32), Image.BILINEAR)))
+    assert np.array_equal(dsl._labels[:12], np.arange(12) % 10) and len(dsl._labels) == 157
+    only3 = D.DatasetLoader(name="MNIST", root=root, label=3, device="cpu").set_poison("BOX_14", "CORNER", poison_rate=0.0).prepare_dataset()
+    assert len(only3) == 16                                               # 15 in train + 1 in test carry label 3
+    bd = D.Backdoor(root=root)
+
+    def ref_item(arr, ch, size):
+        im = Image.fromarray(arr, "L").convert("RGB" if ch == 3 else "L").resize((size, size), Image.BILINEAR)
+        t = torch.from_numpy(np.asarray(im).copy())
+        t = (t.permute(2, 0, 1) if t.dim() == 3 else t[None]).float() / 255.0
+        return D.normalize(t, 0.0, 1.0, -1.0, 1.0)
+
+    for typ, (arr, dx, dy) in {"FASHION": (tr[::-1][0], 0, 2), "FASHION_EZ": (tr[::-1][144], 0, 4), "MNIST": (tr[3], 10, 3),
+                               "MNIST_EZ": (tr[6], 10, 3)}.items():
+        for ch in (1, 3):
+            want = ref_item(arr, ch, 32)
+            want[want <= -0.4] = -1.0                                      # __bg2black
+            want = torch.roll(want, shifts=(dy, dx), dims=(1, 2))
+            assert torch.equal(bd.get_trigger(typ, ch, 32), want), (typ, ch)
+    shoe = ref_item(tr[::-1][0], 3, 32)
+    shoe[shoe <= -0.4] = -0.4                                              # __bg2grey
+    assert torch.equal(bd.get_target("SHOE", bd.get_trigger("BOX_14", 3, 32)), shoe)
+    with pytest.raises(FileNotFoundError):
+        D.Backdoor(root=str(tmp_path / "nowhere")).get_target("SHOE", bd.get_trigger("BOX_14", 3, 32))
+
+
+def test_driver_preflight_rejects_unreadable_dataset_before_side_effects(tmp_path, monkeypatch):
+    """A --dataset with no local copy must fail before the run directory / args.json exist (the reference would download it)."""
+    import VillanDiffusion as V
+    monkeypatch.chdir(tmp_path)
+    res = tmp_path / "exp"
+    args = V.parse_args(["--mode", "train", "--dataset", "CELEBA-HQ", "--batch", "64", "--result", str(res), "-o"])
+    with pytest.raises(FileNotFoundError):
+        V.setup(args, preflight=True)
+    assert not res.exists()
+    args = V.parse_args(["--mode", "train", "--dataset", "SYNTHETIC-CIFAR10", "--batch", "64", "--result", str(res), "-o"])
+    cfg = V.setup(args, preflight=True)
+    assert os.path.exists(os.path.join(cfg.output_dir, "args.json"))
+    # every rank but 0 computes the same config without touching the file system
+    monkeypatch.setenv("RANK", "1")
+    args = V.parse_args(["--mode", "train", "--dataset", "SYNTHETIC-CIFAR10", "--batch", "64", "--result", str(tmp_path / "exp2")])
+    cfg1 = V.setup(args, preflight=True)
+    assert cfg1.output_dir.startswith(str(tmp_path / "exp2")) and not (tmp_path / "exp2").exists()
+    args = V.parse_args(["--mode", "train", "--dataset", "SYNTHETIC-CIFAR10", "--batch", "64", "--result", str(res)])     # exists, no -o:
+    assert V.setup(args).output_dir == cfg.output_dir                                                                     # only rank 0 raises
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(ValueError):
+        V.setup(args)
+
+
+def test_scheduler_variance_and_prediction_types(tmp_path):
+    """`variance_type` / `prediction_type` of a loaded scheduler_config.json are honoured or rejected, never ignored."""
+    from villandiffusion_amd import schedulers as S
+    from villandiffusion_amd.pipelines import DDPMPipeline
+    for vt in ("fixed_large_log", "learned", "learned_range"):
+        with pytest.raises(NotImplementedError):
+            S.DDPMScheduler(variance_type=vt)
+    with pytest.raises(NotImplementedError):
+        S.DDPMScheduler(prediction_type="v_prediction")
+    with pytest.raises(NotImplementedError):
+        S.DDIMScheduler(prediction_type="sample")
+    a = S.DDPMScheduler(variance_type="fixed_large")
+    ac = a.alphas_cumprod
+    assert a._noise_scale(ac[500], ac[499], 1 - ac[500] / ac[499]) == float((1 - ac[500] / ac[499]) ** 0.5)
+    # the from-scratch ids take the scheduler of google/ddpm-cifar10-32 when --sched is unset (model.py:654, 813)
+    _, _, sched, _ = DMS._get_model_sched_vp(DMS.HUB_IDS[DMS.DDPM_CIFAR10_32], None, noise_sched_type=None, build_model=False)
+    assert sched.config.variance_type == "fixed_large" and sched.config.clip_sample is False      # CLIP_SAMPLE_DEFAULT (model.py:601,657-659)
+    _, _, sched, _ = DMS._get_model_sched_vp(DMS.HUB_IDS[DMS.DDPM_CIFAR10_32], False, noise_sched_type=DMS.DDPM_SCHED, build_model=False)
+    assert sched.config.variance_type == "fixed_small" and sched.config.clip_sample is False          # model.py:615
+    # a diffusers directory whose scheduler asks for something unsupported fails loudly at load time
+    net = UNet2DModel(block_out_channels=(32, 64), down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+                      up_block_types=("AttnUpBlock2D", "UpBlock2D"), layers_per_block=1, sample_size=8, device="cpu")
+    DDPMPipeline(net, S.DDPMScheduler(variance_type="fixed_large")).save_pretrained(str(tmp_path / "ck"))
+    cfgp = tmp_path / "ck" / "scheduler" / "scheduler_config.json"
+    cfg = json.load(open(cfgp))
+    assert cfg["variance_type"] == "fixed_large"
+    assert DDPMPipeline.from_pretrained(str(tmp_path / "ck")).scheduler.config.variance_type == "fixed_large"
+    cfg["prediction_type"] = "v_prediction"
+    json.dump(cfg, open(cfgp, "w"))
+    with pytest.raises(NotImplementedError):
+        DDPMPipeline.from_pretrained(str(tmp_path / "ck"))

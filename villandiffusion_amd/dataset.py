@@ -72,15 +72,7 @@ class Backdoor:
         """convert('RGB'|'L') -> Resize (PIL bilinear; int = short side) -> ToTensor   (dataset.py:689-703)."""
         from PIL import Image
         img = Image.open(self._asset(rel)).convert("RGB" if channel == 3 else "L")
-        if isinstance(size, int):
-            w, h = img.size
-            ow, oh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
-        else:
-            oh, ow = size
-        arr = np.asarray(img.resize((ow, oh), Image.BILINEAR), dtype=np.uint8).copy()
-        t = torch.from_numpy(arr)
-        t = t.permute(2, 0, 1) if t.dim() == 3 else t[None]
-        return t.float() / 255.0
+        return _pil_to_tensor01(_pil_resize(img, size))
 
     @staticmethod
     def _bg2grey(t, vmin, vmax):
@@ -88,6 +80,27 @@ class Backdoor:
         t = t.clone()
         t[t <= thres] = thres
         return t
+
+    @staticmethod
+    def _bg2black(t, vmin, vmax):                                      # dataset.py:712-715
+        thres = (vmax - vmin) * Backdoor.GREY_BG_RATIO + vmin
+        t = t.clone()
+        t[t <= thres] = vmin
+        return t
+
+    # trigger id -> (torchvision dataset name, train item, roll dx, roll dy)   dataset.py:791-812
+    _IDX_TRIGGERS = {"FASHION": ("FashionMNIST", 0, 0, 2), "FASHION_EZ": ("FashionMNIST", 144, 0, 4),
+                     "MNIST": ("MNIST", 3, 10, 3), "MNIST_EZ": ("MNIST", 6, 10, 3)}
+
+    def _idx_item(self, ds: str, item: int, size, channel: int) -> torch.Tensor:
+        """Train image `item` of torchvision's MNIST / FashionMNIST (an 'L' PIL image) through the reference's transform
+        (dataset.py:689-703): Grayscale(1) | convert('RGB') -> Resize(size) -> ToTensor.  The reference lets torchvision download
+        the files (download=True); there is no network here, so they must already sit where torchvision would have put them:
+        <root>/<ds>/raw/train-images-idx3-ubyte[.gz]."""
+        from PIL import Image
+        imgs = read_idx_images(locate_idx(self._root, ds, "train-images-idx3-ubyte"))
+        img = Image.fromarray(imgs[item], mode="L").convert("RGB" if channel == 3 else "L")
+        return _pil_to_tensor01(_pil_resize(img, size))
 
     @staticmethod
     def _box(n, channel, image_size, vmin, val):
@@ -121,8 +134,11 @@ class Backdoor:
             return self._img_trigger(self.GLASSES_IMG, image_size, channel, int(image_size * 0.625), vmin, vmax)
         if type == self.TRIGGER_NONE:
             return torch.full((channel, image_size, image_size), float(vmin))
-        if type in (self.TRIGGER_FA, self.TRIGGER_FA_EZ, self.TRIGGER_MNIST, self.TRIGGER_MNIST_EZ):
-            raise NotImplementedError(f"trigger {type} needs the (Fashion)MNIST download (dataset.py:791-812): no network")
+        if type in self._IDX_TRIGGERS:                                 # dataset.py:791-812
+            ds, item, dx, dy = self._IDX_TRIGGERS[type]
+            img = normalize(self._idx_item(ds, item, image_size, channel), 0.0, 1.0, vmin, vmax)
+            img = self._bg2black(img, vmin, vmax)
+            return torch.roll(img, shifts=(0, dy, dx), dims=(0, 1, 2))
         raise ValueError(f"Trigger type {type} isn't found")
 
     def get_target(self, type: str, trigger: torch.Tensor = None, dx: int = -5, dy: int = -3, vmin=DEFAULT_VMIN,
@@ -139,12 +155,139 @@ class Backdoor:
         if type in self._IMG_TARGETS:
             img = normalize(self._load_rgb(self._IMG_TARGETS[type], (image_size, image_size), channel), 0.0, 1.0, vmin, vmax)
             return self._bg2grey(img, vmin, vmax)
-        if type == self.TARGET_FA:
-            raise NotImplementedError("target SHOE needs the FashionMNIST download (dataset.py:947-951): no network")
+        if type == self.TARGET_FA:                                     # dataset.py:947-951: FashionMNIST train item 0
+            img = normalize(self._idx_item("FashionMNIST", 0, image_size, channel), 0.0, 1.0, vmin, vmax)
+            return self._bg2grey(img, vmin, vmax)
         raise NotImplementedError(f"Target type {type} isn't found")
 
 
+# ------------------------------------------------------------------------------------------------------ PIL restatement of the transform
+def _pil_resize(img, size):
+    """torchvision.transforms.Resize on a PIL image [UPSTREAM]: bilinear `Image.resize`; an int sizes the SHORT side
+    (long side int(size * long / short)), a pair is (h, w)."""
+    from PIL import Image
+    if isinstance(size, int):
+        w, h = img.size
+        ow, oh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+    else:
+        oh, ow = size
+    if (ow, oh) == img.size:
+        return img
+    return img.resize((ow, oh), Image.BILINEAR)
+
+
+def _pil_to_tensor01(img) -> torch.Tensor:
+    """transforms.ToTensor: uint8 HWC -> float CHW / 255."""
+    t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+    t = t.permute(2, 0, 1) if t.dim() == 3 else t[None]
+    return t.float() / 255.0
+
+
+def to_training_size(img, size: int, channel: int) -> np.ndarray:
+    """The deterministic head of the reference's dataset transform (dataset.py:160-176) for ONE image, kept in uint8:
+    Grayscale(1) / convert('RGB') -> Resize([S, S]).  ToTensor + util.normalize + the random flip run in `vd_poison_batch`;
+    resizing once at load time is the same function of the pixels as resizing on every fetch."""
+    from PIL import Image
+    if not isinstance(img, Image.Image):
+        a = np.asarray(img, dtype=np.uint8)
+        img = Image.fromarray(a[..., 0] if a.ndim == 3 and a.shape[-1] == 1 else a)
+    img = _pil_resize(img.convert("RGB" if channel == 3 else "L"), (size, size))
+    a = np.asarray(img, dtype=np.uint8)
+    return a[..., None] if a.ndim == 2 else a
+
+
 # ------------------------------------------------------------------------------------------------------ data sources
+IMG_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".webp", ".ppm", ".pgm", ".tif", ".tiff")
+
+
+def read_idx_images(path: str) -> np.ndarray:
+    """An idx3-ubyte file (MNIST family), optionally gzip-compressed -> uint8 [N, H, W]."""
+    import gzip
+    import struct
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as f:
+        raw = f.read()
+    magic, n, h, w = struct.unpack(">IIII", raw[:16])
+    if magic != 2051 or len(raw) != 16 + n * h * w:
+        raise ValueError(f"{path}: not an idx3-ubyte image file (magic {magic}, {len(raw)} bytes for {n}x{h}x{w})")
+    return np.frombuffer(raw, dtype=np.uint8, offset=16).reshape(n, h, w)
+
+
+def read_idx_labels(path: str) -> np.ndarray:
+    import gzip
+    import struct
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as f:
+        raw = f.read()
+    magic, n = struct.unpack(">II", raw[:8])
+    if magic != 2049 or len(raw) != 8 + n:
+        raise ValueError(f"{path}: not an idx1-ubyte label file")
+    return np.frombuffer(raw, dtype=np.uint8, offset=8).astype(np.int64)
+
+
+def locate_idx(root: Optional[str], ds: str, stem: str) -> str:
+    roots = [r for r in (root, "datasets", ".") if r]
+    for r in roots:
+        for sub in (os.path.join(ds, "raw"), ds, ds.lower(), ""):
+            for ext in ("", ".gz"):
+                p = os.path.join(r, sub, stem + ext)
+                if os.path.exists(p):
+                    return p
+    raise FileNotFoundError(
+        f"{ds}: {stem}[.gz] not found under {roots} (torchvision layout <root>/{ds}/raw/). The reference downloads it "
+        f"(dataset.py:791-812, 947-951); there is no network here: place the idx files locally.")
+
+
+def _load_mnist(root: Optional[str]) -> Tuple[np.ndarray, np.ndarray]:
+    """train + test (70 000), the reference's 'train+test' split (dataset.py:111-114), from local idx files."""
+    xs = [read_idx_images(locate_idx(root, "MNIST", f"{p}-images-idx3-ubyte")) for p in ("train", "t10k")]
+    ys = [read_idx_labels(locate_idx(root, "MNIST", f"{p}-labels-idx1-ubyte")) for p in ("train", "t10k")]
+    return np.concatenate(xs)[..., None], np.concatenate(ys)
+
+
+FOLDER_NAMES = {"CELEBA-HQ": ("celeba_hq_256", "celeba_hq", "CelebA-HQ", "CELEBA-HQ"), "CELEBA": ("celeba", "celebA", "CelebA", "CELEBA")}
+
+
+def locate_image_source(name: str, root: Optional[str]) -> str:
+    """Local stand-in for the reference's `load_dataset("datasets/celeba_hq_256", split='train')` / `load_dataset("student/celebA")`
+    (dataset.py:118-122): a directory of image files (any nesting, sorted by path like HF's imagefolder builder) or an .npz / .npy
+    holding a uint8 [N, H, W, C] array under `images`."""
+    roots = [r for r in (root, "datasets", ".") if r]
+    for r in roots:
+        for sub in FOLDER_NAMES[name]:
+            for cand in (os.path.join(r, sub), os.path.join(r, sub + ".npz"), os.path.join(r, sub + ".npy")):
+                if os.path.isdir(cand) or os.path.isfile(cand):
+                    return cand
+    raise FileNotFoundError(
+        f"{name}: no local copy found (looked for {FOLDER_NAMES[name]} as an image folder / .npz / .npy under {roots}). The "
+        f"reference reads it from disk or the hub (dataset.py:118-122); there is no network here.")
+
+
+def _load_image_source(src: str, size: int, channel: int, workers: int = 0) -> np.ndarray:
+    """All images of `src` at the training size, uint8 [N, S, S, C] (decode + convert + resize on a thread pool: PIL releases the GIL)."""
+    if os.path.isfile(src):
+        arr = np.load(src)
+        arr = arr["images"] if hasattr(arr, "files") else arr
+        arr = np.asarray(arr, dtype=np.uint8)
+        if arr.ndim == 3:
+            arr = arr[..., None]
+        if arr.shape[1] == size and arr.shape[2] == size and arr.shape[3] == channel:
+            return np.ascontiguousarray(arr)
+        return np.stack([to_training_size(a, size, channel) for a in arr])
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    files = sorted(os.path.join(d, f) for d, _, fs in os.walk(src) for f in fs if f.lower().endswith(IMG_EXT))
+    if not files:
+        raise FileNotFoundError(f"{src}: no image files ({', '.join(IMG_EXT)})")
+    out = np.empty((len(files), size, size, channel), dtype=np.uint8)
+
+    def one(i):
+        with Image.open(files[i]) as im:
+            out[i] = to_training_size(im, size, channel)
+
+    with ThreadPoolExecutor(max_workers=workers or min(32, (os.cpu_count() or 8))) as ex:
+        list(ex.map(one, range(len(files))))
+    return out
+
+
 def synthetic_images(n: int = 60000, size: int = 32, channel: int = 3, seed: int = 0) -> np.ndarray:
     """SURVEY §8d synthetic inputs: i.i.d. uniform uint8, numpy.random.default_rng(seed)."""
     return np.random.default_rng(seed).integers(0, 256, size=(n, size, size, channel), dtype=np.uint8)
@@ -203,18 +346,28 @@ class DatasetLoader:
             self._images, self._labels = synthetic_images(n=int(os.environ.get("VILLAN_SYNTHETIC_N", 2048)), size=256), None
         elif name == self.CIFAR10:
             self._images, self._labels = _load_cifar10(root or "datasets")
+        elif name == self.MNIST:
+            self._images, self._labels = _load_mnist(root)
+            channel, image_size = channel or 1, image_size or 32             # dataset.py:131-149
+        elif name in (self.CELEBA_HQ, self.CELEBA):
+            channel, image_size = channel or 3, image_size or (256 if name == self.CELEBA_HQ else 64)
+            self._images, self._labels = _load_image_source(locate_image_source(name, root), image_size, channel), None
         elif name == self.CELEBA_HQ_LATENT:
             # precomputed VQ-VAE latents (dataset.py:125-126, 440-442): <root>/celeba_hq_256_latents in LatentDataset format;
             # trigger / target stay IMAGE-space tensors (256x256) -- the pipeline encodes them when it needs latents
             self._latent = LatentDataset(os.path.join(root or "datasets", "celeba_hq_256_latents"))
             self._images, self._labels = None, None
             channel, image_size = channel or 3, image_size or 256
-        else:
-            raise NotImplementedError(f"No dataset named as {name} (local loaders exist for CIFAR10 and SYNTHETIC-CIFAR10)")
+        elif name == self.CELEBA_HQ_LATENT_PR05:
+            raise NotImplementedError(f"{name}: the reference itself cannot load it (dataset.py:124 calls an un-imported load_from_disk)")
+        else:                                                              # LSUN-* included: dataset.py:109-128 has no loader for them
+            raise NotImplementedError(f"Undefined dataset: {name}")
         self._channel = channel if channel is not None else self._images.shape[-1]
         self._image_size = image_size if image_size is not None else self._images.shape[1]
-        if self._images is not None and (self._images.shape[1] != self._image_size or self._images.shape[-1] != self._channel):
-            raise NotImplementedError("on-the-fly resize / channel conversion is not implemented; store images at the training size")
+        if self._images is not None and (self._images.shape[1] != self._image_size or self._images.shape[2] != self._image_size
+                                         or self._images.shape[-1] != self._channel):
+            # dataset.py:160-176: channel conversion + Resize([S, S]) (PIL bilinear), applied once here instead of per fetch
+            self._images = np.stack([to_training_size(a, self._image_size, self._channel) for a in self._images])
         self._backdoor = Backdoor(root=root)
         self._trigger = self._target = None
         self._trigger_type = self._target_type = None
@@ -252,8 +405,29 @@ class DatasetLoader:
             return np.concatenate(parts)
         return self._rng.permutation(n_total)[: int(n_total * rate)].astype(np.int64)
 
+    @classmethod
+    def check_available(cls, name: str, root: Optional[str]) -> None:
+        """Raise (FileNotFoundError / NotImplementedError) if `name` cannot be loaded from local files -- the driver calls this
+        before it creates the run directory."""
+        if name in (cls.SYNTHETIC_CIFAR10, cls.SYNTHETIC_CELEBA_HQ, cls.CELEBA_HQ_LATENT):
+            return
+        if name == cls.CIFAR10:
+            for cand in (root or "datasets", os.path.join(root or "datasets", "cifar10"), "datasets", "."):
+                if os.path.exists(os.path.join(cand, "cifar10.npz")) or os.path.isdir(os.path.join(cand, "cifar-10-batches-py")):
+                    return
+            raise FileNotFoundError("CIFAR10 not found locally (no network here): put cifar-10-batches-py/ or cifar10.npz under the "
+                                    "dataset root, or use --dataset SYNTHETIC-CIFAR10")
+        if name == cls.MNIST:
+            locate_idx(root, "MNIST", "train-images-idx3-ubyte")
+            return
+        if name in FOLDER_NAMES:
+            locate_image_source(name, root)
+            return
+        raise NotImplementedError(f"Undefined dataset: {name}")
+
     def prepare_dataset(self, mode: str = "FIXED", R_trigger_only: bool = False, ext_R_trigger_only: bool = False,
                         R_gaussian_aug: float = 0.0) -> "DatasetLoader":
+        # R_gaussian_aug: stored and never read by the reference either (dataset.py:419-422 is its only use)
         self._R_trigger_only = bool(R_trigger_only)
         if self._latent is not None:
             return self._prepare_latent()
