@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config #2)")
     ap.add_argument("--sample-steps", type=int, default=1000)
     ap.add_argument("--sample-images", type=int, default=128, help="per-GPU images of the DDPM sampling leg (0 = skip)")
+    ap.add_argument("--mode", choices=("all", "train", "sample"), default="all",
+                    help="train: training legs only (no sampler) / sample: sampler only -- so that a rocprofv3 summary covers ONE dispatch population")
+    ap.add_argument("--cpu-batch", type=int, default=128, help="batch of the CPU-oracle training baseline (SURVEY 8d: 128)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-math", choices=("bf16x3", "f32"), default=None,
@@ -47,7 +51,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int = 32):
+def cpu_baseline(batch: int = 128, n_steps: int = 3):
     """The oracle (plain torch fp32 = what the reference's diffusers path executes on a CPU) on the host cores:
     fwd + bwd + clip(1.0) + Adam on a bounded sample of the same workload."""
     from oracle.loss_ref import LossFnRef, SDE_VP
@@ -75,7 +79,6 @@ def cpu_baseline(batch: int = 32):
         opt.step()
 
     step(2)                                     # warm-up (allocator, oneDNN primitives)
-    n_steps = 10
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step(batch)
@@ -112,9 +115,27 @@ def main():
     dev_id = local_rank % max(1, ndev)                    # one GPU per rank on a real node (local_rank < ndev)
     torch.cuda.set_device(dev_id)
     dev = torch.device("cuda", dev_id)
+    ranks_seen = None
     if world > 1:
         # "nccl" IS RCCL on ROCm.  VD_BENCH_BACKEND=gloo exists only to exercise the multi-process path on a 1-GPU box.
-        dist.init_process_group(os.environ.get("VD_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("VD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":                             # RCCL prints its communicator / ring set-up (rank count, transport) to stderr
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        # proof that the collective really spans N ranks on N devices: every rank contributes (rank, device index, PCI bus id)
+        prop = torch.cuda.get_device_properties(dev_id)
+        mine = torch.tensor([rank, dev_id, int(getattr(prop, "pci_bus_id", -1)), 1], device=dev, dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        tot = mine.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted_by_all_reduce": int(tot[3]),
+                      "rank_device_pci": [[int(v) for v in t_[:3]] for t_ in seen],
+                      "distinct_devices": len({(int(t_[1]), int(t_[2])) for t_ in seen})}
+        if rank == 0:
+            print(f"[bench] process group: {ranks_seen}", file=sys.stderr, flush=True)
+        assert ranks_seen["ranks_counted_by_all_reduce"] == world == ranks_seen["world_size"]
 
     from villandiffusion_amd import ops
     from villandiffusion_amd.dataset import DatasetLoader
@@ -152,77 +173,95 @@ def main():
         if world > 1:
             dist.barrier()
 
-    log(f"setup done (world={world}, B={B}); warm-up {args.warmup} steps")
-    for i in range(args.warmup):
-        one_step(i)
-        if i == 0:
-            torch.cuda.synchronize()
-            log("first step done")
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt)
-    train_ips = world * B * args.steps / dt
-    final_loss = float(loss)
-    log(f"train: {train_ips:.1f} img/s ({1e3 * dt / args.steps:.2f} ms/step), loss {final_loss:.4f}")
-
-    # ---- the same K steps with every contraction on the exact-f32 MFMA (reported beside the headline, not as `value`) ----
+    do_train, do_sample = args.mode in ("all", "train"), args.mode in ("all", "sample") and args.sample_images > 0
+    log(f"setup done (world={world}, B={B}, mode={args.mode}); warm-up {args.warmup} steps")
+    train_ips = dt = final_loss = None
     exact = None
-    if net.conv_math != "f32":
-        mode0, net.conv_math = net.conv_math, "f32"
-        for i in range(2):
+    if do_train:
+        for i in range(args.warmup):
             one_step(i)
+            if i == 0:
+                torch.cuda.synchronize()
+                log("first step done")
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            one_step(args.warmup + i)
+            loss = one_step(args.warmup + i)
         torch.cuda.synchronize()
         barrier()
-        te = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        exact = {"train_images_per_sec": round(world * B * args.steps / float(te), 2), "ms_per_step": round(1e3 * float(te) / args.steps, 3),
-                 "note": "same run, net.conv_math = 'f32': all contractions on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s peak)"}
-        net.conv_math = mode0
-        log(f"exact-f32 mode: {exact}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+        train_ips = world * B * args.steps / dt
+        final_loss = float(loss)
+        log(f"train: {train_ips:.1f} img/s ({1e3 * dt / args.steps:.2f} ms/step), loss {final_loss:.4f}")
+
+        # ---- the same K steps with every contraction on the exact-f32 MFMA (reported beside the headline, not as `value`) ----
+        if net.conv_math != "f32":
+            mode0, net.conv_math = net.conv_math, "f32"
+            for i in range(2):
+                one_step(i)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(args.warmup + i)
+            torch.cuda.synchronize()
+            barrier()
+            te = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            exact = {"train_images_per_sec": round(world * B * args.steps / float(te), 2), "ms_per_step": round(1e3 * float(te) / args.steps, 3),
+                     "note": "same run, net.conv_math = 'f32': all contractions on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s peak)"}
+            net.conv_math = mode0
+            log(f"exact-f32 mode: {exact}")
 
     # ---- 1000-step DDPM sampling (second half of the metric), embarrassingly parallel ----
-    sample_ips, sample_s, secondary = None, None, None
-    if args.sample_images > 0:
-        pipe = DDPMPipeline(net, sched)
+    sample_ips, sample_s, secondary, sample_eager = None, None, None, None
+    pipe = DDPMPipeline(net, sched)
+    n_img = args.sample_images
+    if do_sample:
         sched.device_rng_seed = 99 + rank                 # throughput mode: Philox noise fused into the step kernel
-        n_img = args.sample_images
         init = torch.empty((n_img, 3, 32, 32), device=dev)
         ops.randn(init, 7 + rank, 0)
-        with torch.no_grad():                             # short warm-up of the inference path
-            pipe(batch_size=n_img, init=init, num_inference_steps=1000, start_from=995, return_tensor=True)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        chunks = torch.split(init, B)
-        outs = [pipe(batch_size=len(c), init=c, num_inference_steps=args.sample_steps, return_tensor=True) for c in chunks]
-        final = torch.cat(outs)
         pp = torch.empty((n_img, 32, 32, 3), device=dev)
-        ops.postprocess(final, pp, 0.5, 0.5, 0.0, 1.0, True)      # (x/2+0.5).clamp(0,1), NHWC; PNG encode excluded
-        torch.cuda.synchronize()
-        barrier()
-        ts = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        sample_s = float(ts)
+
+        def sample_all(steps):
+            chunks = torch.split(init, B)
+            outs = [pipe(batch_size=len(c), init=c, num_inference_steps=steps, return_tensor=True) for c in chunks]
+            final = torch.cat(outs)
+            ops.postprocess(final, pp, 0.5, 0.5, 0.0, 1.0, True)      # (x/2+0.5).clamp(0,1), NHWC; PNG encode excluded
+            return final
+
+        def timed_sampling():
+            with torch.no_grad():                             # short warm-up of the inference path (graph capture included)
+                pipe(batch_size=min(B, n_img), init=init[:B], num_inference_steps=1000, start_from=995, return_tensor=True)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sample_all(args.sample_steps)
+            torch.cuda.synchronize()
+            barrier()
+            ts = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            return float(ts)
+
+        sample_s = timed_sampling()
         sample_ips = world * n_img / sample_s
         assert bool(torch.isfinite(pp).all())
+        log(f"sample: {sample_ips:.4f} img/s ({sample_s:.2f} s for {n_img} images x {args.sample_steps} steps; hip graph = {net.sampler_graph})")
+        if net.sampler_graph and args.mode == "all":      # the same loop launched eagerly (what the graph replay replaces), reported beside it
+            net.sampler_graph = False
+            sched._rng_offset = 0
+            s_eager = timed_sampling()
+            net.sampler_graph = True
+            sample_eager = {"images_per_sec": round(world * n_img / s_eager, 4), "seconds": round(s_eager, 2)}
+            log(f"sample (eager launches): {sample_eager}")
         sched.device_rng_seed = None
-        log(f"sample: {sample_ips:.4f} img/s ({sample_s:.2f} s for {n_img} images x {args.sample_steps} steps)")
         # secondary samplers of SURVEY.md §8d (configs #2-#4): same network, same init, whole loop incl. post-processing
         from villandiffusion_amd.pipelines import DDIMPipeline, PNDMPipeline
         from villandiffusion_amd.schedulers import DDIMScheduler, DPMSolverMultistepScheduler, UniPCMultistepScheduler
@@ -246,80 +285,127 @@ def main():
             secondary[tag] = round(world * len(c0) / float(tsec), 2)
         log(f"secondary samplers (img/s): {secondary}")
 
-    # ---- roofline: per-launch HIP-event timing of the MFMA kernels over one extra training step ----
-    roofline, kernels = None, None
-    if not args.no_roofline:
+    # ---- roofline: per-launch HIP-event timing (on the launch stream) of one extra training step and of one denoising step ----
+    def peak_of(kname):      # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
+        return PEAK_BF16_MFMA_TFLOPS if ("bx3" in kname or "attn_core" in kname) else PEAK_F32_MFMA_TFLOPS
+
+    def summarise(rec):
+        """Per kernel symbol: launches, summed event time, algorithmic TFLOP/s and GB/s, and the fraction of the BINDING roofline:
+        a kernel cannot beat min(MFMA peak, arithmetic intensity x HBM peak), so frac = max(frac of MFMA peak, frac of 8 TB/s)."""
+        agg = {}
+        for r_ in rec:
+            a = agg.setdefault(r_["name"], {"n": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "kind": r_["kind"]})
+            a["n"] += 1
+            a["flops"] += r_["flops"]
+            a["bytes"] += r_["bytes"]
+            a["ms"] += r_["e0"].elapsed_time(r_["e1"])
+        rows = []
+        for k, v in agg.items():
+            tf = v["flops"] / v["ms"] / 1e9 if v["ms"] > 0 else 0.0
+            gbs = v["bytes"] / v["ms"] / 1e6 if v["ms"] > 0 else 0.0
+            split = "bx3" in k or "attn_core" in k
+            f_mfma = tf / peak_of(k) if v["kind"] == "mfma" else 0.0
+            f_hbm = gbs / PEAK_HBM_GBS
+            rows.append({"kernel": k, "launches": v["n"], "ms": round(v["ms"], 3), "avg_us": round(1e3 * v["ms"] / v["n"], 1),
+                         "tflops": round(tf, 2), "gbs": round(gbs, 1), "gflop": round(v["flops"] / 1e9, 1), "mbytes": round(v["bytes"] / 1e6, 1),
+                         "frac_mfma": round(f_mfma, 4), "frac_mfma_executed": round((3 if split else 1) * f_mfma, 4), "frac_hbm": round(f_hbm, 4),
+                         "bound": "hbm" if f_hbm >= f_mfma else "mfma", "frac": round(max(f_mfma, f_hbm), 4), "mfma_peak": peak_of(k) if v["kind"] == "mfma" else None})
+        return sorted(rows, key=lambda r: -r["ms"])
+
+    roofline, kernels, sample_kernels = None, None, None
+    if not args.no_roofline and do_train:
         for _ in range(2):                       # every rank runs the step (it contains the all-reduce); rank 0 reports
             ops.profile_start()
             one_step(10_000)
             torch.cuda.synchronize()
             rec = ops.profile_stop()
         barrier()
-    if not args.no_roofline and rank == 0:
-        agg = {}
-        for name, flops, e0, e1 in rec:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += e0.elapsed_time(e1)
-        def peak_of(kname):      # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
-            return PEAK_BF16_MFMA_TFLOPS if "bx3" in kname else PEAK_F32_MFMA_TFLOPS
-        kernels = sorted(({"kernel": k, "launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / v[2] / 1e9, 2),
-                           "avg_us": round(1e3 * v[2] / v[0], 1), "peak": peak_of(k), "gflop_per_step": round(v[1] / 1e9, 1)}
-                          for k, v in agg.items()), key=lambda r: -r["ms"])
-        # dominant kernel = the symbol that carries the largest share of the step's algorithmic FLOPs (by summed time the many short
-        # 1x1 launches can edge ahead under per-launch event timing; they carry a fifth of the work of the 32x32 convolutions)
-        top = max(kernels, key=lambda r: r["gflop_per_step"])
-        top_peak = peak_of(top["kernel"])
-        traffic = None          # HBM bytes per launch from the committed PMC pass (rocprofv3 cannot run inside this process)
+        if rank == 0:
+            kernels = summarise(rec)
+    if not args.no_roofline and do_sample:
+        g0, net.sampler_graph = net.sampler_graph, False          # events bracket eager launches
+        sched.device_rng_seed = 99 + rank
+        xs = init[:B]
+        for _ in range(2):
+            ops.profile_start()
+            pipe(batch_size=len(xs), init=xs, num_inference_steps=1000, start_from=999, return_tensor=True)
+            torch.cuda.synchronize()
+            rec_s = ops.profile_stop()
+        sched.device_rng_seed = None
+        net.sampler_graph = g0
+        if rank == 0:
+            sample_kernels = summarise(rec_s)
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+    def traffic_of(kname):      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"].get(top["kernel"], {}).get("traffic_bytes_per_launch")
+            with open(pmc_file) as f:
+                return json.load(f)["kernels"].get(kname, {}).get("traffic_bytes_per_launch")
         except OSError:
-            pass
-        roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": top_peak,
-                    "unit": "TFLOP/s", "frac": round(top["tflops"] / top_peak, 4), "traffic": traffic,
-                    # algorithmic FLOPs (2*M*N*K) above; a split-precision kernel EXECUTES three bf16 MFMAs per product term
-                    "executed_tflops": round(3 * top["tflops"], 2) if "bx3" in top["kernel"] else top["tflops"],
-                    "frac_executed": round((3 if "bx3" in top["kernel"] else 1) * top["tflops"] / top_peak, 4),
-                    "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                    "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
-                    "all_mfma_kernels_ms": round(sum(k["ms"] for k in kernels), 2)}
+            return None
+
+    def roof_entry(k, rule):
+        split = "bx3" in k["kernel"] or "attn_core" in k["kernel"]
+        tr = traffic_of(k["kernel"])
+        if k["bound"] == "mfma":
+            e = {"bound": "mfma", "kernel": k["kernel"], "achieved": k["tflops"], "peak": k["mfma_peak"], "unit": "TFLOP/s", "frac": k["frac_mfma"],
+                 "executed_tflops": round((3 if split else 1) * k["tflops"], 2), "frac_executed": k["frac_mfma_executed"]}
+        else:
+            e = {"bound": "hbm", "kernel": k["kernel"], "achieved": k["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k["frac_hbm"],
+                 "tflops": k["tflops"], "frac_mfma_executed": k["frac_mfma_executed"]}
+        e.update({"traffic": tr, "traffic_source": "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc passes)" if tr else None,
+                  "launches_per_step": k["launches"], "avg_launch_us": k["avg_us"], "ms_per_step": k["ms"],
+                  "algorithmic_mbytes_per_launch": round(k["mbytes"] / k["launches"], 2), "algorithmic_gflop_per_launch": round(k["gflop"] / k["launches"], 2),
+                  "selection_rule": rule})
+        return e
+
+    roofline_by_flops = None
+    src = kernels if kernels else sample_kernels
+    if src:
+        mf = [k for k in src if k["mfma_peak"]]
+        roofline = roof_entry(mf[0], "the MFMA kernel symbol with the largest TOTAL TIME in the profiled step (HIP events around every launch)")
+        roofline["all_mfma_kernels_ms"] = round(sum(k["ms"] for k in mf), 2)
+        roofline_by_flops = roof_entry(max(mf, key=lambda r: r["gflop"]), "the MFMA kernel symbol carrying the most algorithmic FLOPs in the profiled step")
 
     log("roofline leg done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.cpu_batch, args.cpu_steps)
         log(f"cpu baseline: {cpu}")
 
     if rank == 0:
-        ms = 1e3 * dt / args.steps
+        split = net.conv_math == "bf16x3"
+        ms = None if dt is None else 1e3 * dt / args.steps
         out = {
             "metric": "train imgs/sec + 1000-step DDPM sample imgs/sec, CIFAR10 bs128",
-            "value": round(train_ips, 2), "unit": "train images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3/f32" if net.conv_math == "bf16x3" else "f32", "data": "synthetic",
+            "value": None if train_ips is None else round(train_ips, 2), "unit": "train images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None if ms is None else round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16x3/f32" if split else "f32", "data": "synthetic",
             "dtype_note": ("f32 tensors and accumulation; 3x3 / 1x1 convolutions and the attention contractions (forward, input and weight "
                            "gradients) as hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32 per contraction; the "
                            "reference trains this config under fp16 autocast); stride-2 convolutions, linears, conv_in / conv_out on the "
-                           "exact f32 MFMA") if net.conv_math == "bf16x3" else
+                           "exact f32 MFMA") if split else
                           "every contraction on the f32-input MFMA (exact f32)",
             "exact_f32_mode": exact,
             "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), "
                                    "per-GPU batch %d; + %d-step DDPM sampling of %d images/GPU" % (B, args.sample_steps, args.sample_images),
-                       "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}", "mode": args.mode},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
             "sample_seconds": None if sample_s is None else round(sample_s, 2),
+            "sample_hip_graph": bool(net.sampler_graph), "sample_eager_launches": sample_eager,
             "sample_secondary_images_per_sec": secondary,
-            "train_tflops": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
-            "train_frac_of_bf16_peak": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
-            # > 1 in the split-precision arithmetic: the whole step runs faster than the f32-input MFMA could do its contractions
-            "train_frac_of_f32_peak": round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "sample_frac_of_f32_peak": None if sample_ips is None else round(
-                sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "final_loss": round(final_loss, 5),
-            "roofline": roofline, "mfma_kernels": kernels, "cpu_baseline": cpu,
+            "train_tflops": None if train_ips is None else round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
+            "sample_tflops": None if sample_ips is None else round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3, 2),
+            "final_loss": None if final_loss is None else round(final_loss, 5),
+            "roofline": roofline, "roofline_largest_flops": roofline_by_flops,
+            "train_step_kernels": kernels, "sampler_step_kernels": sample_kernels, "cpu_baseline": cpu, "process_group": ranks_seen,
         }
+        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS          # whole-job fractions against the peak of the arithmetic that ran
+        key = "bf16" if split else "f32"
+        if train_ips is not None:
+            out[f"train_frac_of_{key}_peak"] = round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (peak * world), 4)
+        if sample_ips is not None:
+            out[f"sample_frac_of_{key}_peak"] = round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3 / (peak * world), 4)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 3
+#define VD_ABI_VERSION 4
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -98,6 +98,10 @@ typedef struct vd_gemm_desc {
                                 scores / values and their gradients): per-batch A (a_bstride != 0), VD_B_PLAIN or VD_B_KCONTIG,
                                 NP % 128 == 0, K % 16 == 0, K >= 32, M >= 64, 16-byte aligned operands and strides; both operands
                                 are split into bf16 (hi, lo) inside the kernel.  Anything else fails with VD_EINVAL.           */
+    int32_t pool2;           /* 1: VD_B_CONV3_T with a_packed at 16x16 / 32x32 outputs only (the input gradient of an Upsample2D convolution):
+                                the epilogue adds each 2x2 block of output pixels and writes D at HALF resolution (ldd = (OH/2)*(OW/2)),
+                                i.e. conv-transpose followed by the adjoint of the nearest-2x upsample, without the full-resolution tensor.
+                                Needs an unsplit grid (M/128 * N/128 >= 256 tiles), no bias / rowadd / residual / accumulate; else VD_EINVAL */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -199,6 +203,18 @@ int vd_attn_small_fwd(const float* qkv, float* out, float* P, int B, int C, int 
                       int64_t qkv_bstride, int64_t out_bstride, void* stream);
 int vd_attn_small_bwd(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int C, int N,
                       float scale, int64_t qkv_bstride, int64_t dout_bstride, int64_t dqkv_bstride, void* stream);
+
+/* K4 fused (diffusers AttentionBlock reached from loss.py:993): the whole attention core of N == 256 tokens in one
+ * launch, scores / probabilities in registers, split-precision (bf16 hi/lo, f32 accumulation) contractions on the bf16 MFMA.
+ *   qkv [B][3C][N] (q | k | v, C = heads * head_dim, a head = a channel slice), out [B][C][N]:
+ *   out[b][h d + c][i] = sum_j v[c][j] P[j][i],  P[.][i] = softmax_j(scale * sum_c k[c][j] q[c][i]).
+ * P == NULL: nothing but `out` is written (no-grad path).  P != NULL: [B*heads][N][N] (P[j][i]) is written once for the backward pass.
+ * head_dim in {32, 64, 128} or a multiple of 256; anything else / N != 256 -> VD_EINVAL (callers keep the 3-launch path).
+ * vd_attn_core_bwd: dP = v^T dout, dS = scale P (dP - sum_j P dP) (written to dS, [B*heads][N][N]) and dq = k dS (written into the
+ * q slice of dqkv [B][3C][N]) in one launch; dk = q dS^T and dv = dout P^T are plain products of dS / P (vd_gemm). */
+int vd_attn_core_fwd(const float* qkv, float* out, float* P, int B, int heads, int head_dim, int N, float scale, void* stream);
+int vd_attn_core_bwd(const float* qkv, const float* P, const float* dout, float* dS, float* dqkv, int B, int heads, int head_dim,
+                     int N, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3 -- timestep embedding + small elementwise helpers.

@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle (plain torch fp32) runs inside the GPU tests on the box's host cores.  For these 32x32 / batch <= 8 problems oneDNN
+    # gets SLOWER with more threads (measured on the 256-thread GPU host: 8 threads 0.28 s, 32 threads 0.39 s, 64 threads 0.79 s per
+    # B = 8 forward + backward; torch's default of one thread per core makes a 1000-step oracle trajectory take > 10 minutes).
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    except Exception:          # noqa: BLE001  (torch missing / no affinity API: leave the default)
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

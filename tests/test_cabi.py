@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, s), f"{s} declared in villan_hip.h but not exported"
         assert s in lib.PROTOTYPES, f"{s} has no ctypes prototype in lib.py"
     assert set(lib.PROTOTYPES) == set(syms)
-    assert handle.vd_abi_version() == 3
+    assert handle.vd_abi_version() == 4
 
 
 def test_struct_layout_matches_c(tmp_path):
@@ -88,6 +88,8 @@ def test_split_precision_planner_agrees_with_the_python_side_eligibility():
                     want = ops.bx3_eligible(M, Cc, OH, OW, mode)
                     got = h.vd_gemm_tile(C.byref(d))
                     assert (got == 8) == want and got in (8, -1), (mode, OW, M, Cc, nb, got, want)
+                    if mode == B_CONV3_T and ops.bx3_pool2_eligible(M, Cc, OH, OW, nb):      # pool2 needs the unsplit grid
+                        assert got == 8 and h.vd_gemm_ws_floats(C.byref(d)) == 0, (OW, M, Cc, nb)
                     if mode in (B_CONV3, B_CONV3_UP):
                         w = WgradDesc()
                         w.dY, w.X, w.dW = FAKE, FAKE, FAKE

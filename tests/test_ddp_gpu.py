@@ -55,7 +55,10 @@ def _worker(rank, world, port, path):
 def test_two_rank_step_equals_single_process_step(tmp_path):
     from villandiffusion_amd.trainer import Trainer
     path = str(tmp_path / "p.pt")
-    port = 29700 + (os.getpid() % 1000)
+    import socket
+    with socket.socket() as sk:                 # a port the OS says is free right now (a fixed one can be left in TIME_WAIT by an earlier test)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port, path), nprocs=2, join=True)
     ddp = torch.load(path)
     net, lf = _make()

@@ -277,6 +277,41 @@ def test_attention_mfma_path():
     check(dqkv, qkv.grad, 5e-5, "attention backward (dq,dk,dv)")
 
 
+@pytest.mark.parametrize("B,heads,d", [(3, 1, 256), (2, 1, 512), (2, 8, 32), (1, 2, 128), (2, 4, 64), (5, 1, 256)])
+def test_attention_core_fused(B, heads, d):
+    """vd_attn_core_fwd / _bwd (N = 256 tokens, split-precision contractions, scores in registers) against the torch fp32 attention
+    of the oracle: output, the saved probabilities, dS, and all three input gradients (dq from the fused launch, dk / dv from the
+    products of dS / P)."""
+    C, N = heads * d, 256
+    qkv = (torch.randn(B, 3 * C, N, generator=g(0)) * 1.3).requires_grad_(True)
+    scale = 1 / math.sqrt(d)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(B, heads, d, N) for i in range(3))
+    S = torch.einsum("bhcj,bhci->bhji", k, q) * scale
+    S.retain_grad()
+    P = torch.softmax(S, dim=2)
+    o = torch.einsum("bhcj,bhji->bhci", v, P).reshape(B, C, N)
+    do = torch.randn(o.shape, generator=g(1))
+    o.backward(do)
+    qd = qkv.detach().to(DEV)
+    od, Pd = torch.empty(B, C, N, device=DEV), torch.empty(B, heads, N, N, device=DEV)
+    assert ops.attn_core_eligible(heads, d, N)
+    ops.attn_core_fwd(qd, od, Pd, heads, d, N, scale)
+    check(Pd, P, 2e-5, "fused softmax(QK^T)")
+    check(od, o, 2e-5, "fused PV")
+    od2 = torch.full((B, C, N), float("nan"), device=DEV)
+    ops.attn_core_fwd(qd, od2, None, heads, d, N, scale)                 # no-grad path: nothing but `out` is written
+    assert torch.equal(od2, od)
+    dS, dqkv = torch.empty(B, heads, N, N, device=DEV), torch.zeros(B, 3 * C, N, device=DEV)
+    ops.attn_core_bwd(qd, Pd, do.to(DEV), dS, dqkv, heads, d, N, scale)
+    check(dS, S.grad * scale, 5e-5, "fused dS")                          # S.grad is d/d(scaled scores); dS carries the scale for dq / dk
+    check(dqkv[:, :C], qkv.grad[:, :C], 5e-5, "fused dq")
+    assert float(dqkv[:, C:].abs().max()) == 0.0                         # only the q slice is written
+    for bad in ((1, 48, 256), (1, 256, 128), (1, 256, 1024)):
+        assert not ops.attn_core_eligible(*bad)
+    with pytest.raises(RuntimeError):
+        ops.attn_core_fwd(qd[:, :, :128].contiguous(), od, None, heads, d, 128, scale)
+
+
 def test_timestep_embedding_and_silu():
     from oracle.unet_ref import timestep_embedding
     t = torch.tensor([0, 1, 17, 500, 999], dtype=torch.long)
@@ -597,6 +632,34 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
     dx = torch.empty(B, Cin, H, H, device=DEV)
     ops.conv3x3(dy.to(DEV), wt, None, dx, mode=B_CONV3_T, a_packed=pkt)
     check(dx, x.grad, BX3_TOL, f"bf16x3 dgrad {Cin}->{Cout}@{H}")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(32, 256, 256, 16), (128, 128, 256, 8), (40, 200, 128, 16), (128, 64, 64, 8)])
+def test_upsample_conv_input_gradient_with_the_2x2_sum_in_the_epilogue(B, Cin, Cout, H):
+    """Upsample2D = nearest 2x + conv3x3; its input gradient is the stride-1 dgrad at the OUTPUT resolution followed by 2x2 block sums.
+    vd_gemm_desc.pool2 does the sums in the dgrad epilogue (H is the input side; outputs 16x16 / 32x32, unsplit grid)."""
+    x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9))
+    y = ref_conv(x, w, None, B_CONV3_UP)
+    dy = torch.randn(y.shape, generator=g(2))
+    y.backward(dy)
+    OH = 2 * H
+    assert ops.bx3_pool2_eligible(Cin, Cout, OH, OH, B)
+    wd = w.to(DEV).view(Cout, -1)
+    pkt = ops.conv3_pack_weights(wd, Cin, Cout, transposed=True)
+    wt = torch.empty(Cin, Cout * 9, device=DEV)
+    dxbuf = torch.full((B, Cin + 2, H, H), 7.0, device=DEV)             # a channel slice of a wider buffer
+    ops.conv3x3(dy.to(DEV), wt, None, dxbuf[:, 1:1 + Cin], mode=B_CONV3_T, a_packed=pkt, pool2=True)
+    check(dxbuf[:, 1:1 + Cin], x.grad, BX3_TOL, f"bf16x3 upsample dgrad (fused 2x2 sum) {Cin}->{Cout}@{H}")
+    assert float((dxbuf[:, 0] - 7).abs().max()) == 0 and float((dxbuf[:, -1] - 7).abs().max()) == 0
+    dU, dx2 = torch.empty(B, Cin, OH, OH, device=DEV), torch.empty(B, Cin, H, H, device=DEV)
+    ops.conv3x3(dy.to(DEV), wt, None, dU, mode=B_CONV3_T, a_packed=pkt)
+    ops.sumpool2x2(dU, dx2)
+    assert float((dxbuf[:, 1:1 + Cin] - dx2).abs().max()) <= 2e-6 * float(dx2.abs().max())      # same products, the four sums in another order
+    # outside the supported set the flag must fail loudly, never fall back silently
+    assert not ops.bx3_pool2_eligible(Cin, Cout, OH, OH, 1)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3(dy[:1].to(DEV), wt, None, dx2[:1], mode=B_CONV3_T, a_packed=pkt, pool2=True)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,mode", [(4, 128, 128, 32, B_CONV3), (3, 192, 64, 32, B_CONV3), (2, 256, 256, 16, B_CONV3),

@@ -226,6 +226,305 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
     }
 }
 
+
+// ---- K4 fused: flash-style attention core for N = 256 tokens, split-precision (bf16x3) contractions on the bf16 matrix cores -------
+// Replaces the three launches  St = scale k^T q  ->  softmax over j  ->  o = v P  (and, backward, dP = v^T do -> dS -> dq = k dS)
+// by one: the 256 x 256 score / probability matrix of a (batch, head) lives in the accumulator registers and never reaches HBM in the
+// no-grad path (training writes P once for the backward pass; backward writes dS once for the dk product).
+//
+// Work split: one workgroup per (batch, head, 128 query columns i); wave w owns the 32 columns i0 + 32 w and ALL 256 keys j, so the
+// softmax reduction over j is lane-local (128 values per lane) plus one exchange with lane ^ 32 -- no LDS, no barrier.
+//   phase 1   X[j][i] = sum_c A1[c][j] B1[c][i]      (forward: A1 = k, B1 = q; backward: A1 = v, B1 = do)  8 accumulator tiles / wave
+//   softmax   forward:  P = softmax_j(scale X);   backward:  dS = scale P (X - sum_j P X)  with the saved P loaded into the same layout
+//   phase 2   Y[c][i] = sum_j A2[c][j] T[j][i]       (forward: A2 = v, T = P -> o;  backward: A2 = k, T = dS -> dq)
+// The phase-1 accumulator is the phase-2 B operand as it stands (guide: "an accumulator tile as the next MFMA's operand"): registers
+// 8s..8s+7 of tile jt are the k-fragment of keys  32 jt + 16 s + 8 (e >> 2) + 4 h + (e & 3)  (e = element, h = lane >> 5), so the
+// A2 fragments are staged in that key order.  Every product is hi*hi + hi*lo + lo*hi over bf16 halves (f32 accumulation), the halves
+// made where an operand is written to LDS (A1, B1, A2) or taken from the registers (T).
+// One workgroup per CU (a wave may use the whole 512-register file): 128 + 128 accumulator registers + 48 staging registers.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4_t& hi, u32x4_t& lo) {
+    bf16x8_t h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 t = (__bf16)v[j];
+        h[j] = t;
+        l[j] = (__bf16)(v[j] - (float)t);
+    }
+    hi = __builtin_bit_cast(u32x4_t, h);
+    lo = __builtin_bit_cast(u32x4_t, l);
+}
+
+struct attn_core_args {
+    const float* a1; const float* b1; const float* a2;   // [batch][channels][256] slices; channel stride 256
+    float* y;                                            // phase-2 output, same form
+    float* t_out;                                        // forward: P or null; backward: dS   ([batch*heads][256 j][256 i])
+    const float* p_in;                                   // backward: saved P
+    int64_t a1_bs, b1_bs, a2_bs, y_bs;                   // batch strides (floats)
+    int heads, d;                                        // head h = channels [h*d, (h+1)*d) of every slice
+    float scale;
+};
+
+template <int DT, bool BWD>   // DT = 32-channel tiles of the head handled per phase-2 pass (d = 32 * DT * passes)
+__global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args g) {
+    constexpr int N = 256, JT = 8;
+    constexpr int BUF1 = 8 * 256 + 8 * 128;              // phase 1: A planes [chunk][part][octet][256 j] + B planes [..][128 i], units of 16 B
+    constexpr int VPL = 258;                             // phase 2: plane stride (units); 258 = 2 mod 8 keeps the 4 planes a row is written to on distinct banks
+    constexpr int BUF2 = 8 * VPL;
+    static_assert(2 * BUF2 <= 2 * BUF1, "phase 2 reuses the phase-1 buffers");
+    __shared__ u32x4_t lds[2 * BUF1];                    // 96 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;                       // the two column halves of a (batch, head) on one XCD: they share A1 / A2
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int bh = bid >> 1, i0 = (bid & 1) * 128;
+    const int b = bh / g.heads, hd = bh - b * g.heads;
+    const int d = g.d;
+    const float* __restrict__ A1 = g.a1 + (int64_t)b * g.a1_bs + (int64_t)hd * d * N;
+    const float* __restrict__ B1 = g.b1 + (int64_t)b * g.b1_bs + (int64_t)hd * d * N + i0;
+    const float* __restrict__ A2 = g.a2 + (int64_t)b * g.a2_bs + (int64_t)hd * d * N;
+    float* __restrict__ Yb = g.y + (int64_t)b * g.y_bs + (int64_t)hd * d * N + i0;
+
+    // ---------------------------------------------------------------- phase 1
+    f32x16 sacc[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sacc[jt][v] = 0.f;
+
+    float ra[32], rb[16];
+    const int bi = tid & 127, bo = tid >> 7;             // B1 item: column, octet (and octet + 2)
+    auto load1 = [&](int st) {                           // stage = 32 channels
+        const float* __restrict__ a = A1 + (int64_t)(st * 32) * N + tid;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) ra[c] = a[(int64_t)c * N];
+        const float* __restrict__ bq = B1 + (int64_t)(st * 32) * N + bi;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rb[8 * e + c] = bq[(int64_t)((bo + 2 * e) * 8 + c) * N];
+    };
+    auto store1 = [&](int buf) {
+        u32x4_t* __restrict__ As = lds + buf * BUF1;
+        u32x4_t* __restrict__ Bs = As + 8 * 256;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {                    // octet o = chunk (o >> 1), k-octet (o & 1)
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = ra[8 * o + c];
+            u32x4_t hi, lo;
+            split8(v, hi, lo);
+            As[(((o >> 1) * 2 + 0) * 2 + (o & 1)) * 256 + tid] = hi;
+            As[(((o >> 1) * 2 + 1) * 2 + (o & 1)) * 256 + tid] = lo;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int o = bo + 2 * e;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = rb[8 * e + c];
+            u32x4_t hi, lo;
+            split8(v, hi, lo);
+            Bs[(((o >> 1) * 2 + 0) * 2 + (o & 1)) * 128 + bi] = hi;
+            Bs[(((o >> 1) * 2 + 1) * 2 + (o & 1)) * 128 + bi] = lo;
+        }
+    };
+    const int nst1 = d / 32;
+    load1(0);
+    store1(0);
+    __syncthreads();
+    for (int st = 0; st < nst1; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst1;
+        if (more) load1(st + 1);
+        const u32x4_t* __restrict__ As = lds + buf * BUF1 + h * 256 + l31;
+        const u32x4_t* __restrict__ Bs = lds + buf * BUF1 + 8 * 256 + h * 128 + 32 * wave + l31;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const bf16x8_t bhf = __builtin_bit_cast(bf16x8_t, Bs[((ch * 2 + 0) * 2) * 128]);
+            const bf16x8_t blf = __builtin_bit_cast(bf16x8_t, Bs[((ch * 2 + 1) * 2) * 128]);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, As[((ch * 2 + 0) * 2) * 256 + 32 * jt]);
+                const bf16x8_t al = __builtin_bit_cast(bf16x8_t, As[((ch * 2 + 1) * 2) * 256 + 32 * jt]);
+                sacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhf, sacc[jt], 0, 0, 0);
+                sacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blf, sacc[jt], 0, 0, 0);
+                sacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhf, sacc[jt], 0, 0, 0);
+            }
+        }
+        if (more) store1(buf ^ 1);                       // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- softmax (forward) / its gradient (backward), in registers
+    // lane (l31, h) of wave w holds column i = i0 + 32 w + l31, rows j = 32 jt + (v & 3) + 8 (v >> 2) + 4 h
+    // wave-uniform base (SGPR pair) + one 32-bit lane offset: the 128 rows of a lane are then constants added to that offset, not
+    // 128 separate 64-bit addresses
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int64_t t_base = ((int64_t)bh * N) * N + i0 + 32 * wave_u;
+    const unsigned t_lane = (unsigned)(l31 + 4 * h * N);
+    const float* __restrict__ p_in = g.p_in + t_base;
+    float* __restrict__ t_out = g.t_out + t_base;
+    if (!BWD) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                sacc[jt][v] *= g.scale;
+                mx = fmaxf(mx, sacc[jt][v]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                sacc[jt][v] = __expf(sacc[jt][v] - mx);
+                sum += sacc[jt][v];
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) sacc[jt][v] *= inv;
+    } else {
+        // two sweeps over the saved P (the second one is served by L2 / MALL): holding it beside the accumulators would need 256 + 128
+        // live registers per lane and spill
+        float dot = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                dot += p_in[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] * sacc[jt][v];
+            }
+            asm volatile("" ::: "memory");               // at most one tile's 16 loads in flight: all 128 hoisted cost 128 registers and spill
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        asm volatile("" ::: "memory");                   // really load P again: common-subexpression elimination would keep all 128 values live
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                sacc[jt][v] = g.scale * p_in[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] * (sacc[jt][v] - dot);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+    if (g.t_out) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                t_out[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] = sacc[jt][v];
+            }
+    }
+
+    // T as the phase-2 B operand: bf16 (hi, lo) k-fragments, made once (the f32 tile dies as its halves are made)
+    u32x4_t thi[JT][2], tlo[JT][2];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float tv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tv[e] = sacc[jt][8 * s2 + e];
+            split8(tv, thi[jt][s2], tlo[jt][s2]);
+        }
+
+    // ---------------------------------------------------------------- phase 2
+    // A2 item (row c, u = (k-step of the stage, lane half)): keys 32 st + 16 (u >> 1) + 4 (u & 1) + {0..3} and + 8 + {0..3}
+    constexpr int ROWS = 32 * DT, ITEMS = (ROWS * 4 + 255) / 256;
+    const int vu = tid & 3, vc = tid >> 2;               // row vc + 64 it
+    f32x4 rv[ITEMS][2];
+    const int npass = d / ROWS;
+    for (int pass = 0; pass < npass; ++pass) {
+        const float* __restrict__ A2p = A2 + (int64_t)(pass * ROWS) * N;
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) oacc[ct][v] = 0.f;
+        auto load2 = [&](int st) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int c = min(vc + 64 * it, ROWS - 1);
+                const float* __restrict__ src = A2p + (int64_t)c * N + 32 * st + 16 * (vu >> 1) + 4 * (vu & 1);
+                rv[it][0] = *reinterpret_cast<const f32x4*>(src);
+                rv[it][1] = *reinterpret_cast<const f32x4*>(src + 8);
+            }
+        };
+        auto store2 = [&](int buf) {
+            u32x4_t* __restrict__ Vs = lds + buf * BUF2;
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int c = vc + 64 * it;
+                if (c < ROWS) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = rv[it][0][e];
+                        v[4 + e] = rv[it][1][e];
+                    }
+                    u32x4_t hi, lo;
+                    split8(v, hi, lo);
+                    Vs[(0 * 4 + vu) * VPL + c] = hi;         // plane = part * 4 + kstep * 2 + h = part * 4 + u
+                    Vs[(1 * 4 + vu) * VPL + c] = lo;
+                }
+            }
+        };
+        __syncthreads();                                 // every wave is done with the LDS of the previous phase / pass
+        load2(0);
+        store2(0);
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < JT; ++st) {                // stage = 32 keys = accumulator tile st of phase 1 (static register indices)
+            const int buf = st & 1;
+            if (st + 1 < JT) load2(st + 1);
+            const u32x4_t* __restrict__ Vs = lds + buf * BUF2 + l31;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t bhf = __builtin_bit_cast(bf16x8_t, thi[st][s2]), blf = __builtin_bit_cast(bf16x8_t, tlo[st][s2]);
+#pragma unroll
+                for (int ct = 0; ct < DT; ++ct) {
+                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, Vs[(0 * 4 + s2 * 2 + h) * VPL + 32 * ct]);
+                    const bf16x8_t al = __builtin_bit_cast(bf16x8_t, Vs[(1 * 4 + s2 * 2 + h) * VPL + 32 * ct]);
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhf, oacc[ct], 0, 0, 0);
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blf, oacc[ct], 0, 0, 0);
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhf, oacc[ct], 0, 0, 0);
+                }
+            }
+            if (st + 1 < JT) store2(buf ^ 1);
+            __syncthreads();
+        }
+        float* __restrict__ Yp = Yb + (int64_t)(pass * ROWS) * N + 32 * wave_u;
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                Yp[t_lane + (unsigned)((32 * ct + (v & 3) + 8 * (v >> 2)) * N)] = oacc[ct][v];
+            }
+    }
+}
+
+template <bool BWD>
+static int launch_attn_core(const attn_core_args& a, int nbh, hipStream_t st) {
+    const dim3 grid(2 * nbh);
+    const int d = a.d;
+    if (d % 256 == 0) hipLaunchKernelGGL((attn_core_kernel<8, BWD>), grid, dim3(256), 0, st, a);
+    else if (d == 128) hipLaunchKernelGGL((attn_core_kernel<4, BWD>), grid, dim3(256), 0, st, a);
+    else if (d == 64) hipLaunchKernelGGL((attn_core_kernel<2, BWD>), grid, dim3(256), 0, st, a);
+    else if (d == 32) hipLaunchKernelGGL((attn_core_kernel<1, BWD>), grid, dim3(256), 0, st, a);
+    else return VD_EINVAL;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int vd_softmax_col_fwd(float* S, int nb, int N, void* stream) {
@@ -264,5 +563,58 @@ extern "C" int vd_attn_small_bwd(const float* qkv, const float* P, const float* 
     hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, P, dout, dqkv, C, N, scale,
                        qkv_bstride, dout_bstride, dqkv_bstride);
     VD_LAUNCH_CHECK("vd_attn_small_bwd");
+    return 0;
+}
+
+static bool attn_core_shape_ok(int B, int heads, int d, int N) {
+    return B > 0 && heads > 0 && N == 256 && (d == 32 || d == 64 || d == 128 || (d > 0 && d % 256 == 0));
+}
+
+extern "C" int vd_attn_core_fwd(const float* qkv, float* out, float* P, int B, int heads, int head_dim, int N, float scale,
+                                void* stream) {
+    VD_REQUIRE(qkv && out, "vd_attn_core_fwd: null pointer");
+    VD_REQUIRE(attn_core_shape_ok(B, heads, head_dim, N), "vd_attn_core_fwd: needs N == 256 tokens and head_dim in {32, 64, 128, 256 k} "
+               "(B=%d heads=%d head_dim=%d N=%d)", B, heads, head_dim, N);
+    VD_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0, "vd_attn_core_fwd: pointers must be 16-byte aligned");
+    const int64_t C = (int64_t)heads * head_dim;
+    attn_core_args a;
+    a.a1 = qkv + C * N;          // k
+    a.b1 = qkv;                  // q
+    a.a2 = qkv + 2 * C * N;      // v
+    a.y = out;
+    a.t_out = P;
+    a.p_in = nullptr;
+    a.a1_bs = a.b1_bs = a.a2_bs = 3 * C * N;
+    a.y_bs = C * N;
+    a.heads = heads;
+    a.d = head_dim;
+    a.scale = scale;
+    VD_REQUIRE(launch_attn_core<false>(a, B * heads, (hipStream_t)stream) == 0, "vd_attn_core_fwd: unsupported head_dim %d", head_dim);
+    VD_LAUNCH_CHECK("vd_attn_core_fwd");
+    return 0;
+}
+
+extern "C" int vd_attn_core_bwd(const float* qkv, const float* P, const float* dout, float* dS, float* dqkv, int B, int heads,
+                                int head_dim, int N, float scale, void* stream) {
+    VD_REQUIRE(qkv && P && dout && dS && dqkv, "vd_attn_core_bwd: null pointer");
+    VD_REQUIRE(attn_core_shape_ok(B, heads, head_dim, N), "vd_attn_core_bwd: needs N == 256 tokens and head_dim in {32, 64, 128, 256 k} "
+               "(B=%d heads=%d head_dim=%d N=%d)", B, heads, head_dim, N);
+    VD_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) == 0, "vd_attn_core_bwd: pointers must be 16-byte aligned");
+    const int64_t C = (int64_t)heads * head_dim;
+    attn_core_args a;
+    a.a1 = qkv + 2 * C * N;      // v:  dP[j][i] = sum_c v[c][j] do[c][i]
+    a.b1 = dout;
+    a.a2 = qkv + C * N;          // k:  dq[c][i] = sum_j k[c][j] dS[j][i]
+    a.y = dqkv;                  // the q slice of dqkv
+    a.t_out = dS;
+    a.p_in = P;
+    a.a1_bs = a.a2_bs = 3 * C * N;
+    a.b1_bs = C * N;
+    a.y_bs = 3 * C * N;
+    a.heads = heads;
+    a.d = head_dim;
+    a.scale = scale;
+    VD_REQUIRE(launch_attn_core<true>(a, B * heads, (hipStream_t)stream) == 0, "vd_attn_core_bwd: unsupported head_dim %d", head_dim);
+    VD_LAUNCH_CHECK("vd_attn_core_bwd");
     return 0;
 }

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("debug", _i32), ("alpha", _f32),
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32), ("nb2", _i32),
-                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32)]
+                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32), ("pool2", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -68,6 +68,8 @@ PROTOTYPES = {
     "vd_softmax_col_bwd": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "vd_attn_small_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i64, _i64, _vp]),
     "vd_attn_small_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i64, _i64, _i64, _vp]),
+    "vd_attn_core_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "vd_attn_core_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "vd_timestep_embedding": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_silu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "vd_silu_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
@@ -123,7 +125,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 3:
+    if lib.vd_abi_version() != 4:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -44,6 +44,21 @@ def _s() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _timed(name, amount, kind, call, nbytes=None):
+    """Run `call()`; while profiling is on, bracket it with HIP events on the launch stream and record a dict
+    {name, flops, bytes, e0, e1, kind}: kind "mfma" -> amount = algorithmic FLOPs (nbytes = algorithmic bytes, optional),
+    kind "hbm" -> amount = algorithmic bytes (every operand read once / written once)."""
+    if _PROF is None:
+        return call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = call()
+    e1.record()
+    _PROF.append({"name": name, "flops": float(amount) if kind == "mfma" else 0.0, "bytes": float(nbytes if nbytes is not None else (amount if kind == "hbm" else 0.0)),
+                  "e0": e0, "e1": e1, "kind": kind})
+    return r
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -73,9 +88,10 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0):
+         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False):
     d = GemmDesc()
     d.pad = pad
+    d.pool2 = int(pool2)
     d.math = math_mode
     if a_packed is not None:
         d.a_packed, d.a_packed_mpad = a_packed.data_ptr(), (M + 127) // 128 * 128
@@ -105,6 +121,16 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     L.check(lib.vd_gemm(C.byref(d), _s()), "vd_gemm")
     e1.record()
     flops = 2.0 * M * N * K * (0.25 if b_mode == B_CONV3_DIL else 1.0)     # DIL: 3/4 of the taps are structural zeros
+    # algorithmic bytes: B (the activation operand) read once, D written once (+ residual read), A read once
+    if conv is not None:
+        nb_ = N // d.NP
+        b_elems = nb_ * d.C * d.H * d.W
+        a_elems = M * K
+    else:
+        b_elems = K * N
+        a_elems = M * K * (N // d.NP if a_bstride else 1)
+    d_elems = M * N // (4 if pool2 else 1)
+    nbytes = 4.0 * (b_elems + d_elems * (2 if residual is not None else 1) + a_elems)
     tl = lib.vd_gemm_tile(C.byref(d))
     if tl == 10:
         name = f"gemm_bx3_act_kernel<{int(a_mode == A_ROW)}, {int(b_mode == B_KCONTIG)}>"
@@ -123,7 +149,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = f"conv3_smallm_kernel<{32 if d.W % 32 == 0 else 16}, 4>"
     else:
         name = f"gemm_kernel<{_TILE_NAMES[tl]},{'ROW' if a_mode == A_ROW else 'COL'},{_B_NAMES[b_mode]}>"
-    _PROF.append((name, flops, e0, e1))
+    _PROF.append({"name": name, "flops": flops, "bytes": nbytes, "e0": e0, "e1": e1, "kind": "mfma"})
     return D
 
 
@@ -166,24 +192,40 @@ def bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     return OH == OW and OW in (4, 8, 16, 32)
 
 
+def bx3_pool2_eligible(M, Cc, OH, OW, nb) -> bool:
+    """The split-precision stride-1 dgrad can add the 2x2 blocks of its output in the epilogue (vd_gemm_desc.pool2): 16x16 / 32x32 outputs
+    on an unsplit grid (>= 256 tiles of 128 channels x 128 pixels; below that the kernel splits the channel loop over workgroups)."""
+    return bx3_eligible(M, Cc, OH, OW, B_CONV3_T) and OH == OW and OW in (16, 32) and ((M + 127) // 128) * ((nb * OH * OW + 127) // 128) >= 256
+
+
 def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
-            pad=0, gn_ss=None, a_packed=None):
+            pad=0, gn_ss=None, a_packed=None, pool2=False):
     """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9].
-    pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1)."""
+    pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1).
+    pool2 (B_CONV3_T with a_packed only): `out` has HALF the resolution and receives the 2x2 block sums of the result."""
     Bn, Cc, H, W, xbs = _img(x)
     M = w2d.shape[0]
     assert w2d.shape[1] == Cc * 9 and w2d.is_contiguous()
     OH, OW = _CONV_OUT[mode](H, W)
     Bo, Mo, OHo, OWo, obs = _img(out)
-    assert (Bo, Mo, OHo, OWo) == (Bn, M, OH, OW), (out.shape, (Bn, M, OH, OW))
+    if pool2:
+        assert (Bo, Mo, OHo, OWo) == (Bn, M, OH // 2, OW // 2) and mode == B_CONV3_T and a_packed is not None, (out.shape, (Bn, M, OH, OW))
+        assert bias is None and rowadd is None and residual is None and not accumulate
+    else:
+        assert (Bo, Mo, OHo, OWo) == (Bn, M, OH, OW), (out.shape, (Bn, M, OH, OW))
     rbs = 0
     if residual is not None:
         rbs = _img(residual)[4]
         assert residual.shape == out.shape
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
-                ldd=OH * OW, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
+                ldd=OHo * OWo, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
-                pad=pad, gn_ss=gn_ss, a_packed=a_packed)
+                pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2)
+
+
+def attn_core_eligible(heads, head_dim, N) -> bool:
+    """Shapes the fused attention core takes (vd_attn_core_fwd / _bwd): 256 tokens, head_dim 32 / 64 / 128 or a multiple of 256."""
+    return N == 256 and heads >= 1 and (head_dim in (32, 64, 128) or (head_dim > 0 and head_dim % 256 == 0))
 
 
 def gemm_bx3_act_eligible(M, K, NP) -> bool:
@@ -276,7 +318,8 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
         name = f"wgrad_patch_kernel<{OW}, {0 if mode == B_CONV3 else 2}>(+slab_reduce)"
     else:
         name = f"wgrad_kernel<{_TILE_NAMES[tl.value]},{_B_NAMES[mode]}>(+slab_reduce)"
-    _PROF.append((name, 2.0 * M * Cc * T * Bn * OH * OW, e0, e1))
+    _PROF.append({"name": name, "flops": 2.0 * M * Cc * T * Bn * OH * OW, "bytes": 4.0 * (dy.numel() + x.numel() + M * Cc * T),
+                  "e0": e0, "e1": e1, "kind": "mfma"})
     return dw2d
 
 
@@ -359,8 +402,9 @@ def groupnorm_fwd(x, gamma, beta, y, mean, rstd, G, eps, silu):
     Bn, Cc, H, W, xbs = _img(x)
     ybs = _img(y)[4]
     assert y.shape == x.shape and mean.numel() >= Bn * G and rstd.numel() >= Bn * G
-    L.check(_lib().vd_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps,
-                                    int(silu), xbs, ybs, _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_fwd")
+    _timed("groupnorm_fwd (gn_fwd_reg_kernel<*> / gn_chunk_*)", 8.0 * x.numel(), "hbm", lambda: L.check(
+        _lib().vd_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps,
+                                int(silu), xbs, ybs, _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_fwd"))
     return y
 
 
@@ -384,9 +428,11 @@ def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma_ws, dbeta_ws, G, si
     dbs, dxbs = _img(dy)[4], _img(dx)[4]
     ebs = _img(extra)[4] if extra is not None else 0
     assert dgamma_ws.numel() >= Bn * Cc and dbeta_ws.numel() >= Bn * Cc
-    L.check(_lib().vd_groupnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(extra), _p(dx),
-                                    _p(dgamma_ws), _p(dbeta_ws), Bn, Cc, H * W, G, int(silu), dbs, xbs, ebs, dxbs,
-                                    _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_bwd")
+    nbytes = (12.0 + (4.0 if extra is not None else 0.0)) * x.numel()          # dy, x (+ extra) read once, dx written once
+    _timed("groupnorm_bwd (gn_bwd_reg_kernel<*> / gn_chunk_*)", nbytes, "hbm", lambda: L.check(
+        _lib().vd_groupnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(extra), _p(dx),
+                                _p(dgamma_ws), _p(dbeta_ws), Bn, Cc, H * W, G, int(silu), dbs, xbs, ebs, dxbs,
+                                _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_bwd"))
     return dx
 
 
@@ -399,6 +445,28 @@ def softmax_col_fwd(S, nb, N):
 def softmax_col_bwd(P, dP, nb, N, scale):
     L.check(_lib().vd_softmax_col_bwd(_p(P), _p(dP), nb, N, scale, _s()), "vd_softmax_col_bwd")
     return dP
+
+
+def attn_core_fwd(qkv, out, P, heads, head_dim, N, scale):
+    """Fused attention core (qkv [B, 3C, H, W] contiguous); P = None in the no-grad path, else the [B, heads, N, N] probabilities."""
+    Bn = qkv.shape[0]
+    assert qkv.is_contiguous() and out.is_contiguous() and (P is None or P.is_contiguous())
+    dt = 8 if head_dim % 256 == 0 else head_dim // 32
+    _timed(f"attn_core_kernel<{dt}, false>", 4.0 * Bn * heads * N * N * head_dim, "mfma", lambda: L.check(
+        _lib().vd_attn_core_fwd(_p(qkv), _p(out), _p(P), Bn, heads, head_dim, N, scale, _s()), "vd_attn_core_fwd"),
+        nbytes=4.0 * (qkv.numel() + out.numel() + (P.numel() if P is not None else 0)))
+    return out
+
+
+def attn_core_bwd(qkv, P, dout, dS, dqkv, heads, head_dim, N, scale):
+    """dS (into `dS`, [B, heads, N, N]) and dq (into dqkv[:, :C]) of the fused attention core."""
+    Bn = qkv.shape[0]
+    assert qkv.is_contiguous() and P.is_contiguous() and dout.is_contiguous() and dS.is_contiguous() and dqkv.is_contiguous()
+    dt = 8 if head_dim % 256 == 0 else head_dim // 32
+    _timed(f"attn_core_kernel<{dt}, true>", 4.0 * Bn * heads * N * N * head_dim, "mfma", lambda: L.check(
+        _lib().vd_attn_core_bwd(_p(qkv), _p(P), _p(dout), _p(dS), _p(dqkv), Bn, heads, head_dim, N, scale, _s()), "vd_attn_core_bwd"),
+        nbytes=4.0 * (qkv.numel() * 2 // 3 + dout.numel() + 2 * P.numel() + dS.numel() + qkv.numel() // 3))
+    return dqkv
 
 
 def attn_small_fwd(qkv, out, P, Cc, N, scale):
@@ -494,15 +562,17 @@ def mse_fwd_bwd(pred, y, dpred, loss, partial, pscale=None, gscale=1.0, kind="l2
 
 def l2norm_sq(g, partial, out_sq):
     assert g.is_contiguous() and partial.numel() >= 1024
-    L.check(_lib().vd_l2norm_sq(_p(g), g.numel(), _p(partial), _p(out_sq), _s()), "vd_l2norm_sq")
+    _timed("l2norm_sq (sumsq_kernel)", 4.0 * g.numel(), "hbm",
+           lambda: L.check(_lib().vd_l2norm_sq(_p(g), g.numel(), _p(partial), _p(out_sq), _s()), "vd_l2norm_sq"))
     return out_sq
 
 
 def adam_step(p, g, m, v, norm_sq, max_norm, inv_scale, lr, beta1, beta2, eps, step):
     global WEIGHTS_EPOCH
     WEIGHTS_EPOCH += 1
-    L.check(_lib().vd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm_sq), max_norm, inv_scale, lr, beta1, beta2,
-                                eps, step, _s()), "vd_adam_step")
+    _timed("adam_step (adam_kernel)", 28.0 * p.numel(), "hbm", lambda: L.check(      # p, g, m, v read; p, m, v written
+        _lib().vd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm_sq), max_norm, inv_scale, lr, beta1, beta2,
+                            eps, step, _s()), "vd_adam_step"))
 
 
 # --------------------------------------------------------------------------------------------- samplers / data

@@ -85,7 +85,14 @@ class _PackedConvWeights:
         ent = self.off[bwd].get(prefix)
         if ent is None:
             return None
+        self.refresh(bwd)
+        return self.buf[ent[0]:ent[0] + ent[1]]
+
+    def refresh(self, bwd):
+        """Rebuild the `bwd` set (one launch) if the weights have changed since it was built."""
         net = self.net
+        if not self.jobs[bwd]:
+            return
         key = (net.flat_param._version, ops.WEIGHTS_EPOCH)
         if self.key[bwd] != key:
             if self.buf is None:
@@ -100,7 +107,6 @@ class _PackedConvWeights:
             tab, nj, blk = self.tables[bwd]
             ops.conv3_pack_weights_multi(tab, nj, blk)
             self.key[bwd] = key
-        return self.buf[ent[0]:ent[0] + ent[1]]
 
 
 def _bx3_packed(net, prefix, bwd, M, Cc, OH, OW, mode):
@@ -178,9 +184,12 @@ class _Conv:
             ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T, a_packed=pk)
         elif self.mode == B_CONV3_UP:
             B, _, OH, OW = dout.shape
-            dU = torch.empty((B, self.cin, OH, OW), device=dout.device, dtype=torch.float32)
-            ops.conv3x3(dout, wt, None, dU, mode=B_CONV3_T, a_packed=pk)
-            ops.sumpool2x2(dU, dx)
+            if pk is not None and ops.bx3_pool2_eligible(self.cin, self.cout, OH, OW, B):
+                ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T, a_packed=pk, pool2=True)     # 2x2 sums in the epilogue: no 4x tensor
+            else:
+                dU = torch.empty((B, self.cin, OH, OW), device=dout.device, dtype=torch.float32)
+                ops.conv3x3(dout, wt, None, dU, mode=B_CONV3_T, a_packed=pk)
+                ops.sumpool2x2(dU, dx)
         else:
             raise NotImplementedError(self.mode)
         return dx
@@ -334,6 +343,13 @@ class _Attn:
         ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", False, 3 * Cc, Cc, N, B))
         o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
+        if net.conv_math == "bf16x3" and net.fused_attention and ops.attn_core_eligible(nh, dh, N):
+            # one launch: scores and probabilities stay in registers; P reaches HBM only when a backward pass will read it
+            P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32) if save else None
+            ops.attn_core_fwd(qkv, o, P, nh, dh, N, self.scale)
+            ops.conv1x1(o, net.P[self.prefix + ".to_out.0.weight"], net.P[self.prefix + ".to_out.0.bias"], out, residual=x,
+                        a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", False, Cc, Cc, N, B))
+            return (x, mean, rstd, g, qkv, P, o) if save else None
         P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
         if nh > 1:
             if N % 64:
@@ -382,7 +398,20 @@ class _Attn:
                  b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N, B))
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
-        if nh > 1:
+        if net.conv_math == "bf16x3" and net.fused_attention and ops.attn_core_eligible(nh, dh, N):
+            # dP, the softmax gradient and dq in one launch (dP never reaches HBM); dv and dk are products of the saved P / of dS
+            dS = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
+            ops.attn_core_bwd(qkv, P, do, dS, dqkv, nh, dh, N, self.scale)
+            bs, hs, pbs, NN = 3 * Cc * N, dh * N, nh * N * N, N * N
+            q = qkv[:, :Cc]
+            dk, dv = dqkv[:, Cc:2 * Cc], dqkv[:, 2 * Cc:]
+            two = dict(nb2=nh, NP=N, N=B * nh * N) if nh > 1 else dict(NP=N, N=B * N)
+            st2 = (lambda a, b: dict(a_b2stride=a, b_b2stride=b, d_b2stride=hs)) if nh > 1 else (lambda a, b: {})
+            ops.gemm(do, P, dv, M=dh, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, lda=N, a_bstride=Cc * N, ldb=N, b_bstride=pbs, ldd=N,
+                     d_bstride=bs, **two, **st2(hs, NN), math_mode=_amath(net, dh, N, N))
+            ops.gemm(q, dS, dk, M=dh, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, lda=N, a_bstride=bs, ldb=N, b_bstride=pbs, ldd=N,
+                     d_bstride=bs, **two, **st2(hs, NN), math_mode=_amath(net, dh, N, N))
+        elif nh > 1:
             bs, hs, pbs, NN = 3 * Cc * N, dh * N, nh * N * N, N * N
             dP = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
             q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
@@ -629,6 +658,11 @@ class UNet2DModel(nn.Module):
         # more than the saved normalise pass (26 -> 14 us): 8.22 vs 8.30 img/s for DDPM-1000.  On the split-precision kernels the patch
         # is stored once per 16 channels x 9 taps and the fold pays (7.39 -> 7.22 ms per sampler step).  None = on for "bf16x3" only.
         self.fuse_gn_inference = None
+        # attention blocks of 256 tokens run as ONE fused launch per direction in the split-precision arithmetic (vd_attn_core_*);
+        # False keeps the three-launch GEMM / column-softmax / GEMM sequence (the only path of the exact-f32 arithmetic)
+        self.fused_attention = os.environ.get("VILLAN_FUSED_ATTENTION", "1") != "0"
+        # sampler loops replay the no-grad forward from a HIP graph captured once per batch shape (pipelines.GraphedForward)
+        self.sampler_graph = os.environ.get("VILLAN_SAMPLER_GRAPH", "1") != "0"
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
