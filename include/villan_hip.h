@@ -140,6 +140,22 @@ int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc);
 /* Tile and split count vd_conv_wgrad will use (profiling / tests). */
 int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits);
 
+/* GROUPED weight gradients: several split-precision (math = 1) weight gradients of one kernel class in ONE launch pair (compute +
+ * fixed-order slab reduction).  A weight gradient has a small output and a huge reduction length (K = batch * pixels), so a launch
+ * that must fill 256 CUs alone splits K over ~32 workgroups per tile and moves 32 partial copies of dW through memory; sharing the
+ * grid between the convolutions of a whole gradient bucket keeps the chip full with ~3 splits per tile.  (The reference's autograd
+ * computes one weight gradient per convolution, VillanDiffusion.py:1161 accelerator.backward; the result is the same sum.)
+ *   class  = vd_conv_wgrad_group_class(desc): 0 = not groupable (vd_conv_wgrad), equal values may share a launch;
+ *   plan   : writes the host image of the device job table (n * vd_conv_wgrad_group_job_bytes() bytes; slab pointers held as OFFSETS),
+ *            the workspace floats, the compute and reduce grid sizes; returns the class (> 0) or VD_EINVAL (< 0 never; 0 = error);
+ *   rebase : once per uploaded table: turns the slab offsets into pointers into `ws`;
+ *   launch : the two launches.  Deterministic (fixed reduction order); results agree with vd_conv_wgrad to summation order. */
+int vd_conv_wgrad_group_class(const vd_wgrad_desc* desc);
+int64_t vd_conv_wgrad_group_job_bytes(void);
+int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void* table_out, int64_t* ws_floats, int* blocks, int* rblocks);
+int vd_conv_wgrad_group_rebase(void* dev_table, int n, float* ws, void* stream);
+int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls, int blocks, int rblocks, void* stream);
+
 /* Split-precision operand for vd_gemm_desc.a_packed.  taps = 9: element (m, c, t) of the logical [M][C][9] matrix of a 3x3
  * convolution is read from W[m*row_stride + c*chan_stride + t] (plain weights: row_stride = C*9, chan_stride = 9; the transposed
  * operand of the stride-1 dgrad, A'[c_in][m_out] = W[m_out][c_in]: row_stride = 9, chan_stride = C_in*9 with M = C_in, C = M_out).
@@ -210,11 +226,12 @@ int vd_attn_small_bwd(const float* qkv, const float* P, const float* dout, float
  *   out[b][h d + c][i] = sum_j v[c][j] P[j][i],  P[.][i] = softmax_j(scale * sum_c k[c][j] q[c][i]).
  * P == NULL: nothing but `out` is written (no-grad path).  P != NULL: [B*heads][N][N] (P[j][i]) is written once for the backward pass.
  * head_dim in {32, 64, 128} or a multiple of 256; anything else / N != 256 -> VD_EINVAL (callers keep the 3-launch path).
- * vd_attn_core_bwd: dP = v^T dout, dS = scale P (dP - sum_j P dP) (written to dS, [B*heads][N][N]) and dq = k dS (written into the
- * q slice of dqkv [B][3C][N]) in one launch; dk = q dS^T and dv = dout P^T are plain products of dS / P (vd_gemm). */
+ * vd_attn_core_bwd: dP = v^T dout, dS = scale P (dP - delta) with delta_i = sum_j P dP = sum_c dout[c][i] out[c][i] (the saved forward
+ * output, so P is read once), dS written to [B*heads][N][N], and dq = k dS written into the q slice of dqkv [B][3C][N] -- one launch;
+ * dk = q dS^T and dv = dout P^T are plain products of dS / P (vd_gemm). */
 int vd_attn_core_fwd(const float* qkv, float* out, float* P, int B, int heads, int head_dim, int N, float scale, void* stream);
-int vd_attn_core_bwd(const float* qkv, const float* P, const float* dout, float* dS, float* dqkv, int B, int heads, int head_dim,
-                     int N, float scale, void* stream);
+int vd_attn_core_bwd(const float* qkv, const float* P, const float* out, const float* dout, float* dS, float* dqkv, int B, int heads,
+                     int head_dim, int N, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3 -- timestep embedding + small elementwise helpers.

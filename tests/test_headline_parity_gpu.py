@@ -109,11 +109,9 @@ def test_twenty_optimiser_steps_match_oracle(ref0):
         upd = _update_l2(nets[cm], ref, theta0)
         print(f"[parity] 20 optimiser steps ({cm}): worst per-step loss rel-err {worst_loss[cm]:.3e}, update L2 error {upd:.3e}")
         assert trs[cm].opt.step_count == steps and trs[cm].sched_step == steps
-        # the per-step loss is held to 1e-4 (grows from 2e-6 at step 0 as the two parameter trajectories separate); the update as a
-        # whole to 2e-2: Adam's early steps are ~lr * sign(g) per element, so every element whose gradient sits at rounding level
-        # contributes a full-size difference whatever the arithmetic (exact f32 shows the same floor)
-        assert worst_loss[cm] <= 1e-4, (cm, worst_loss[cm])
-        assert upd <= 2e-2, (cm, upd)
+        # measured on MI355X: per-step loss 2.4e-7 (bf16x3) / 1.2e-7 (f32), update L2 error 3.5e-5 / 1.2e-5
+        assert worst_loss[cm] <= 1e-5, (cm, worst_loss[cm])
+        assert upd <= 1e-3, (cm, upd)
 
 
 @pytest.mark.timeout(900)
@@ -145,7 +143,9 @@ def test_config1_batch4_grad_accum_32_one_sync_step(ref0):
         upd = _update_l2(nets[cm], ref, theta0)
         print(f"[parity] G=32 sync step ({cm}): grad-norm rel-err {abs(gn - gn_ref) / gn_ref:.3e}, update L2 error {upd:.3e}")
         assert abs(gn - gn_ref) <= 1e-4 * gn_ref
-        assert upd <= 2e-2, (cm, upd)
+        # The first Adam step is lr * sign(g) per element: an element whose gradient sits at rounding level flips and contributes a
+        # full-size difference whatever the arithmetic.  Measured: 3.3e-4 (bf16x3) / 8.8e-5 (f32)
+        assert upd <= 3e-3, (cm, upd)
         assert trs[cm].sched_step == 2
 
 
@@ -184,4 +184,4 @@ def test_accumulation_boundaries_restart_every_epoch(ref0):
     assert pattern == [0, 1, 1, 0, 1, 1]
     upd = _update_l2(net, ref, theta0)
     print(f"[parity] accumulation across epochs: update L2 error {upd:.3e}")
-    assert upd <= 2e-2
+    assert upd <= 5e-3            # measured 6.5e-4 (four early-Adam steps of a 2-image batch: sign flips of rounding-level gradients)

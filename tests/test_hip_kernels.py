@@ -302,7 +302,7 @@ def test_attention_core_fused(B, heads, d):
     ops.attn_core_fwd(qd, od2, None, heads, d, N, scale)                 # no-grad path: nothing but `out` is written
     assert torch.equal(od2, od)
     dS, dqkv = torch.empty(B, heads, N, N, device=DEV), torch.zeros(B, 3 * C, N, device=DEV)
-    ops.attn_core_bwd(qd, Pd, do.to(DEV), dS, dqkv, heads, d, N, scale)
+    ops.attn_core_bwd(qd, Pd, od, do.to(DEV), dS, dqkv, heads, d, N, scale)
     check(dS, S.grad * scale, 5e-5, "fused dS")                          # S.grad is d/d(scaled scores); dS carries the scale for dq / dk
     check(dqkv[:, :C], qkv.grad[:, :C], 5e-5, "fused dq")
     assert float(dqkv[:, C:].abs().max()) == 0.0                         # only the q slice is written
@@ -693,6 +693,64 @@ def test_split_precision_weight_gradient(B, Cin, Cout, H, mode):
     ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw3, mode, ws, accumulate=False, math_mode=1)
     ops.conv_wgrad(dy.to(DEV), xbuf[:, 4:], dw2, mode, ws, accumulate=False, math_mode=1)
     assert torch.equal(dw2, dw3)
+
+
+GROUPS = [
+    # (input side H, mode, [(B, Cin, Cout), ...]) -- one kernel class per group, ragged shapes, mixed batch sizes
+    (16, B_CONV3, [(16, 256, 256), (16, 512, 256), (5, 64, 200), (16, 128, 96)]),
+    (32, B_CONV3, [(8, 128, 128), (8, 384, 128), (3, 192, 64)]),
+    (8, B_CONV3, [(32, 256, 256), (6, 256, 128), (1, 64, 64)]),
+    (4, B_CONV3, [(128, 256, 256), (7, 64, 96), (1, 128, 64)]),
+    (8, B_CONV3_UP, [(8, 256, 128), (3, 128, 128)]),
+    (64, B_CONV3, [(2, 64, 128), (1, 72, 64)]),
+    (16, B_PLAIN, [(16, 256, 768), (16, 512, 256), (3, 80, 64), (16, 256, 256)]),
+    (32, B_PLAIN, [(8, 384, 128), (8, 256, 128), (2, 128, 256)]),
+]
+
+
+@pytest.mark.parametrize("H,mode,jobs", GROUPS)
+def test_grouped_weight_gradients(H, mode, jobs):
+    """vd_conv_wgrad_group_*: several weight gradients of one kernel class in ONE launch pair, each job split over only as many
+    workgroups as its share of the grid -- against torch's fp32 weight gradient and against the one-launch-per-convolution path."""
+    T = 1 if mode == B_PLAIN else 9
+    descs, keep, refs, outs = [], [], [], []
+    for k, (B, Cin, Cout) in enumerate(jobs):
+        x = torch.randn(B, Cin, H, H, generator=g(10 * k))
+        w = (torch.randn(Cout, Cin, 3 if T == 9 else 1, 3 if T == 9 else 1, generator=g(10 * k + 1)) / math.sqrt(Cin * T)).requires_grad_()
+        y = ref_conv(x, w, None, mode) if T == 9 else F.conv2d(x, w)
+        dy = torch.randn(y.shape, generator=g(10 * k + 2))
+        y.backward(dy)
+        xbuf = torch.zeros(B, Cin + 4, H, H, device=DEV)            # operands that are channel slices of wider buffers
+        xbuf[:, 4:] = x.to(DEV)
+        dyd = dy.to(DEV)
+        dw = torch.full((Cout, Cin * T), 0.25, device=DEV)
+        d = ops.wgrad_desc(dyd, xbuf[:, 4:], dw, mode, None, accumulate=True, math_mode=1)
+        assert ops.wgrad_group_class(d) != 0, (H, mode, B, Cin, Cout)
+        descs.append(d)
+        keep.append((xbuf, dyd))
+        refs.append(w.grad.view(Cout, -1))
+        outs.append(dw)
+    assert len({ops.wgrad_group_class(d) for d in descs}) == 1
+    ops.conv_wgrad_group(descs, torch.device(DEV))
+    for k, (dw, ref) in enumerate(zip(outs, refs)):
+        check(dw - 0.25, ref, BX3_TOL, f"grouped wgrad mode={mode} job {k} {jobs[k]}@{H}")
+    snap = [o.clone() for o in outs]
+    ops.conv_wgrad_group(descs, torch.device(DEV))                  # cached job table; accumulate = True adds the same bits again
+    for o, s0, ref in zip(outs, snap, refs):
+        check(o - s0, ref, BX3_TOL, "grouped wgrad, second accumulation")
+    # the one-launch-per-convolution path computes the same sums in another split order
+    for k, (B, Cin, Cout) in enumerate(jobs):
+        xbuf, dyd = keep[k]
+        OH = dyd.shape[-1]
+        ws = torch.empty(max(ops.wgrad_ws_floats(Cout, Cin, T, B, OH * OH, mode=mode, math_mode=1), 4), device=DEV)
+        single = torch.zeros(Cout, Cin * T, device=DEV)
+        ops.conv_wgrad(dyd, xbuf[:, 4:], single, mode, ws, accumulate=False, math_mode=1)
+        assert float((single - (snap[k] - 0.25)).abs().max()) <= 2e-5 * float(single.abs().max())
+    # mixing kernel classes in one group is an error
+    if mode == B_CONV3 and H == 16:
+        x8, dy8, dw8 = torch.randn(2, 64, 8, 8, device=DEV), torch.randn(2, 64, 8, 8, device=DEV), torch.zeros(64, 64 * 9, device=DEV)
+        with pytest.raises(RuntimeError):
+            ops.conv_wgrad_group(descs[:1] + [ops.wgrad_desc(dy8, x8, dw8, B_CONV3, None, accumulate=True, math_mode=1)], torch.device(DEV))
 
 
 def test_split_precision_requests_outside_the_supported_set_fail_loudly():

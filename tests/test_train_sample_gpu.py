@@ -304,7 +304,9 @@ def test_celebahq256_config_train_step_with_image_trigger():
 
 def test_cli_resume_continues_from_the_checkpoint(tmp_path):
     """--mode resume (reference :454-461, 1103-1115): model from the run directory, optimiser / LR-schedule / counters from
-    ckpt/trainer.pt and data.ckpt; training continues at the saved epoch."""
+    ckpt/trainer.pt and data.ckpt.  As in the reference the checkpoint records the 0-based index of the epoch it was written AFTER
+    (`checkpoint(cur_epoch=epoch)`, :1181) and the loop restarts AT that index (`range(start_epoch, config.epoch)`, :1132): the last
+    checkpointed epoch is run again."""
     res = str(tmp_path / "exp")
     env = dict(os.environ, PYTHONPATH=ROOT)
     code = ("import sys; sys.argv=['VillanDiffusion.py']+%r; import villandiffusion_amd.dataset as D;"
@@ -318,7 +320,7 @@ def test_cli_resume_continues_from_the_checkpoint(tmp_path):
     run = os.path.join(res, os.listdir(res)[0])
     st1 = torch.load(os.path.join(run, "ckpt", "trainer.pt"), map_location="cpu")
     d1 = torch.load(os.path.join(run, "data.ckpt"))
-    assert d1["epoch"] == 1 and d1["step"] == 2 and st1["sched_step"] == 2 and st1["optimizer"]["step"] == 2
+    assert d1["epoch"] == 0 and d1["step"] == 2 and st1["sched_step"] == 2 and st1["optimizer"]["step"] == 2
     w1 = {}
     from safetensors.torch import load_file
     w1 = load_file(os.path.join(run, "unet", "diffusion_pytorch_model.safetensors"))["conv_in.weight"].clone()
@@ -330,7 +332,7 @@ def test_cli_resume_continues_from_the_checkpoint(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     st2 = torch.load(os.path.join(run, "ckpt", "trainer.pt"), map_location="cpu")
     d2 = torch.load(os.path.join(run, "data.ckpt"))
-    assert d2["epoch"] == 2 and d2["step"] == 4 and st2["sched_step"] == 4 and st2["optimizer"]["step"] == 4
+    assert d2["epoch"] == 1 and d2["step"] == 6 and st2["sched_step"] == 6 and st2["optimizer"]["step"] == 6      # epochs 0 (again) and 1
     w2 = load_file(os.path.join(run, "unet", "diffusion_pytorch_model.safetensors"))["conv_in.weight"]
     assert not torch.equal(w1, w2) and bool(torch.isfinite(w2).all())
     assert float(st2["optimizer"]["exp_avg_sq"].abs().max()) > 0

@@ -262,7 +262,8 @@ struct attn_core_args {
     float* y;                                            // phase-2 output, same form
     float* t_out;                                        // forward: P or null; backward: dS   ([batch*heads][256 j][256 i])
     const float* p_in;                                   // backward: saved P
-    int64_t a1_bs, b1_bs, a2_bs, y_bs;                   // batch strides (floats)
+    const float* o_in;                                   // backward: saved forward output o (for delta_i = sum_c do[c][i] o[c][i])
+    int64_t a1_bs, b1_bs, a2_bs, y_bs, o_bs;             // batch strides (floats)
     int heads, d;                                        // head h = channels [h*d, (h+1)*d) of every slice
     float scale;
 };
@@ -287,19 +288,25 @@ __global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args 
     const int d = g.d;
     const float* __restrict__ A1 = g.a1 + (int64_t)b * g.a1_bs + (int64_t)hd * d * N;
     const float* __restrict__ B1 = g.b1 + (int64_t)b * g.b1_bs + (int64_t)hd * d * N + i0;
+    const float* __restrict__ O1 = BWD ? g.o_in + (int64_t)b * g.o_bs + (int64_t)hd * d * N + i0 : nullptr;
     const float* __restrict__ A2 = g.a2 + (int64_t)b * g.a2_bs + (int64_t)hd * d * N;
     float* __restrict__ Yb = g.y + (int64_t)b * g.y_bs + (int64_t)hd * d * N + i0;
 
     // ---------------------------------------------------------------- phase 1
+    // One wave per SIMD: nothing else hides a load's latency, so the loads run TWO stages ahead (two register sets, stages unrolled by
+    // two) and a stage is one branch-free block  {issue loads of stage s + 2 | 48 MFMAs of stage s | split + LDS writes of stage s + 1}.
     f32x16 sacc[JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) sacc[jt][v] = 0.f;
 
-    float ra[32], rb[16];
+    float ra0[32], rb0[16], ro0[BWD ? 16 : 1], ra1[32], rb1[16], ro1[BWD ? 16 : 1];
+    float dpart = 0.f;                                   // backward: this thread's share of delta for column bi
     const int bi = tid & 127, bo = tid >> 7;             // B1 item: column, octet (and octet + 2)
-    auto load1 = [&](int st) {                           // stage = 32 channels
+    const int nst1 = d / 32;
+    auto load1 = [&](int st, float (&ra)[32], float (&rb)[16], float (&ro)[BWD ? 16 : 1]) {     // stage = 32 channels
+        st = min(st, nst1 - 1);                          // past the end: reload the last stage (its copy is never read)
         const float* __restrict__ a = A1 + (int64_t)(st * 32) * N + tid;
 #pragma unroll
         for (int c = 0; c < 32; ++c) ra[c] = a[(int64_t)c * N];
@@ -308,8 +315,15 @@ __global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args 
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int c = 0; c < 8; ++c) rb[8 * e + c] = bq[(int64_t)((bo + 2 * e) * 8 + c) * N];
+        if (BWD) {
+            const float* __restrict__ oq = O1 + (int64_t)(st * 32) * N + bi;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) ro[8 * e + c] = oq[(int64_t)((bo + 2 * e) * 8 + c) * N];
+        }
     };
-    auto store1 = [&](int buf) {
+    auto store1 = [&](int buf, const float (&ra)[32], const float (&rb)[16], const float (&ro)[BWD ? 16 : 1], bool real) {
         u32x4_t* __restrict__ As = lds + buf * BUF1;
         u32x4_t* __restrict__ Bs = As + 8 * 256;
 #pragma unroll
@@ -328,20 +342,19 @@ __global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args 
             float v[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = rb[8 * e + c];
+            if (BWD) {
+                float t = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) t += rb[8 * e + c] * ro[8 * e + c];
+                dpart += real ? t : 0.f;
+            }
             u32x4_t hi, lo;
             split8(v, hi, lo);
             Bs[(((o >> 1) * 2 + 0) * 2 + (o & 1)) * 128 + bi] = hi;
             Bs[(((o >> 1) * 2 + 1) * 2 + (o & 1)) * 128 + bi] = lo;
         }
     };
-    const int nst1 = d / 32;
-    load1(0);
-    store1(0);
-    __syncthreads();
-    for (int st = 0; st < nst1; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < nst1;
-        if (more) load1(st + 1);
+    auto mfma1 = [&](int buf) {
         const u32x4_t* __restrict__ As = lds + buf * BUF1 + h * 256 + l31;
         const u32x4_t* __restrict__ Bs = lds + buf * BUF1 + 8 * 256 + h * 128 + 32 * wave + l31;
 #pragma unroll
@@ -357,18 +370,30 @@ __global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args 
                 sacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhf, sacc[jt], 0, 0, 0);
             }
         }
-        if (more) store1(buf ^ 1);                       // the other buffer was last read before the previous barrier
+    };
+    load1(0, ra0, rb0, ro0);
+    load1(1, ra1, rb1, ro1);
+    store1(0, ra0, rb0, ro0, true);
+    __syncthreads();
+    for (int st = 0; st < nst1; st += 2) {
+        load1(st + 2, ra0, rb0, ro0);
+        mfma1(0);
+        store1(1, ra1, rb1, ro1, st + 1 < nst1);
+        __syncthreads();
+        if (st + 1 >= nst1) break;
+        load1(st + 3, ra1, rb1, ro1);
+        mfma1(1);
+        store1(0, ra0, rb0, ro0, st + 2 < nst1);
         __syncthreads();
     }
 
     // ---------------------------------------------------------------- softmax (forward) / its gradient (backward), in registers
-    // lane (l31, h) of wave w holds column i = i0 + 32 w + l31, rows j = 32 jt + (v & 3) + 8 (v >> 2) + 4 h
+    // lane (l31, h) of wave w holds column i = i0 + 32 w + l31, rows j = 32 jt + (v & 3) + 8 (v >> 2) + 4 h.
     // wave-uniform base (SGPR pair) + one 32-bit lane offset: the 128 rows of a lane are then constants added to that offset, not
     // 128 separate 64-bit addresses
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int64_t t_base = ((int64_t)bh * N) * N + i0 + 32 * wave_u;
     const unsigned t_lane = (unsigned)(l31 + 4 * h * N);
-    const float* __restrict__ p_in = g.p_in + t_base;
     float* __restrict__ t_out = g.t_out + t_base;
     if (!BWD) {
         float mx = -INFINITY;
@@ -395,41 +420,29 @@ __global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args 
 #pragma unroll
             for (int v = 0; v < 16; ++v) sacc[jt][v] *= inv;
     } else {
-        // two sweeps over the saved P (the second one is served by L2 / MALL): holding it beside the accumulators would need 256 + 128
-        // live registers per lane and spill
-        float dot = 0.f;
+        // delta_i = sum_j P[j][i] dP[j][i] = sum_c do[c][i] o[c][i]  (o = v P): gathered while do was staged, so P is read ONCE
+        float* __restrict__ dsum = reinterpret_cast<float*>(lds);
+        dsum[tid] = dpart;                               // (column bi, octet half bo): the phase-1 buffers are free after its last barrier
+        __syncthreads();
+        const float delta = dsum[32 * wave + l31] + dsum[128 + 32 * wave + l31];
+        const float* __restrict__ p_in = g.p_in + t_base;
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                dot += p_in[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] * sacc[jt][v];
-            }
-            asm volatile("" ::: "memory");               // at most one tile's 16 loads in flight: all 128 hoisted cost 128 registers and spill
-        }
-        dot += __shfl_xor(dot, 32, 64);
-        asm volatile("" ::: "memory");                   // really load P again: common-subexpression elimination would keep all 128 values live
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                sacc[jt][v] = g.scale * p_in[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] * (sacc[jt][v] - dot);
-            }
-            asm volatile("" ::: "memory");
+            for (int v = 0; v < 16; ++v)
+                sacc[jt][v] = g.scale * p_in[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] * (sacc[jt][v] - delta);
+            asm volatile("" ::: "memory");               // one tile's 16 loads in flight at a time: 128 hoisted loads cost 128 registers
         }
     }
-    if (g.t_out) {
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                t_out[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] = sacc[jt][v];
-            }
-    }
-
-    // T as the phase-2 B operand: bf16 (hi, lo) k-fragments, made once (the f32 tile dies as its halves are made)
+    // T leaves for HBM (P for the backward pass / dS for the dk product) and becomes the phase-2 B operand: bf16 (hi, lo) k-fragments,
+    // made once, tile by tile (the f32 tile dies as its halves are made)
     u32x4_t thi[JT][2], tlo[JT][2];
 #pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
+    for (int jt = 0; jt < JT; ++jt) {
+        if (g.t_out) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) t_out[t_lane + (unsigned)((32 * jt + (v & 3) + 8 * (v >> 2)) * N)] = sacc[jt][v];
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float tv[8];
@@ -437,12 +450,13 @@ __global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args 
             for (int e = 0; e < 8; ++e) tv[e] = sacc[jt][8 * s2 + e];
             split8(tv, thi[jt][s2], tlo[jt][s2]);
         }
+    }
 
     // ---------------------------------------------------------------- phase 2
     // A2 item (row c, u = (k-step of the stage, lane half)): keys 32 st + 16 (u >> 1) + 4 (u & 1) + {0..3} and + 8 + {0..3}
     constexpr int ROWS = 32 * DT, ITEMS = (ROWS * 4 + 255) / 256;
     const int vu = tid & 3, vc = tid >> 2;               // row vc + 64 it
-    f32x4 rv[ITEMS][2];
+    f32x4 rv[2][ITEMS][2];
     const int npass = d / ROWS;
     for (int pass = 0; pass < npass; ++pass) {
         const float* __restrict__ A2p = A2 + (int64_t)(pass * ROWS) * N;
@@ -451,65 +465,63 @@ __global__ __launch_bounds__(256, 1) void attn_core_kernel(const attn_core_args 
         for (int ct = 0; ct < DT; ++ct)
 #pragma unroll
             for (int v = 0; v < 16; ++v) oacc[ct][v] = 0.f;
-        auto load2 = [&](int st) {
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int c = min(vc + 64 * it, ROWS - 1);
-                const float* __restrict__ src = A2p + (int64_t)c * N + 32 * st + 16 * (vu >> 1) + 4 * (vu & 1);
-                rv[it][0] = *reinterpret_cast<const f32x4*>(src);
-                rv[it][1] = *reinterpret_cast<const f32x4*>(src + 8);
-            }
-        };
-        auto store2 = [&](int buf) {
-            u32x4_t* __restrict__ Vs = lds + buf * BUF2;
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int c = vc + 64 * it;
-                if (c < ROWS) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = rv[it][0][e];
-                        v[4 + e] = rv[it][1][e];
-                    }
-                    u32x4_t hi, lo;
-                    split8(v, hi, lo);
-                    Vs[(0 * 4 + vu) * VPL + c] = hi;         // plane = part * 4 + kstep * 2 + h = part * 4 + u
-                    Vs[(1 * 4 + vu) * VPL + c] = lo;
-                }
-            }
-        };
         __syncthreads();                                 // every wave is done with the LDS of the previous phase / pass
-        load2(0);
-        store2(0);
-        __syncthreads();
 #pragma unroll
-        for (int st = 0; st < JT; ++st) {                // stage = 32 keys = accumulator tile st of phase 1 (static register indices)
-            const int buf = st & 1;
-            if (st + 1 < JT) load2(st + 1);
-            const u32x4_t* __restrict__ Vs = lds + buf * BUF2 + l31;
+        for (int st = -1; st < JT; ++st) {               // st = -1: prologue (loads of stages 0 and 1, LDS image of stage 0)
+            // loads two stages ahead into the register set that stage st + 1's image has just been made from (st >= 0) / the first two
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t bhf = __builtin_bit_cast(bf16x8_t, thi[st][s2]), blf = __builtin_bit_cast(bf16x8_t, tlo[st][s2]);
+            for (int pre = (st < 0 ? 0 : st + 2); pre <= (st < 0 ? 1 : st + 2); ++pre) {
+                if (pre < JT) {
 #pragma unroll
-                for (int ct = 0; ct < DT; ++ct) {
-                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, Vs[(0 * 4 + s2 * 2 + h) * VPL + 32 * ct]);
-                    const bf16x8_t al = __builtin_bit_cast(bf16x8_t, Vs[(1 * 4 + s2 * 2 + h) * VPL + 32 * ct]);
-                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhf, oacc[ct], 0, 0, 0);
-                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blf, oacc[ct], 0, 0, 0);
-                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhf, oacc[ct], 0, 0, 0);
+                    for (int it = 0; it < ITEMS; ++it) {
+                        const int c = min(vc + 64 * it, ROWS - 1);
+                        const float* __restrict__ src = A2p + (int64_t)c * N + 32 * pre + 16 * (vu >> 1) + 4 * (vu & 1);
+                        rv[pre & 1][it][0] = *reinterpret_cast<const f32x4*>(src);
+                        rv[pre & 1][it][1] = *reinterpret_cast<const f32x4*>(src + 8);
+                    }
                 }
             }
-            if (st + 1 < JT) store2(buf ^ 1);
+            if (st >= 0) {
+                const u32x4_t* __restrict__ Vs = lds + (st & 1) * BUF2 + l31;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t bhf = __builtin_bit_cast(bf16x8_t, thi[st][s2]), blf = __builtin_bit_cast(bf16x8_t, tlo[st][s2]);
+#pragma unroll
+                    for (int ct = 0; ct < DT; ++ct) {
+                        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, Vs[(0 * 4 + s2 * 2 + h) * VPL + 32 * ct]);
+                        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, Vs[(1 * 4 + s2 * 2 + h) * VPL + 32 * ct]);
+                        oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhf, oacc[ct], 0, 0, 0);
+                        oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blf, oacc[ct], 0, 0, 0);
+                        oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhf, oacc[ct], 0, 0, 0);
+                    }
+                }
+            }
+            if (st + 1 < JT) {                           // LDS image of stage st + 1 (its loads were issued a full stage ago)
+                u32x4_t* __restrict__ Vw = lds + ((st + 1) & 1) * BUF2;
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int c = vc + 64 * it;
+                    if (c < ROWS) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = rv[(st + 1) & 1][it][0][e];
+                            v[4 + e] = rv[(st + 1) & 1][it][1][e];
+                        }
+                        u32x4_t hi, lo;
+                        split8(v, hi, lo);
+                        Vw[(0 * 4 + vu) * VPL + c] = hi;         // plane = part * 4 + kstep * 2 + h = part * 4 + u
+                        Vw[(1 * 4 + vu) * VPL + c] = lo;
+                    }
+                }
+            }
             __syncthreads();
         }
         float* __restrict__ Yp = Yb + (int64_t)(pass * ROWS) * N + 32 * wave_u;
 #pragma unroll
         for (int ct = 0; ct < DT; ++ct)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                Yp[t_lane + (unsigned)((32 * ct + (v & 3) + 8 * (v >> 2)) * N)] = oacc[ct][v];
-            }
+            for (int v = 0; v < 16; ++v) Yp[t_lane + (unsigned)((32 * ct + (v & 3) + 8 * (v >> 2)) * N)] = oacc[ct][v];
     }
 }
 
@@ -584,6 +596,8 @@ extern "C" int vd_attn_core_fwd(const float* qkv, float* out, float* P, int B, i
     a.y = out;
     a.t_out = P;
     a.p_in = nullptr;
+    a.o_in = nullptr;
+    a.o_bs = 0;
     a.a1_bs = a.b1_bs = a.a2_bs = 3 * C * N;
     a.y_bs = C * N;
     a.heads = heads;
@@ -594,9 +608,9 @@ extern "C" int vd_attn_core_fwd(const float* qkv, float* out, float* P, int B, i
     return 0;
 }
 
-extern "C" int vd_attn_core_bwd(const float* qkv, const float* P, const float* dout, float* dS, float* dqkv, int B, int heads,
-                                int head_dim, int N, float scale, void* stream) {
-    VD_REQUIRE(qkv && P && dout && dS && dqkv, "vd_attn_core_bwd: null pointer");
+extern "C" int vd_attn_core_bwd(const float* qkv, const float* P, const float* out, const float* dout, float* dS, float* dqkv, int B,
+                                int heads, int head_dim, int N, float scale, void* stream) {
+    VD_REQUIRE(qkv && P && out && dout && dS && dqkv, "vd_attn_core_bwd: null pointer");
     VD_REQUIRE(attn_core_shape_ok(B, heads, head_dim, N), "vd_attn_core_bwd: needs N == 256 tokens and head_dim in {32, 64, 128, 256 k} "
                "(B=%d heads=%d head_dim=%d N=%d)", B, heads, head_dim, N);
     VD_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) == 0, "vd_attn_core_bwd: pointers must be 16-byte aligned");
@@ -608,6 +622,8 @@ extern "C" int vd_attn_core_bwd(const float* qkv, const float* P, const float* d
     a.y = dqkv;                  // the q slice of dqkv
     a.t_out = dS;
     a.p_in = P;
+    a.o_in = out;
+    a.o_bs = C * N;
     a.a1_bs = a.a2_bs = 3 * C * N;
     a.b1_bs = C * N;
     a.y_bs = 3 * C * N;

@@ -13,6 +13,7 @@
 // Reference ops replaced: F.conv2d 3x3/1x1 (ResnetBlock2D, Downsample2D, Upsample2D, conv_in/out), F.linear
 // (time embedding, attention projections), torch.bmm (attention) -- diffusers UNet2DModel reached from loss.py:993.
 #include "vd_common.h"
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
@@ -1327,11 +1328,11 @@ __global__ __launch_bounds__(NT, 3) void wgrad_patch_kernel(const vd_wgrad_desc 
 
 // Epilogue shared by the two patch weight-gradient kernels: split-K slab in the permuted layout, or dW directly.
 __device__ __forceinline__ void wgrad_patch_store(const vd_wgrad_desc& d, const f32x16 (&acc)[2][3], int r, int m0, int c0, int wm,
-                                                  int wc, int lane, int h, int by) {
+                                                  int wc, int lane, int h, int by, int nsplit) {
     const int Ncols = d.C * 9;
     const int c = c0 + wc * 32 + (lane & 31);
     if (c >= d.C) return;
-    if (gridDim.y > 1) {
+    if (nsplit > 1) {
         float* __restrict__ slab = d.ws + (int64_t)by * d.M * Ncols + (int64_t)r * d.M * d.C * 3;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -1515,7 +1516,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_gen_kernel(const vd_wgrad_d
             __syncthreads();
         }
     }
-    wgrad_patch_store(d, acc, r, m0, c0, wm, wc, lane, h, by);
+    wgrad_patch_store(d, acc, r, m0, c0, wm, wc, lane, h, by, gridDim.y);
 }
 
 
@@ -1952,10 +1953,16 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 7: rc = launch_smallm(d, st); break;
         case 8: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
-        case 9:
-            hipLaunchKernelGGL(gemm_bx3_kernel, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
+        case 9: {
+            const int ntiles = vd_cdiv(d.M, 128) * (d.N / 128);
+            static const int persist = getenv("VD_GEMM_BX3_PERSIST") ? atoi(getenv("VD_GEMM_BX3_PERSIST")) : 1;
+            if (persist && ntiles >= 1024)      // >= 2 tiles per resident workgroup: walk them with the loads of the next tile in flight
+                hipLaunchKernelGGL(gemm_bx3_persist_kernel, dim3(512), dim3(NT), 0, st, d, ntiles);
+            else
+                hipLaunchKernelGGL(gemm_bx3_kernel, dim3(ntiles), dim3(NT), 0, st, d);
             rc = 0;
             break;
+        }
         case 5: {
             const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
             if (d.a_mode == VD_A_ROW)
@@ -2156,6 +2163,121 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
             hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3(grid), dim3(256), 0, st, d.ws, d.dW, n, splits, d.accumulate);
         }
         VD_LAUNCH_CHECK("vd_conv_wgrad/reduce");
+    }
+    return 0;
+}
+
+// ---- grouped weight gradients -----------------------------------------------------------------------------------------------
+// Class of a split-precision weight gradient = the kernel instantiation it runs on; only jobs of one class share a launch.
+//   3x3: 4 * W + 2 * (CONV3_UP) + (wide image)   (W = 32 / 16 / 8 / 4),   1x1: 1000,   0: not groupable
+static int wgrad_group_class(const vd_wgrad_desc& d) {
+    if (d.math != 1 || d.splits != 0 || d.tile != 0) return 0;
+    if (wgrad1x1_bx3_eligible(d)) return 1000;
+    if (d.T != 9 || wgrad_patch_kind(d) != 4) return 0;
+    const int up = d.mode == VD_B_CONV3_UP ? 2 : 0;
+    if (d.OW >= 64) return 4 * 32 + up + 1;
+    return 4 * d.OW + up;
+}
+
+extern "C" int vd_conv_wgrad_group_class(const vd_wgrad_desc* desc) { return desc ? wgrad_group_class(*desc) : 0; }
+extern "C" int64_t vd_conv_wgrad_group_job_bytes(void) { return (int64_t)sizeof(vd_wgrad_job); }
+
+// Plan: fills the HOST image of the device job table (n * vd_conv_wgrad_group_job_bytes() bytes) with ws OFFSETS (floats) in d.ws,
+// so the image does not depend on where the workspace lives; vd_conv_wgrad_group_launch adds the base.  Every workgroup of the
+// grid gets about the same number of K-steps: sum_j tiles_j * ksteps_j / target.
+extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void* table_out, int64_t* ws_floats, int* blocks, int* rblocks) {
+    VD_REQUIRE(descs && n > 0 && table_out && ws_floats && blocks && rblocks, "vd_conv_wgrad_group_plan: bad args");
+    const int cls = wgrad_group_class(descs[0]);
+    VD_REQUIRE(cls != 0, "vd_conv_wgrad_group_plan: job 0 is not a split-precision (math = 1) 3x3 / 1x1 weight gradient");
+    vd_wgrad_job* jobs = reinterpret_cast<vd_wgrad_job*>(table_out);
+    const bool one = cls == 1000;
+    int64_t work = 0;
+    for (int j = 0; j < n; ++j) {
+        const vd_wgrad_desc& d = descs[j];
+        VD_REQUIRE(d.dY && d.X && d.dW && wgrad_group_class(d) == cls, "vd_conv_wgrad_group_plan: job %d is of another kernel class (%d vs %d)", j,
+                   wgrad_group_class(d), cls);
+        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
+        const int64_t ks = one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32);
+        work += base * ks;
+    }
+    static const int t3 = getenv("VD_WGRAD_GROUP_TARGET") ? atoi(getenv("VD_WGRAD_GROUP_TARGET")) : 768;
+    static const int t1 = getenv("VD_W1X1_GROUP_TARGET") ? atoi(getenv("VD_W1X1_GROUP_TARGET")) : 512;
+    const int target = one ? t1 : t3;
+    const int min_ks = one ? 4 : 8;
+    int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
+    if (per < min_ks) per = min_ks;
+    int64_t off = 0;
+    int blk = 0, rblk = 0;
+    for (int j = 0; j < n; ++j) {
+        vd_wgrad_job& jb = jobs[j];
+        memset(&jb, 0, sizeof(jb));
+        jb.d = descs[j];
+        const vd_wgrad_desc& d = descs[j];
+        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
+        const int ks = (int)(one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32));
+        int splits = (int)((ks + per - 1) / per);
+        if (splits < 1) splits = 1;
+        const int ks_per = vd_cdiv(ks, splits);
+        splits = vd_cdiv(ks, ks_per);
+        jb.gx = base;
+        jb.gy = splits;
+        jb.ks_per = ks_per;
+        jb.first_block = blk;
+        blk += (base * splits + 7) / 8 * 8;
+        const int64_t nel = (int64_t)d.M * d.C * d.T;
+        jb.first_rblock = rblk;
+        jb.rblocks = 0;
+        jb.d.ws = reinterpret_cast<float*>((uintptr_t)0);
+        if (splits > 1) {
+            jb.rblocks = (int)((nel + 255) / 256 < 1024 ? (nel + 255) / 256 : 1024);
+            jb.d.ws = reinterpret_cast<float*>((uintptr_t)(off * sizeof(float)));      // offset, rebased at launch
+            off += (int64_t)splits * nel;
+            off = (off + 3) / 4 * 4;
+        }
+        rblk += jb.rblocks;
+    }
+    *ws_floats = off;
+    *blocks = blk;
+    *rblocks = rblk;
+    return cls;
+}
+
+__global__ __launch_bounds__(64) void wgrad_group_rebase_kernel(vd_wgrad_job* __restrict__ jobs, int n, float* ws) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j < n && jobs[j].gy > 1) jobs[j].d.ws = ws + ((uintptr_t)jobs[j].d.ws) / sizeof(float);
+}
+
+// dev_table: the planned image copied to the device, ALREADY rebased onto ws (vd_conv_wgrad_group_rebase, once per upload).
+extern "C" int vd_conv_wgrad_group_rebase(void* dev_table, int n, float* ws, void* stream) {
+    VD_REQUIRE(dev_table && n > 0, "vd_conv_wgrad_group_rebase: bad args");
+    hipLaunchKernelGGL(wgrad_group_rebase_kernel, dim3(vd_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<vd_wgrad_job*>(dev_table), n, ws);
+    VD_LAUNCH_CHECK("vd_conv_wgrad_group_rebase");
+    return 0;
+}
+
+extern "C" int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls, int blocks, int rblocks, void* stream) {
+    VD_REQUIRE(dev_table && n > 0 && blocks > 0 && rblocks >= 0, "vd_conv_wgrad_group_launch: bad args");
+    const vd_wgrad_job* jobs = reinterpret_cast<const vd_wgrad_job*>(dev_table);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(blocks);
+    switch (cls) {
+        case 1000: hipLaunchKernelGGL(wgrad1x1_bx3_group_kernel, grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 32 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 0>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 32 + 2: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 2>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 32 + 1: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 0, true>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 32 + 3: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 2, true>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 16 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<16, 0>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 16 + 2: hipLaunchKernelGGL((wgrad_bx3_group_kernel<16, 2>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 8 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<8, 0>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 8 + 2: hipLaunchKernelGGL((wgrad_bx3_group_kernel<8, 2>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 4 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<4, 0>), grid, dim3(NT), 0, st, jobs, n); break;
+        default: vd_set_error("vd_conv_wgrad_group_launch: unknown kernel class %d", cls); return VD_EINVAL;
+    }
+    VD_LAUNCH_CHECK("vd_conv_wgrad_group_launch");
+    if (rblocks > 0) {
+        hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(rblocks), dim3(256), 0, st, jobs, n);
+        VD_LAUNCH_CHECK("vd_conv_wgrad_group_launch/reduce");
     }
     return 0;
 }

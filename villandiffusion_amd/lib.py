@@ -51,6 +51,11 @@ PROTOTYPES = {
     "vd_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "vd_conv_wgrad_plan": (_i32, [C.POINTER(WgradDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),
+    "vd_conv_wgrad_group_class": (_i32, [C.POINTER(WgradDesc)]),
+    "vd_conv_wgrad_group_job_bytes": (_i64, []),
+    "vd_conv_wgrad_group_plan": (_i32, [C.POINTER(WgradDesc), _i32, _vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)]),
+    "vd_conv_wgrad_group_rebase": (_i32, [_vp, _i32, _vp, _vp]),
+    "vd_conv_wgrad_group_launch": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),
     "vd_conv3_packed_bytes": (_i64, [_i32, _i32, _i32]),
     "vd_conv3_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_conv3_pack_weights_multi": (_i32, [_vp, _i32, _i64, _vp]),
@@ -69,7 +74,7 @@ PROTOTYPES = {
     "vd_attn_small_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i64, _i64, _vp]),
     "vd_attn_small_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i64, _i64, _i64, _vp]),
     "vd_attn_core_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
-    "vd_attn_core_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "vd_attn_core_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "vd_timestep_embedding": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_silu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "vd_silu_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -280,8 +280,7 @@ def linear_wgrad(dy, x, dw, accumulate=False):
                 accumulate=accumulate)
 
 
-def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, splits=0, tile=0, pad=0, math_mode=0):
-    """dw2d[M, C*T] (+)= sum_{b,p} dy[b,m,p] * gather_mode(x)[b, c, p(+)t]."""
+def wgrad_desc(dy, x, dw2d, mode, ws=None, accumulate=False, splits=0, tile=0, pad=0, math_mode=0) -> WgradDesc:
     Bn, M, OH, OW, dbs = _img(dy)
     Bx, Cc, H, W, xbs = _img(x)
     assert Bx == Bn
@@ -295,6 +294,57 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     d.dy_bstride, d.x_bstride = dbs, xbs
     d.pad = pad
     d.math = math_mode
+    return d
+
+
+def wgrad_group_class(d: WgradDesc) -> int:
+    """Kernel class of a split-precision weight gradient for the grouped launch (0: not groupable -> conv_wgrad)."""
+    return int(L.load().vd_conv_wgrad_group_class(C.byref(d)))
+
+
+_WG_CACHE, _WG_WS = {}, {}
+
+
+def conv_wgrad_group(descs: Sequence[WgradDesc], device):
+    """All `descs` (one kernel class, see wgrad_group_class) in ONE compute launch + ONE fixed-order slab reduction.  The device job
+    table is planned by the library and uploaded once per distinct set of operand addresses (steady-state training repeats them)."""
+    lib = _lib()
+    n = len(descs)
+    key = tuple((d.dY, d.X, d.dW, d.M, d.C, d.T, d.nb, d.NP, d.H, d.W, d.OH, d.OW, d.mode, d.accumulate, d.dy_bstride, d.x_bstride)
+                for d in descs)
+    ent = _WG_CACHE.get(key)
+    ws = _WG_WS.get(device)
+    if ent is None or ws is None or ent["ws_ptr"] != ws.data_ptr() or ent["ws_floats"] > ws.numel():
+        arr = (WgradDesc * n)(*descs)
+        jb = int(lib.vd_conv_wgrad_group_job_bytes())
+        host = (C.c_uint8 * (n * jb))()
+        wsf, blocks, rblocks = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        cls = lib.vd_conv_wgrad_group_plan(arr, n, host, C.byref(wsf), C.byref(blocks), C.byref(rblocks))
+        if cls <= 0:
+            raise L.VillanHipError(f"vd_conv_wgrad_group_plan: {lib.vd_last_error().decode()}")
+        if ws is None or ws.numel() < wsf.value:
+            ws = torch.empty(max(int(wsf.value), 1 << 22), device=device, dtype=torch.float32)
+            _WG_WS[device] = ws
+        table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+        L.check(lib.vd_conv_wgrad_group_rebase(table.data_ptr(), n, ws.data_ptr(), _s()), "vd_conv_wgrad_group_rebase")
+        if len(_WG_CACHE) > 256:
+            _WG_CACHE.clear()
+        ent = _WG_CACHE[key] = {"table": table, "cls": cls, "blocks": blocks.value, "rblocks": rblocks.value, "ws_ptr": ws.data_ptr(),
+                                "ws_floats": int(wsf.value)}
+    flops = sum(2.0 * d.M * d.C * d.T * d.nb * d.NP for d in descs)
+    nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
+    name = (f"wgrad1x1_bx3_group_kernel(+group_reduce)" if ent["cls"] == 1000 else
+            f"wgrad_bx3_group_kernel<{ent['cls'] // 4}, {ent['cls'] & 2}{', wide' if ent['cls'] & 1 else ''}>(+group_reduce)")
+    _timed(name, flops, "mfma", lambda: L.check(
+        lib.vd_conv_wgrad_group_launch(ent["table"].data_ptr(), n, ent["cls"], ent["blocks"], ent["rblocks"], _s()), "vd_conv_wgrad_group_launch"),
+        nbytes=nbytes)
+
+
+def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, splits=0, tile=0, pad=0, math_mode=0):
+    """dw2d[M, C*T] (+)= sum_{b,p} dy[b,m,p] * gather_mode(x)[b, c, p(+)t]."""
+    d = wgrad_desc(dy, x, dw2d, mode, ws, accumulate, splits, tile, pad, math_mode)
+    Bn, M, OH, OW = dy.shape
+    Cc, T = x.shape[1], d.T
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_floats(C.byref(d))
     if need > 0:
@@ -458,14 +508,14 @@ def attn_core_fwd(qkv, out, P, heads, head_dim, N, scale):
     return out
 
 
-def attn_core_bwd(qkv, P, dout, dS, dqkv, heads, head_dim, N, scale):
-    """dS (into `dS`, [B, heads, N, N]) and dq (into dqkv[:, :C]) of the fused attention core."""
+def attn_core_bwd(qkv, P, out, dout, dS, dqkv, heads, head_dim, N, scale):
+    """dS (into `dS`, [B, heads, N, N]) and dq (into dqkv[:, :C]) of the fused attention core; `out` = the saved forward output."""
     Bn = qkv.shape[0]
-    assert qkv.is_contiguous() and P.is_contiguous() and dout.is_contiguous() and dS.is_contiguous() and dqkv.is_contiguous()
+    assert qkv.is_contiguous() and P.is_contiguous() and dout.is_contiguous() and dS.is_contiguous() and dqkv.is_contiguous() and out.is_contiguous()
     dt = 8 if head_dim % 256 == 0 else head_dim // 32
     _timed(f"attn_core_kernel<{dt}, true>", 4.0 * Bn * heads * N * N * head_dim, "mfma", lambda: L.check(
-        _lib().vd_attn_core_bwd(_p(qkv), _p(P), _p(dout), _p(dS), _p(dqkv), Bn, heads, head_dim, N, scale, _s()), "vd_attn_core_bwd"),
-        nbytes=4.0 * (qkv.numel() * 2 // 3 + dout.numel() + 2 * P.numel() + dS.numel() + qkv.numel() // 3))
+        _lib().vd_attn_core_bwd(_p(qkv), _p(P), _p(out), _p(dout), _p(dS), _p(dqkv), Bn, heads, head_dim, N, scale, _s()), "vd_attn_core_bwd"),
+        nbytes=4.0 * (qkv.numel() * 2 // 3 + 2 * dout.numel() + P.numel() + dS.numel() + qkv.numel() // 3))
     return dqkv
 
 

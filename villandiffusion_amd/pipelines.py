@@ -38,7 +38,7 @@ class GraphedForward:
     (the ~250 launches of a denoising step are 5-20 us kernels at the 4x4 / 8x8 stages; eager launch leaves the GPU idle
     between them once the host falls behind).  The graph reads the network's own parameter / packed-operand buffers, so it stays
     valid across optimiser steps; the split-precision operands are refreshed (outside the graph) when the weights have changed.
-    Inputs are copied into static buffers; the returned tensor is the graph's static output (valid until the next call)."""
+    Inputs are copied into static buffers, the output out of one."""
 
     def __init__(self, unet, batch, dtype=torch.float32):
         dev = unet.device
@@ -72,7 +72,7 @@ class GraphedForward:
         self.x.copy_(x)
         self.t.copy_(t)
         self.graph.replay()
-        return self.out
+        return self.out.clone()          # multistep samplers keep model outputs across steps: never hand out the static buffer itself
 
 
 def sampler_forward(unet, batch):

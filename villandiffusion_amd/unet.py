@@ -164,8 +164,7 @@ class _Conv:
         net = self.net
         bx3 = getattr(net, "conv_math", "f32") == "bf16x3" and ops.wgrad_bx3_eligible(self.cout, self.cin, dout.shape[2], dout.shape[3],
                                                                                        self.mode) and x.stride(0) % 4 == 0
-        ops.conv_wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, net.wgrad_ws,
-                       accumulate=True, pad=self.pad, math_mode=int(bx3))
+        net.wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=int(bx3))
         if not skip_bias:
             B = dout.shape[0]
             ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
@@ -303,8 +302,8 @@ class _Resnet:
         self.conv1.bwd(dh1, a1, da1, bias_ws=dt)
         if self.has_sc:
             wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
-            ops.conv_wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
-                           net.wgrad_ws, accumulate=True, math_mode=_wgrad1x1_math(net, dout, x))
+            net.wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
+                      math_mode=_wgrad1x1_math(net, dout, x))
             net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout)
             dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
             HW = H * W
@@ -343,7 +342,7 @@ class _Attn:
         ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", False, 3 * Cc, Cc, N, B))
         o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
-        if net.conv_math == "bf16x3" and net.fused_attention and ops.attn_core_eligible(nh, dh, N):
+        if getattr(net, "conv_math", "f32") == "bf16x3" and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
             # one launch: scores and probabilities stay in registers; P reaches HBM only when a backward pass will read it
             P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32) if save else None
             ops.attn_core_fwd(qkv, o, P, nh, dh, N, self.scale)
@@ -388,8 +387,7 @@ class _Attn:
         N = H * W
         dev = x.device
         wo = net.P[self.prefix + ".to_out.0.weight"]
-        ops.conv_wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, net.wgrad_ws, accumulate=True,
-                       math_mode=_wgrad1x1_math(net, dout, o))
+        net.wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, math_mode=_wgrad1x1_math(net, dout, o))
         bias_ws = net.scratch_bc(B, Cc)
         ops.rowsum(dout, bias_ws)
         net.colsum_later(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc)
@@ -398,10 +396,10 @@ class _Attn:
                  b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N, B))
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
-        if net.conv_math == "bf16x3" and net.fused_attention and ops.attn_core_eligible(nh, dh, N):
+        if getattr(net, "conv_math", "f32") == "bf16x3" and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
             # dP, the softmax gradient and dq in one launch (dP never reaches HBM); dv and dk are products of the saved P / of dS
             dS = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
-            ops.attn_core_bwd(qkv, P, do, dS, dqkv, nh, dh, N, self.scale)
+            ops.attn_core_bwd(qkv, P, o, do, dS, dqkv, nh, dh, N, self.scale)
             bs, hs, pbs, NN = 3 * Cc * N, dh * N, nh * N * N, N * N
             q = qkv[:, :Cc]
             dk, dv = dqkv[:, Cc:2 * Cc], dqkv[:, 2 * Cc:]
@@ -449,7 +447,7 @@ class _Attn:
             # dk[c][j] = sum_i q[c][i] dS[j][i]
             ops.gemm(q, dP, dk, M=Cc, N=B * N, K=N, a_mode=A_ROW, b_mode=B_KCONTIG, NP=N, lda=N, a_bstride=bs, ldb=N,
                      b_bstride=N * N, ldd=N, d_bstride=bs, math_mode=_amath(net, Cc, N, N))
-        ops.conv_wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, net.wgrad_ws, accumulate=True, math_mode=_wgrad1x1_math(net, dqkv, g))
+        net.wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, math_mode=_wgrad1x1_math(net, dqkv, g))
         ws3 = net.scratch_bc(B, 3 * Cc)
         ops.rowsum(dqkv, ws3)
         net.colsum_later(ws3, net.Gq[self.qkv_b], B, 3 * Cc)
@@ -663,6 +661,9 @@ class UNet2DModel(nn.Module):
         self.fused_attention = os.environ.get("VILLAN_FUSED_ATTENTION", "1") != "0"
         # sampler loops replay the no-grad forward from a HIP graph captured once per batch shape (pipelines.GraphedForward)
         self.sampler_graph = os.environ.get("VILLAN_SAMPLER_GRAPH", "1") != "0"
+        # weight gradients of a gradient bucket run as grouped launches (see wgrad()); False: one launch pair per convolution
+        self.group_wgrad = os.environ.get("VILLAN_GROUP_WGRAD", "1") != "0"
+        self._wg_jobs: Dict[int, list] = {}
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
@@ -760,7 +761,28 @@ class UNet2DModel(nn.Module):
         for c0 in range(0, Cc, 64):
             self._cs_jobs.append((wp + 4 * c0, op + 4 * c0, min(64, Cc - c0), ld))
 
+    # ---- weight gradients: deferred and launched GROUPED per kernel class (ops.conv_wgrad_group) ----
+    # A weight gradient has a small output and a reduction over batch * pixels: launched alone it must split that reduction ~32 ways
+    # to fill the chip and moves 32 partial copies of dW through memory.  The gradients of one bucket are independent of each other
+    # and off the critical path of the backward pass, so they are queued (operands kept alive) and run as a few grouped launches when
+    # the bucket is final.
+    def wgrad(self, dy, x, dw2d, mode, pad=0, math_mode=0):
+        if math_mode == 1 and self.group_wgrad:
+            d = ops.wgrad_desc(dy, x, dw2d, mode, None, accumulate=True, pad=pad, math_mode=1)
+            cls = ops.wgrad_group_class(d)
+            if cls:
+                self._wg_jobs.setdefault(cls, []).append((d, dy, x))
+                return
+        ops.conv_wgrad(dy, x, dw2d, mode, self.wgrad_ws, accumulate=True, pad=pad, math_mode=math_mode)
+
+    def _wg_flush(self):
+        for cls, jobs in self._wg_jobs.items():
+            if jobs:
+                ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
+        self._wg_jobs = {}
+
     def _cs_flush(self):
+        self._wg_flush()
         jobs = self._cs_jobs
         if not jobs:
             return
