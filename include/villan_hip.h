@@ -110,7 +110,8 @@ int vd_gemm(const vd_gemm_desc* desc, void* stream);
 int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
 /* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4 / 6: patch-staged 3x3
  * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel, 7: direct 3x3 convolution for <= 4 output
- * channels, 8 / 9 / 10: split-precision bf16 3x3 convolution / plain product (a_packed) / activation product (math = 1), -1: a_packed given for an unsupported problem (profiling / tests). */
+ * channels, 8 / 9 / 10: split-precision bf16 3x3 convolution / plain product (a_packed) / activation product (math = 1), 11: the persistent
+ * variant of 9 (grids of >= 1024 tiles), -1: a_packed given for an unsupported problem (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):

@@ -426,3 +426,16 @@ def test_scheduler_variance_and_prediction_types(tmp_path):
     json.dump(cfg, open(cfgp, "w"))
     with pytest.raises(NotImplementedError):
         DDPMPipeline.from_pretrained(str(tmp_path / "ck"))
+
+
+def test_metrics_agree_with_the_oracle_restatement():
+    """villandiffusion_amd/metrics.py (one grouped convolution) vs oracle/metrics_ref.py (numpy loops): MSE / SSIM of the measure pipeline."""
+    from oracle.metrics_ref import mse_ref, ssim_ref
+    from villandiffusion_amd.metrics import mse_batch, ssim_batch
+    rng = np.random.default_rng(3)
+    for shape in ((5, 3, 32, 32), (2, 1, 40, 28), (3, 3, 16, 16)):
+        a = rng.random(shape).astype(np.float32)
+        b = np.clip(a + 0.2 * rng.standard_normal(shape).astype(np.float32), 0, 1)
+        assert abs(mse_batch(torch.from_numpy(a), torch.from_numpy(b)) - mse_ref(a, b)) < 1e-7
+        assert abs(ssim_batch(torch.from_numpy(a), torch.from_numpy(b)) - ssim_ref(a, b)) < 1e-5
+    assert abs(ssim_ref(a, a) - 1.0) < 1e-12

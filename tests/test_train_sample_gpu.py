@@ -197,6 +197,33 @@ def test_cli_train_and_sampling_end_to_end(tmp_path):
     assert set(sc) == {"FID_noclip_DDIM-SCHED-4_16", "MSE_noclip_DDIM-SCHED-4_16", "SSIM_noclip_DDIM-SCHED-4_16"}
     assert sc["FID_noclip_DDIM-SCHED-4_16"] is None and 0 <= sc["MSE_noclip_DDIM-SCHED-4_16"] <= 1 and -1 <= sc["SSIM_noclip_DDIM-SCHED-4_16"] <= 1
     assert len(os.listdir(os.path.join(run, "backdoor_noclip_DDIM-SCHED-4_16"))) == 16
+    # ... and the scores themselves are held to the ORACLE: the same 16 backdoor samples (checkpoint weights, seeded CPU noise + trigger,
+    # 4 DDIM steps in chunks of --eval_max_batch) from the CPU UNet and sampler, quantised to 8 bits like the saved PNGs, scored by
+    # oracle/metrics_ref.py (VillanDiffusion.py:1050-1091)
+    from safetensors.torch import load_file
+    from oracle.metrics_ref import mse_ref, ssim_ref
+    from villandiffusion_amd.dataset import Backdoor
+    ref = UNet2DModelRef()
+    ref.load_state_dict(load_file(os.path.join(run, "unet", "diffusion_pytorch_model.safetensors")))
+    bd = Backdoor(root=ROOT)
+    trig = bd.get_trigger("BOX_14", 3, 32, -1.0, 1.0)
+    tgt01 = (bd.get_target("HAT", trig, vmin=-1.0, vmax=1.0) / 2 + 0.5).clamp(0, 1)
+    noise = torch.randn((16, 3, 32, 32), generator=torch.Generator().manual_seed(0)) + trig[None]
+    outs = []
+    with torch.no_grad():
+        for c in torch.split(noise, 4):
+            x = R.sample_loop(ref, R.DDIMSchedulerRef(clip_sample=False), c.clone(), 4)
+            outs.append(((x / 2 + 0.5).clamp(0, 1) * 255).round() / 255)
+    gen_ref = torch.cat(outs).numpy()
+    tg = tgt01[None].expand(16, -1, -1, -1).numpy()
+    mse_o, ssim_o = mse_ref(gen_ref, tg), ssim_ref(gen_ref, tg)
+    print(f"[parity] measure: MSE {sc['MSE_noclip_DDIM-SCHED-4_16']:.6f} (oracle {mse_o:.6f}), SSIM {sc['SSIM_noclip_DDIM-SCHED-4_16']:.6f} (oracle {ssim_o:.6f})")
+    assert abs(sc["MSE_noclip_DDIM-SCHED-4_16"] - mse_o) <= 1e-4 + 1e-3 * mse_o         # 8-bit quantisation: a pixel at a rounding boundary may flip by 1/255
+    assert abs(sc["SSIM_noclip_DDIM-SCHED-4_16"] - ssim_o) <= 2e-3
+    from PIL import Image
+    png = np.stack([np.asarray(Image.open(os.path.join(run, "backdoor_noclip_DDIM-SCHED-4_16", f"{i}.png")).convert("RGB")) for i in range(16)])
+    diff = np.abs(png.astype(np.int32) - (gen_ref * 255).round().astype(np.int32).transpose(0, 2, 3, 1))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01                       # the saved images ARE the oracle's, up to rounding-boundary pixels
     # the same for a denoise task: MSE / SSIM of the recovered images (reference measure_inpaints; LPIPS needs AlexNet weights)
     argv5 = ["--mode", "measure", "--ckpt", run, "--sched", "DDIM-SCHED", "--infer_steps", "10", "--infer_start", "6", "--eval_max_batch", "4",
              "--task", "poisoned_denoise"]

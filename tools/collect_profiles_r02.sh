@@ -25,6 +25,12 @@ if [ -z "${SKIP_PMC:-}" ]; then
   python3 tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma.json
   rm -rf $O/pmc_mfma
 fi
+python3 tools/shape_probe.py > $O/shape_probe.txt 2>&1
+if [ -z "${SKIP_PMC:-}" ]; then
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_wait -- python3 bench.py --mode train --steps 3 --warmup 2 --no-cpu --no-roofline > /dev/null 2> $O/pmc_wait.err
+  python3 tools/pmc_summary.py $O/pmc_wait > $O/pmc_wait.json
+  rm -rf $O/pmc_wait
+fi
 tail -1 $O/bench_default.json | cut -c1-600
 head -8 $O/train_kernel_stats.csv | cut -c1-160
 head -8 $O/sample_kernel_stats.csv | cut -c1-160

@@ -1904,7 +1904,13 @@ extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
 extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
-    if (d.a_packed) return bx3_eligible(d) ? 8 : (gemm_bx3_eligible(d) ? 9 : -1);
+    if (d.a_packed) {
+        if (bx3_eligible(d)) return 8;
+        if (!gemm_bx3_eligible(d)) return -1;
+        // >= 2 tiles per resident workgroup (512 slots): the persistent variant walks them with the next tile's loads in flight
+        static const int persist = getenv("VD_GEMM_BX3_PERSIST") ? atoi(getenv("VD_GEMM_BX3_PERSIST")) : 1;
+        return (persist && vd_cdiv(d.M, 128) * (d.N / 128) >= 1024) ? 11 : 9;
+    }
     if (d.math == 1) return gemm_bx3_act_eligible(d) ? 10 : -1;
     if (smallm_eligible(d)) return 7;                        // direct convolution for <= 4 output channels
     if (patch_eligible(d)) {
@@ -1953,16 +1959,14 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 7: rc = launch_smallm(d, st); break;
         case 8: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
-        case 9: {
-            const int ntiles = vd_cdiv(d.M, 128) * (d.N / 128);
-            static const int persist = getenv("VD_GEMM_BX3_PERSIST") ? atoi(getenv("VD_GEMM_BX3_PERSIST")) : 1;
-            if (persist && ntiles >= 1024)      // >= 2 tiles per resident workgroup: walk them with the loads of the next tile in flight
-                hipLaunchKernelGGL(gemm_bx3_persist_kernel, dim3(512), dim3(NT), 0, st, d, ntiles);
-            else
-                hipLaunchKernelGGL(gemm_bx3_kernel, dim3(ntiles), dim3(NT), 0, st, d);
+        case 9:
+            hipLaunchKernelGGL(gemm_bx3_kernel, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
             rc = 0;
             break;
-        }
+        case 11:
+            hipLaunchKernelGGL(gemm_bx3_persist_kernel, dim3(512), dim3(NT), 0, st, d, vd_cdiv(d.M, 128) * (d.N / 128));
+            rc = 0;
+            break;
         case 5: {
             const int grid = vd_cdiv(d.M, 128) * (d.N / 128);
             if (d.a_mode == VD_A_ROW)
@@ -2200,11 +2204,19 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
         const int64_t ks = one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32);
         work += base * ks;
     }
+    // K-steps per workgroup: enough workgroups to fill the chip (768 / 512 slots), but no K range longer than `cap` steps: the tiles
+    // that share a K range (3 tap rows x C/64 for dY, x M/128 for X) run side by side on one XCD and re-read it through that XCD's
+    // L2 only while they stay within a few hundred K-steps of each other.  Measured on MI355X (config #2, B = 128): 3x3 at 32x32
+    // 1.93 -> 1.46 ms and at 16x16 1.71 -> 1.29 ms going from ~650 to 128 steps (32 pixels each) per workgroup; 1x1 (64-pixel steps) 1.0 -> 0.76 ms
+    // at 32 steps; still shorter ranges (more slabs) lose again.
     static const int t3 = getenv("VD_WGRAD_GROUP_TARGET") ? atoi(getenv("VD_WGRAD_GROUP_TARGET")) : 768;
     static const int t1 = getenv("VD_W1X1_GROUP_TARGET") ? atoi(getenv("VD_W1X1_GROUP_TARGET")) : 512;
+    static const int cap3 = getenv("VD_WGRAD_GROUP_KCAP") ? atoi(getenv("VD_WGRAD_GROUP_KCAP")) : 128;
+    static const int cap1 = getenv("VD_W1X1_GROUP_KCAP") ? atoi(getenv("VD_W1X1_GROUP_KCAP")) : 32;
     const int target = one ? t1 : t3;
     const int min_ks = one ? 4 : 8;
     int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
+    if (per > (one ? cap1 : cap3)) per = one ? cap1 : cap3;
     if (per < min_ks) per = min_ks;
     int64_t off = 0;
     int blk = 0, rblk = 0;
