@@ -44,6 +44,7 @@ def parse():
                     help="train: training legs only (no sampler) / sample: sampler only -- so that a rocprofv3 summary covers ONE dispatch population")
     ap.add_argument("--cpu-batch", type=int, default=128, help="batch of the CPU-oracle training baseline (SURVEY 8d: 128)")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-f32 leg (profiling runs: the summary then covers the default arithmetic only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-math", choices=("bf16x3", "f32"), default=None,
@@ -200,7 +201,7 @@ def main():
         log(f"train: {train_ips:.1f} img/s ({1e3 * dt / args.steps:.2f} ms/step), loss {final_loss:.4f}")
 
         # ---- the same K steps with every contraction on the exact-f32 MFMA (reported beside the headline, not as `value`) ----
-        if net.conv_math != "f32":
+        if net.conv_math != "f32" and not args.no_exact:
             mode0, net.conv_math = net.conv_math, "f32"
             for i in range(2):
                 one_step(i)
@@ -340,7 +341,7 @@ def main():
     def traffic_of(kname):      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
             with open(pmc_file) as f:
-                return json.load(f)["kernels"].get(kname, {}).get("traffic_bytes_per_launch")
+                return json.load(f)["kernels"].get(kname.split("(+")[0], {}).get("traffic_bytes_per_launch")
         except OSError:
             return None
 

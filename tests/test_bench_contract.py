@@ -1,52 +1,104 @@
-"""The bench line the driver parses (task contract ④): schema of the committed round-1 line + agreement between the HIP-event
-average of the roofline kernel and the committed rocprofv3 summary.  CPU only: reads profiles/, runs nothing."""
+"""The bench line the driver parses (task contract 4): schema of the committed round-2 line and agreement between its HIP-event numbers and
+the committed rocprofv3 summaries / PMC passes of the same commands.  CPU only: reads profiles/, runs nothing."""
 import csv
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
 
 
 def _line(name):
-    with open(os.path.join(ROOT, "profiles", name)) as f:
+    with open(os.path.join(P, name)) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
+def _norm(name):
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    return re.sub(r"\([^()]*\)$", "", name)
+
+
+def _stats(name):
+    with open(os.path.join(P, name)) as f:
+        return {_norm(r["Name"]): (int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in csv.DictReader(f)}
+
+
 def test_bench_line_schema():
-    d = _line("r01_bench_default.json")
+    d = _line("r02_bench_default.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] in ("bf16x3/f32", "f32")
     assert d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3           # whole-job throughput of K timed steps
-    r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["peak"] == (2500.0 if "bx3" in r["kernel"] else 157.3) and 0 < r["frac"] < 1
+    for key in ("roofline", "roofline_largest_flops"):
+        r = d[key]
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+        assert r["peak"] == (8000.0 if r["bound"] == "hbm" else (2500.0 if ("bx3" in r["kernel"] or "attn_core" in r["kernel"]) else 157.3))
+        assert "selection_rule" in r and r["launches_per_step"] >= 1 and r["avg_launch_us"] > 0
+    assert "TOTAL TIME" in d["roofline"]["selection_rule"] and "FLOPs" in d["roofline_largest_flops"]["selection_rule"]
+    # the dominant-by-time kernel really is the largest entry of the per-kernel table, and the table carries both rooflines per kernel
+    mf = [k for k in d["train_step_kernels"] if k["mfma_peak"]]
+    assert d["roofline"]["kernel"] == max(mf, key=lambda k: k["ms"])["kernel"]
+    assert d["roofline_largest_flops"]["kernel"] == max(mf, key=lambda k: k["gflop"])["kernel"]
+    for k in d["train_step_kernels"]:
+        assert k["frac"] == max(k["frac_mfma"], k["frac_hbm"]) and k["bound"] in ("hbm", "mfma")
+    hbm = {k["kernel"].split(" ")[0]: k for k in d["train_step_kernels"] if k["mfma_peak"] is None}
+    assert {"groupnorm_fwd", "groupnorm_bwd", "adam_step"} <= set(hbm)                   # HBM-bound families: bytes / us / 8 TB/s
+    assert all(0 < hbm[n]["frac_hbm"] < 1 for n in ("groupnorm_fwd", "groupnorm_bwd", "adam_step"))
     if d["dtype"] != "f32":                      # the exact-f32 arithmetic is timed in the same run, beside the headline
         assert d["exact_f32_mode"]["train_images_per_sec"] > 0 and d["exact_f32_mode"]["train_images_per_sec"] < d["value"]
+        assert not any(k.endswith("_frac_of_f32_peak") for k in d)                       # no fraction against the wrong peak
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "batch 128" in c["sample"] and c["unit"] == d["unit"]
+    assert d["sample_ddpm1000_images_per_sec"] > 0 and d["sample_eager_launches"]["images_per_sec"] > 0 and d["sample_hip_graph"] is True
 
 
-def test_roofline_kernel_agrees_with_rocprof_summary():
-    d = _line("r01_bench_under_rocprof.json")
-    name, avg_us = d["roofline"]["kernel"], d["roofline"]["avg_launch_us"]
-    with open(os.path.join(ROOT, "profiles", "r01_bench_kernel_stats.csv")) as f:
-        rows = [r for r in csv.DictReader(f) if name + "(" in r["Name"]]
-    assert len(rows) == 1, name
-    prof_us = float(rows[0]["AverageNs"]) / 1e3
-    # HIP-event average of the plain run (the bench line the driver parses) vs rocprofv3's own average for the same command: 5 %;
-    # the events recorded UNDER the profiler carry its per-launch overhead (~10 us on a 180 us kernel): 10 %
-    plain = _line("r01_bench_default.json")["roofline"]
-    assert plain["kernel"] == name and abs(prof_us - plain["avg_launch_us"]) / prof_us < 0.05, (prof_us, plain["avg_launch_us"])
-    assert abs(prof_us - avg_us) / prof_us < 0.10, (prof_us, avg_us)
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-        assert name in json.load(f)["kernels"]
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")) as f:
-        k = json.load(f)["kernels"][name]
-    # MFMA-busy counter == executed flops / peak (a split-precision kernel executes 3 bf16 MFMAs per algorithmic product term).
-    # The counter ratio is per CYCLE, the bench's fraction per SECOND against the 2.4 GHz peak: under the bf16 matrix load the chip
-    # clocks below 2.4 GHz (the kernel's GRBM cycles / 2.4 GHz is shorter than its measured duration), so convert with that ratio.
-    util_time = k["MfmaUtil"] * k["kernel_us_at_2.4GHz"] / prof_us
-    assert abs(util_time - d["roofline"].get("frac_executed", d["roofline"]["frac"])) < 0.03, (k["MfmaUtil"], util_time)
+def test_training_kernels_agree_with_the_training_only_rocprof_summary():
+    """HIP-event averages of the plain bench run vs rocprofv3 --kernel-trace --stats over `bench.py --mode train` (training dispatches only)."""
+    d = _line("r02_bench_default.json")
+    st = _stats("r02_train_kernel_stats.csv")
+    checked = 0
+    for k in d["train_step_kernels"]:
+        sym = k["kernel"].split("(+")[0]
+        if sym not in st or k["avg_us"] < 40 or "(+" in k["kernel"]:
+            continue                              # short kernels: the event pair's own overhead dominates; '(+x)': several symbols per call
+        prof_us = st[sym][1]
+        # the rocprof summary also covers the exact-f32 leg of the run for kernels both arithmetics use; the split-precision symbols are unique to it
+        if "bx3" in sym or "attn_core" in sym:
+            assert abs(prof_us - k["avg_us"]) / prof_us < 0.10, (sym, prof_us, k["avg_us"])
+            checked += 1
+    assert checked >= 6
+    r = d["roofline"]
+    assert r["kernel"].split("(+")[0] in st
+
+
+def test_pmc_tables_cover_the_roofline_kernels():
+    d = _line("r02_bench_default.json")
+    with open(os.path.join(P, "r02_pmc_traffic.json")) as f:
+        tr = json.load(f)["kernels"]
+    with open(os.path.join(P, "r02_pmc_mfma.json")) as f:
+        mf = json.load(f)["kernels"]
+    for key in ("roofline", "roofline_largest_flops"):
+        sym = d[key]["kernel"].split("(+")[0]
+        assert sym in tr and tr[sym]["traffic_bytes_per_launch"] > 0 and "hbm_gbs" in tr[sym], sym
+        assert d[key]["traffic"] == tr[sym]["traffic_bytes_per_launch"]
+    # MFMA-busy counter == executed flops / peak for an MFMA-bound kernel (a split-precision kernel executes 3 bf16 MFMAs per algorithmic
+    # product term).  The counter ratio is per CYCLE, the bench's fraction per SECOND against the 2.4 GHz peak: convert with the kernel's
+    # own cycles (GRBM) / measured duration.
+    k = next(k for k in d["train_step_kernels"] if k["kernel"] == "conv3_bx3_kernel<32, 1, 2>")
+    m = mf["conv3_bx3_kernel<32, 1, 2>"]
+    util_time = m["MfmaUtil"] * m["kernel_us_at_2.4GHz"] / m["avg_us"]
+    assert abs(util_time - k["frac_mfma_executed"]) < 0.04, (m["MfmaUtil"], util_time, k["frac_mfma_executed"])
+    # HBM-bound kernels now have a reproducible GB/s: bytes of the PMC pass / duration of the SAME dispatch population
+    for sym in ("gn_fwd_reg_kernel<4>", "gn_bwd_reg_kernel<4>", "adam_kernel"):
+        assert sym in tr and 0 < tr[sym]["hbm_gbs"] < 8000, (sym, tr.get(sym))
+
+
+def test_sampler_summary_is_sampler_only():
+    st = _stats("r02_sample_kernel_stats.csv")
+    assert not any("wgrad" in s or "gn_bwd" in s or "adam" in s for s in st)              # no training dispatches in the sampler's summary
+    assert any(s.startswith("conv3_bx3_kernel<32, 3, 2>") for s in st) and any(s.startswith("attn_core_kernel") for s in st)
+    assert not any(s.startswith("softmax_col") for s in st)                              # the fused attention core replaced the column softmax

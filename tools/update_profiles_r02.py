@@ -57,7 +57,7 @@ fp, wp = os.path.join(src, "pmc_FETCH_SIZE.json"), os.path.join(src, "pmc_WRITE_
 if os.path.exists(fp) and os.path.exists(wp):
     f, w = json.load(open(fp)), json.load(open(wp))
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --mode train --steps 3 "
-                   "--warmup 2 --no-cpu --no-roofline: two separate passes, training dispatches only (tools/collect_profiles_r02.sh), reduced to "
+                   "--warmup 2 --no-cpu --no-exact --no-roofline: two separate passes, training dispatches only (tools/collect_profiles_r02.sh), reduced to "
                    "per-dispatch averages by tools/pmc_summary.py (KB as rocprofv3 reports them).  traffic_bytes_per_launch = 2 * FETCH_SIZE + "
                    "WRITE_SIZE (gfx950 counts a 128-byte read request as 64 bytes: MI355X_MICROARCH.md, HBM).  avg_us = the same symbol's "
                    "average in r02_train_kernel_stats.csv (same command, --kernel-trace --stats).  hbm_gbs = traffic / avg_us; "
@@ -85,7 +85,7 @@ if os.path.exists(mp):
     d = json.load(open(mp))
     om = {"_how": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 "
                   "SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 bench.py --mode train --steps 3 --warmup 2 "
-                  "--no-cpu --no-roofline (its own pass, training dispatches only), per-dispatch averages.  executed GFLOP = 512 * (MOPS_F32 + "
+                  "--no-cpu --no-exact --no-roofline (its own pass, training dispatches only), per-dispatch averages.  executed GFLOP = 512 * (MOPS_F32 + "
                   "MOPS_BF16) / 1e9; a split-precision (bx3 / attn_core) kernel executes 3 bf16 MFMAs per algorithmic product term; "
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs, so MfmaUtil = MFMA_BUSY / (GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): the fraction of "
                   "matrix-pipe cycles busy, i.e. the EXECUTED-MFMA fraction per cycle.", "kernels": {}}
