@@ -634,6 +634,52 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
     check(dx, x.grad, BX3_TOL, f"bf16x3 dgrad {Cin}->{Cout}@{H}")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,mode", [(64, 128, 128, 32, B_CONV3), (40, 192, 200, 32, B_CONV3), (128, 256, 256, 16, B_CONV3), (72, 64, 256, 16, B_CONV3),
+                                               (64, 128, 128, 16, B_CONV3_UP), (128, 256, 128, 8, B_CONV3_UP)])
+def test_split_precision_conv3x3_on_unsplit_grids(B, Cin, Cout, H, mode):
+    """Full-size grids (>= 256 tiles of 128 channels x 128 pixels, no split-K): the shapes the training / sampling steps actually launch
+    at 16x16 / 32x32 -- forward with the fused epilogue, the GroupNorm-folded loader, and the stride-1 input gradient."""
+    x = torch.randn(B, Cin, H, H, generator=g(0), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)).requires_grad_()
+    b = torch.randn(Cout, generator=g(2))
+    temb = torch.randn(B, Cout, generator=g(3))
+    y0 = ref_conv(x, w, b, mode)
+    res = torch.randn(y0.shape, generator=g(4))
+    y_ref = y0 + temb[:, :, None, None] + res
+    OH = y_ref.shape[-1]
+    wd = w.detach().to(DEV).view(Cout, -1)
+    pk = ops.conv3_pack_weights(wd, Cout, Cin)
+    xd = x.detach().to(DEV)
+    out = torch.empty(B, Cout, OH, OH, device=DEV)
+    ops.conv3x3(xd, wd, b.to(DEV), out, mode=mode, rowadd=temb.to(DEV), rowadd_bstride=Cout, residual=res.to(DEV), a_packed=pk)
+    check(out, y_ref.detach(), BX3_TOL, f"bf16x3 conv (unsplit grid) mode={mode} {Cin}->{Cout}@{H} B={B}")
+    if mode == B_CONV3:
+        # GroupNorm + SiLU folded into the loader == the two-kernel sequence, bit for bit
+        gamma, beta = torch.rand(Cin, generator=g(5)) + 0.5, torch.randn(Cin, generator=g(6)) * 0.1
+        G = 32 if Cin % 32 == 0 else 8
+        a = torch.empty_like(xd)
+        mean, rstd = torch.empty(B * G, device=DEV), torch.empty(B * G, device=DEV)
+        ops.groupnorm_fwd(xd, gamma.to(DEV), beta.to(DEV), a, mean, rstd, G, 1e-6, True)
+        ss = torch.empty(B, Cin, 2, device=DEV)
+        ops.groupnorm_stats(xd, gamma.to(DEV), beta.to(DEV), ss, mean, rstd, G, 1e-6)
+        o3, o4 = torch.empty_like(out), torch.empty_like(out)
+        ops.conv3x3(xd, wd, b.to(DEV), o3, gn_ss=ss, a_packed=pk)
+        ops.conv3x3(a, wd, b.to(DEV), o4, a_packed=pk)
+        assert torch.equal(o3, o4), float((o3 - o4).abs().max())
+        if Cout % 16:
+            return                                              # the transposed operand needs 16-channel chunks of the OUTPUT side
+        dy = torch.randn(y0.shape, generator=g(7))
+        y0.backward(dy)
+        pkt = ops.conv3_pack_weights(wd, Cin, Cout, transposed=True)
+        wt = torch.empty(Cin, Cout * 9, device=DEV)
+        dx = torch.empty(B, Cin, H, H, device=DEV)
+        ops.conv3x3(dy.to(DEV), wt, None, dx, mode=B_CONV3_T, a_packed=pkt)
+        check(dx, x.grad, BX3_TOL, f"bf16x3 dgrad (unsplit grid) {Cin}->{Cout}@{H}")
+        dx2 = torch.empty_like(dx)                              # determinism: same launch, same bits
+        ops.conv3x3(dy.to(DEV), wt, None, dx2, mode=B_CONV3_T, a_packed=pkt)
+        assert torch.equal(dx, dx2)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H", [(32, 256, 256, 16), (128, 128, 256, 8), (40, 200, 128, 16), (128, 64, 64, 8)])
 def test_upsample_conv_input_gradient_with_the_2x2_sum_in_the_epilogue(B, Cin, Cout, H):
     """Upsample2D = nearest 2x + conv3x3; its input gradient is the stride-1 dgrad at the OUTPUT resolution followed by 2x2 block sums.
