@@ -169,7 +169,7 @@ class _Conv:
             B = dout.shape[0]
             ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
             if bias_ws is None:
-                ops.rowsum(dout, ws)
+                net.rowsum(dout, ws)
             net.colsum_later(ws, net.G[self.prefix + ".bias"], B, self.cout, ld=(ws.stride(0) if ws.dim() == 2 else self.cout))
         if dx is None:
             return None
@@ -290,14 +290,14 @@ class _Resnet:
         dev = x.device
         # conv2 (+ shortcut bias: both biases receive rowsum(dout))
         bias_ws = net.scratch_bc(B, self.cout)
-        ops.rowsum(dout, bias_ws)
+        net.rowsum(dout, bias_ws)
         da2 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
         self.conv2.bwd(dout, a2, da2, bias_ws=bias_ws)
         dh1 = torch.empty_like(da2)
         self.norm2.bwd(da2, h1, m2, r2, dh1)
         # temb projection gradient rows + conv1 bias share rowsum(dh1)
         dt = st.d_temb_all[:, self.temb_off:self.temb_off + self.cout]
-        ops.rowsum(dh1, dt, ws_ld=st.d_temb_all.stride(0))
+        net.rowsum(dh1, dt, ws_ld=st.d_temb_all.stride(0))
         da1 = da2 if self.cin == self.cout else torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
         self.conv1.bwd(dh1, a1, da1, bias_ws=dt)
         if self.has_sc:
@@ -389,7 +389,7 @@ class _Attn:
         wo = net.P[self.prefix + ".to_out.0.weight"]
         net.wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, math_mode=_wgrad1x1_math(net, dout, o))
         bias_ws = net.scratch_bc(B, Cc)
-        ops.rowsum(dout, bias_ws)
+        net.rowsum(dout, bias_ws)
         net.colsum_later(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc)
         do = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(wo, dout, do, M=Cc, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
@@ -449,7 +449,7 @@ class _Attn:
                      b_bstride=N * N, ldd=N, d_bstride=bs, math_mode=_amath(net, Cc, N, N))
         net.wgrad(dqkv, g, net.Gq[self.qkv_w], B_PLAIN, math_mode=_wgrad1x1_math(net, dqkv, g))
         ws3 = net.scratch_bc(B, 3 * Cc)
-        ops.rowsum(dqkv, ws3)
+        net.rowsum(dqkv, ws3)
         net.colsum_later(ws3, net.Gq[self.qkv_b], B, 3 * Cc)
         dg = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(net.Pq[self.qkv_w], dqkv, dg, M=Cc, N=B * N, K=3 * Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
@@ -664,6 +664,10 @@ class UNet2DModel(nn.Module):
         # weight gradients of a gradient bucket run as grouped launches (see wgrad()); False: one launch pair per convolution
         self.group_wgrad = os.environ.get("VILLAN_GROUP_WGRAD", "1") != "0"
         self._wg_jobs: Dict[int, list] = {}
+        # ... on a side stream, flushed every `wgrad_flush_jobs` queued convolutions (0: only when a gradient bucket completes)
+        self.wgrad_stream = os.environ.get("VILLAN_WGRAD_STREAM", "1") != "0"
+        self.wgrad_flush_jobs = int(os.environ.get("VILLAN_WGRAD_FLUSH_JOBS", "24"))
+        self._wg_side, self._wg_keep, self._rs_jobs = None, [], []
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
@@ -772,17 +776,54 @@ class UNet2DModel(nn.Module):
             cls = ops.wgrad_group_class(d)
             if cls:
                 self._wg_jobs.setdefault(cls, []).append((d, dy, x))
+                if self.wgrad_stream and self.wgrad_flush_jobs and sum(len(v) for v in self._wg_jobs.values()) >= self.wgrad_flush_jobs:
+                    self._wg_flush()
                 return
         ops.conv_wgrad(dy, x, dw2d, mode, self.wgrad_ws, accumulate=True, pad=pad, math_mode=math_mode)
 
+    def rowsum(self, x, ws, ws_ld=None):
+        """Bias-gradient partials ws[b][m] = sum_p x[b][m][p]: consumed only when the bucket is flushed, so with the side stream they
+        ride there too (x is a dY of a queued weight gradient or is kept referenced like one)."""
+        if self.wgrad_stream and self.group_wgrad:
+            self._rs_jobs.append((x, ws, ws_ld))
+        else:
+            ops.rowsum(x, ws, ws_ld=ws_ld)
+
     def _wg_flush(self):
-        for cls, jobs in self._wg_jobs.items():
-            if jobs:
-                ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
+        if not any(self._wg_jobs.values()) and not self._rs_jobs:
+            return
+        if self.wgrad_stream:
+            # Weight gradients are off the critical path of the backward pass: run the grouped launches on a SIDE stream so that they
+            # fill the tails of (and interleave with) the input-gradient / GroupNorm / 1x1 kernels of the layers still to come.
+            # Operands are kept referenced until the main stream has joined the side stream (_wg_join): the caching allocator
+            # orders reuse on the allocating stream only.
+            if self._wg_side is None:
+                self._wg_side = torch.cuda.Stream(device=self._dev)
+            main = torch.cuda.current_stream()
+            self._wg_side.wait_stream(main)
+            with torch.cuda.stream(self._wg_side):
+                for x, ws, ld in self._rs_jobs:
+                    ops.rowsum(x, ws, ws_ld=ld)
+                for cls, jobs in self._wg_jobs.items():
+                    if jobs:
+                        ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
+            self._wg_keep.append((self._wg_jobs, self._rs_jobs))
+            self._rs_jobs = []
+        else:
+            for cls, jobs in self._wg_jobs.items():
+                if jobs:
+                    ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
         self._wg_jobs = {}
+
+    def _wg_join(self):
+        """The main stream waits for the side-stream weight gradients (before anything reads the flat gradient)."""
+        if self._wg_keep:
+            torch.cuda.current_stream().wait_stream(self._wg_side)
+            self._wg_keep = []
 
     def _cs_flush(self):
         self._wg_flush()
+        self._wg_join()
         jobs = self._cs_jobs
         if not jobs:
             return
@@ -1051,8 +1092,8 @@ class UNet2DModel(nn.Module):
                 self._conv_in.bwd(g, rec[1], None)
             else:
                 raise RuntimeError(kind)
+        self._cs_flush()                                          # d_temb_all's partials may sit on the side stream
         if hook is not None:
-            self._cs_flush()
             hook(2)
         # ---- time embedding backward ----
         emb_sin, e1, e1a, emb, emb_act = st.temb_saved
