@@ -177,6 +177,7 @@ def main():
     do_train, do_sample = args.mode in ("all", "train"), args.mode in ("all", "sample") and args.sample_images > 0
     log(f"setup done (world={world}, B={B}, mode={args.mode}); warm-up {args.warmup} steps")
     train_ips = dt = final_loss = None
+    host_submit_ms = host_sync_ms = None
     exact = None
     if do_train:
         for i in range(args.warmup):
@@ -199,6 +200,17 @@ def main():
         train_ips = world * B * args.steps / dt
         final_loss = float(loss)
         log(f"train: {train_ips:.1f} img/s ({1e3 * dt / args.steps:.2f} ms/step), loss {final_loss:.4f}")
+        # host side of one step: time until the last launch of a step has been SUBMITTED (queue drained first) vs until it has run
+        sub = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            one_step(args.warmup + args.steps + i)
+            h1 = time.perf_counter()
+            torch.cuda.synchronize()
+            sub.append((h1 - h0, time.perf_counter() - h0))
+        host_submit_ms, host_sync_ms = 1e3 * min(a for a, _ in sub), 1e3 * min(b for _, b in sub)
+        log(f"host: one step submitted in {host_submit_ms:.2f} ms, finished in {host_sync_ms:.2f} ms (drained queue)")
 
         # ---- the same K steps with every contraction on the exact-f32 MFMA (reported beside the headline, not as `value`) ----
         if net.conv_math != "f32" and not args.no_exact:
@@ -398,6 +410,8 @@ def main():
             "train_tflops": None if train_ips is None else round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
             "sample_tflops": None if sample_ips is None else round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3, 2),
             "final_loss": None if final_loss is None else round(final_loss, 5),
+            "host_submit_ms_per_step": None if host_submit_ms is None else round(host_submit_ms, 3),
+            "host_drained_step_ms": None if host_sync_ms is None else round(host_sync_ms, 3),
             "roofline": roofline, "roofline_largest_flops": roofline_by_flops,
             "train_step_kernels": kernels, "sampler_step_kernels": sample_kernels, "cpu_baseline": cpu, "process_group": ranks_seen,
         }

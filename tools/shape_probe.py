@@ -1,7 +1,7 @@
 """Per-SHAPE timing (HIP events, 30 back-to-back launches) of the kernels of the config #2 training step that are launched at many
 shapes: the split-precision 1x1 convolutions (forward and input gradient), GroupNorm forward / backward and the fused attention core.
 Prints algorithmic TFLOP/s and GB/s (operands read once, result written once) so the binding roofline can be read per shape.
-    python tools/shape_probe.py [gemm] [gn] [attn]"""
+    python tools/shape_probe.py [gemm] [gn] [attn] [conv3]"""
 import math
 import os
 import sys
@@ -57,3 +57,22 @@ if "attn" in what:
                         ("bwd", lambda: ops.attn_core_bwd(qkv, P, o, do, dS, dqkv, heads, d, N, sc))):
             ms = timeit(fn, n=30)
             print(f"attn_core heads={heads} d={d:3d} {tag:11s}: {ms * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF")
+if "conv3" in what:
+    from villandiffusion_amd.lib import B_CONV3, B_CONV3_T
+    # (cin, cout, H): the 3x3 convolutions of the ResNet blocks (forward, and the flipped-tap input gradient with the roles of cin / cout swapped)
+    for cin, cout, H in [(128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (256, 256, 8), (512, 256, 8),
+                         (256, 256, 4), (512, 256, 4)]:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin * 9, device="cuda") / math.sqrt(cin * 9)
+        out = torch.empty(B, cout, H, H, device="cuda")
+        pk = ops.conv3_pack_weights(w, cout, cin)
+        ms = timeit(lambda: ops.conv3x3(x, w, None, out, mode=B_CONV3, a_packed=pk), n=30)
+        fl = 2.0 * cout * cin * 9 * B * H * H
+        line = f"conv3x3 {cin:4d}->{cout:4d} @{H:2d}^2: fwd {ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF"
+        if cout % 16 == 0:
+            pkt = ops.conv3_pack_weights(w, cin, cout, transposed=True)
+            dx = torch.empty_like(x)
+            wt = torch.empty(cin, cout * 9, device="cuda")                 # shape carrier: the kernel reads the packed operand
+            ms = timeit(lambda: ops.conv3x3(out, wt, None, dx, mode=B_CONV3_T, a_packed=pkt), n=30)
+            line += f" | dgrad {ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF"
+        print(line)

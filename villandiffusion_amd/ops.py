@@ -267,8 +267,27 @@ def linear_dgrad(dy, w, dx, accumulate=False):
     Bn, O = dy.shape
     I = w.shape[1]
     assert dy.is_contiguous() and dx.is_contiguous()
+    S = _long_k_slices(Bn, I, O)
+    if S > 1:
+        # a long reduction over few output tiles (the time-embedding projections of all ResNet blocks at once: K = 4992, 16 tiles):
+        # K slices run as the GEMM's batch dimension into [S][Bn][I] partials, summed in slice order by colsum (deterministic)
+        Kc = O // S
+        ws = _gemm_ws(S * Bn * I, dx.device)
+        gemm(dy, w, ws, M=Bn, N=S * I, K=Kc, NP=I, a_mode=A_ROW, b_mode=B_PLAIN, lda=O, a_bstride=Kc, ldb=w.stride(0),
+             b_bstride=Kc * w.stride(0), ldd=I, d_bstride=Bn * I)
+        return colsum(ws, dx, S, Bn * I, accumulate=accumulate)
     return gemm(dy, w, dx, M=Bn, N=I, K=O, a_mode=A_ROW, b_mode=B_PLAIN, lda=O, ldb=w.stride(0), ldd=I,
                 accumulate=accumulate)
+
+
+def _long_k_slices(M, N, K) -> int:
+    """Number of K slices for a plain product whose tile grid cannot fill the chip by itself (0/1 = do not slice)."""
+    if K < 2048 or N % 128 != 0 or ((M + 63) // 64) * (N // 64) >= 128:
+        return 1
+    for S in range(32, 1, -1):
+        if K % S == 0 and (K // S) % 4 == 0 and K // S >= 256:
+            return S
+    return 1
 
 
 def linear_wgrad(dy, x, dw, accumulate=False):
