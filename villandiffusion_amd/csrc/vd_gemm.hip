@@ -1905,7 +1905,12 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
     if (d.a_packed) {
-        if (bx3_eligible(d)) return 8;
+        if (bx3_eligible(d)) {
+            int splits, c_per;
+            bx3_plan(d, splits, c_per);
+            static const int big_off = getenv("VD_BX3_BIG_OFF") ? atoi(getenv("VD_BX3_BIG_OFF")) : 0;
+            return (!big_off && bx3_big_tile(d, splits)) ? 12 : 8;     // 12: the 128 x 256 tile, eight waves
+        }
         if (!gemm_bx3_eligible(d)) return -1;
         // >= 2 tiles per resident workgroup (512 slots): the persistent variant walks them with the next tile's loads in flight
         static const int persist = getenv("VD_GEMM_BX3_PERSIST") ? atoi(getenv("VD_GEMM_BX3_PERSIST")) : 1;
@@ -1945,7 +1950,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, "
                            "C %% 16 == 0, M >= 64, or a VD_B_PLAIN product with shared A, NP %% 128 == 0, K %% 16 == 0, M >= 64; "
                            "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 32, M >= 64");
-    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8,
+    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     VD_REQUIRE(!d.pool2 || tile == 8, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
     hipStream_t st = (hipStream_t)stream;
@@ -1957,7 +1962,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 4:
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
-        case 8: rc = launch_bx3(d, st); break;
+        case 8: case 12: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 9:
             hipLaunchKernelGGL(gemm_bx3_kernel, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
