@@ -1913,6 +1913,8 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
         }
         if (!gemm_bx3_eligible(d)) return -1;
         // >= 2 tiles per resident workgroup (512 slots): the persistent variant walks them with the next tile's loads in flight
+        static const int gbig_off = getenv("VD_GEMM_BX3_BIG_OFF") ? atoi(getenv("VD_GEMM_BX3_BIG_OFF")) : 0;
+        if (!gbig_off && gemm_bx3_big_tile(d)) return 13;       // 13: the 128 x 256 tile, eight waves
         static const int persist = getenv("VD_GEMM_BX3_PERSIST") ? atoi(getenv("VD_GEMM_BX3_PERSIST")) : 1;
         return (persist && vd_cdiv(d.M, 128) * (d.N / 128) >= 1024) ? 11 : 9;
     }
@@ -1964,8 +1966,12 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 7: rc = launch_smallm(d, st); break;
         case 8: case 12: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
+        case 13:
+            hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d);
+            rc = 0;
+            break;
         case 9:
-            hipLaunchKernelGGL(gemm_bx3_kernel, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
+            hipLaunchKernelGGL(gemm_bx3_kernel<256>, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
             rc = 0;
             break;
         case 11:
