@@ -88,8 +88,9 @@ def test_pmc_tables_cover_the_roofline_kernels():
     # MFMA-busy counter == executed flops / peak for an MFMA-bound kernel (a split-precision kernel executes 3 bf16 MFMAs per algorithmic
     # product term).  The counter ratio is per CYCLE, the bench's fraction per SECOND against the 2.4 GHz peak: convert with the kernel's
     # own cycles (GRBM) / measured duration.
-    k = next(k for k in d["train_step_kernels"] if k["kernel"] == "conv3_bx3_kernel<32, 1, 2>")
-    m = mf["conv3_bx3_kernel<32, 1, 2>"]
+    sym = "conv3_bx3_kernel<32, 1, 2, 512, 2>"            # stride-1 input gradient at 32x32, the 128 x 256 tile
+    k = next(k for k in d["train_step_kernels"] if k["kernel"] == sym)
+    m = mf[sym]
     util_time = m["MfmaUtil"] * m["kernel_us_at_2.4GHz"] / m["avg_us"]
     assert abs(util_time - k["frac_mfma_executed"]) < 0.04, (m["MfmaUtil"], util_time, k["frac_mfma_executed"])
     # HBM-bound kernels now have a reproducible GB/s: bytes of the PMC pass / duration of the SAME dispatch population
@@ -100,5 +101,5 @@ def test_pmc_tables_cover_the_roofline_kernels():
 def test_sampler_summary_is_sampler_only():
     st = _stats("r02_sample_kernel_stats.csv")
     assert not any("wgrad" in s or "gn_bwd" in s or "adam" in s for s in st)              # no training dispatches in the sampler's summary
-    assert any(s.startswith("conv3_bx3_kernel<32, 3, 2>") for s in st) and any(s.startswith("attn_core_kernel") for s in st)
+    assert any(s.startswith("conv3_bx3_kernel<32, 3, 2") for s in st) and any(s.startswith("attn_core_kernel") for s in st)
     assert not any(s.startswith("softmax_col") for s in st)                              # the fused attention core replaced the column softmax

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): round-2 evidence.  Every rocprofv3 summary covers ONE dispatch population:
-#   bench.py --mode train   -> r02_train_kernel_stats.csv  (+ the FETCH_SIZE / WRITE_SIZE / MFMA PMC passes, each its own run, --kernel-trace only)
+#   bench.py --mode train --serial-wgrad (weight gradients on the launch stream: every kernel's duration is its own)
+#                           -> r02_train_kernel_stats.csv  (+ the FETCH_SIZE / WRITE_SIZE / MFMA PMC passes, each its own run, --kernel-trace only)
 #   bench.py --mode sample  -> r02_sample_kernel_stats.csv
 # plus the default bench line.  Outputs under gpurun_out/r02p/; tools/update_profiles_r02.py copies the summaries into profiles/.
 set -u
@@ -8,7 +9,7 @@ O=gpurun_out/r02p
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 1200 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python3 bench.py --mode train --no-cpu --no-exact > $O/bench_train_under_rocprof.json 2> $O/stats_train.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python3 bench.py --mode train --serial-wgrad --no-cpu --no-exact > $O/bench_train_under_rocprof.json 2> $O/stats_train.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sample -- python3 bench.py --mode sample --no-cpu --sample-images 128 > $O/bench_sample_under_rocprof.json 2> $O/stats_sample.err
 for w in train sample; do
   f=$(find $O/stats_$w -name "*kernel_stats.csv" | head -1)
@@ -17,17 +18,19 @@ for w in train sample; do
 done
 if [ -z "${SKIP_PMC:-}" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 bench.py --mode train --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_$c.err
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_$c.err
     python3 tools/pmc_summary.py $O/pmc_$c > $O/pmc_$c.json
     rm -rf $O/pmc_$c
   done
-  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --mode train --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_mfma.err
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_mfma.err
   python3 tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma.json
   rm -rf $O/pmc_mfma
 fi
 python3 tools/shape_probe.py > $O/shape_probe.txt 2>&1
+# sustained matrix-pipe rates from registers / from LDS / with random operand bits (hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o build/mfma_peak)
+if [ -x build/mfma_peak ]; then timeout 120 build/mfma_peak > $O/mfma_sustained.txt 2>&1; fi
 if [ -z "${SKIP_PMC:-}" ]; then
-  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_wait -- python3 bench.py --mode train --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_wait.err
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_wait -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_wait.err
   python3 tools/pmc_summary.py $O/pmc_wait > $O/pmc_wait.json
   rm -rf $O/pmc_wait
 fi

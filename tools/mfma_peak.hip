@@ -47,6 +47,55 @@ __global__ __launch_bounds__(256) void mfma_bf16_loop(float* out, int iters, flo
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// The inner loop of the split-precision kernels without any staging: per "tap" NREAD conflict-free ds_read_b128 fragment reads feed 12 MFMAs
+// (2 x 2 accumulators x 3 products), 4 waves per workgroup.  What does the matrix pipe sustain when its operands arrive from LDS?
+template <int NREAD, bool RANDOM = false>
+__global__ __launch_bounds__(256, 2) void mfma_lds_loop(float* out, int iters) {
+    __shared__ u32x4 L[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        if (RANDOM) {                                              // random signs and mantissas, exponents around 1.0: the bit activity of real operands
+            unsigned x = (i + 1) * 2654435761u + blockIdx.x * 40503u;
+            u32x4 v;
+            for (int k = 0; k < 4; ++k) {
+                x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+                v[k] = (x & 0x80ff80ffu) | 0x3f003f00u;
+            }
+            L[i] = v;
+        } else {
+            L[i] = u32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        }
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 4; ++i)
+        for (int v = 0; v < 16; ++v) acc[i >> 1][i & 1][v] = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32x4* base = L + wave * 64 + lane;                      // 64 consecutive 16-byte units per read: conflict-free
+    bf16x8 f[8];
+    for (int j = 0; j < 8; ++j) f[j] = __builtin_bit_cast(bf16x8, base[256 * j]);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int j = 0; j < NREAD; ++j) f[j & 7] = __builtin_bit_cast(bf16x8, base[256 * (j & 7) + ((it + tap) & 7) * 2048 / 8]);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 + mi], f[4 + 2 * ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mi], f[5 + 2 * ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mi], f[4 + 2 * ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int v = 0; v < 16; ++v) s += acc[i >> 1][i & 1][v];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main() {
     float* out;
     hipMalloc(&out, 256 * 4096 * sizeof(float));
@@ -95,6 +144,26 @@ int main() {
         const double flops = (double)grid * 4 * iters * 4 * nacc * 32768.0;
         printf("bf16 32x32x16: %d accumulators round-robin, wgs/CU=%d  %.2f ms  %.1f TFLOP/s\n", nacc, wgs_per_cu, ms, flops / ms / 1e9);
     };
+    auto runl = [&](auto kern, int nread, int wgs_per_cu) {
+        const int grid = 256 * wgs_per_cu, iters = 20000;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, 10);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, iters);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)grid * 4 * iters * 9 * 12 * 32768.0;
+        printf("LDS-fed: %d ds_read_b128 per 12 MFMAs, wgs/CU=%d  %.2f ms  %.1f TFLOP/s\n", nread, wgs_per_cu, ms, flops / ms / 1e9);
+    };
+    for (int w = 1; w <= 2; ++w) {
+        runl(mfma_lds_loop<0>, 0, w);
+        runl(mfma_lds_loop<4>, 4, w);
+        runl(mfma_lds_loop<8>, 8, w);
+        printf("random operands: ");
+        runl(mfma_lds_loop<8, true>, 8, w);
+    }
     for (int w = 1; w <= 2; ++w) {
         run(mfma_bf16_loop<1>, 1, w);
         run(mfma_bf16_loop<2>, 2, w);

@@ -60,16 +60,16 @@ if "attn" in what:
 if "conv3" in what:
     from villandiffusion_amd.lib import B_CONV3, B_CONV3_T
     # (cin, cout, H): the 3x3 convolutions of the ResNet blocks (forward, and the flipped-tap input gradient with the roles of cin / cout swapped)
-    for cin, cout, H in [(128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (256, 256, 8), (512, 256, 8),
+    for cin, cout, H in [(128, 3, 32), (3, 128, 32), (128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (256, 256, 8), (512, 256, 8),
                          (256, 256, 4), (512, 256, 4)]:
         x = torch.randn(B, cin, H, H, device="cuda")
         w = torch.randn(cout, cin * 9, device="cuda") / math.sqrt(cin * 9)
         out = torch.empty(B, cout, H, H, device="cuda")
-        pk = ops.conv3_pack_weights(w, cout, cin)
+        pk = ops.conv3_pack_weights(w, cout, cin) if (cin % 16 == 0 and cout >= 64) else None      # conv_in / conv_out: exact-f32 kernels
         ms = timeit(lambda: ops.conv3x3(x, w, None, out, mode=B_CONV3, a_packed=pk), n=30)
         fl = 2.0 * cout * cin * 9 * B * H * H
         line = f"conv3x3 {cin:4d}->{cout:4d} @{H:2d}^2: fwd {ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF"
-        if cout % 16 == 0:
+        if cout % 16 == 0 and pk is not None:
             pkt = ops.conv3_pack_weights(w, cin, cout, transposed=True)
             dx = torch.empty_like(x)
             wt = torch.empty(cin, cout * 9, device="cuda")                 # shape carrier: the kernel reads the packed operand

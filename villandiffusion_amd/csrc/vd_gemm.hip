@@ -821,6 +821,94 @@ __global__ __launch_bounds__(256) void conv3_smallm_kernel(const vd_gemm_desc d)
         }
 }
 
+// The same convolution without LDS: a lane owns FOUR consecutive output pixels of a row for all (<= 4) output channels, the four waves of a
+// workgroup split the input channels and their partial sums meet in LDS at the end.  Per channel a lane loads three rows of (1 + 4 + 1)
+// pixels straight from global memory (the float4 is aligned; the two edge pixels hit the lines the neighbouring lanes fetch) and the 27
+// weights arrive as scalar loads (wave-uniform address): 9 loads feed 36 * M FMAs, against 18 LDS reads per 9 * M FMAs in the kernel
+// above, which is LDS-issue bound (85 us at B = 128 for a 17 us read of the input).  W % 4 == 0.
+template <int MM>
+__global__ __launch_bounds__(256) void conv3_fewout_kernel(const vd_gemm_desc d, int64_t quads) {
+    __shared__ float red[3][MM][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = d.W, H = d.H, W4 = W >> 2, HWs = H * W;
+    const int64_t gq = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = gq < quads;
+    const int64_t g = live ? gq : 0;
+    const int x4 = (int)(g % W4);
+    const int64_t rest = g / W4;
+    const int y = (int)(rest % H), b = (int)(rest / H);
+    const float* __restrict__ xb = d.B + (int64_t)b * d.b_bstride + y * W + 4 * x4;
+    const bool rowok[3] = {y > 0, true, y < H - 1};
+    const bool lf = x4 > 0, rt = x4 < W4 - 1;
+    int roff[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) roff[r] = rowok[r] ? (r - 1) * W : 0;
+    float acc[MM][4];
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+    const int cper = (d.C + 3) / 4;
+    const int c_begin = wave * cper, c_end = min(d.C, c_begin + cper);
+    const float* __restrict__ Wp = d.A;
+#pragma unroll 2
+    for (int c = c_begin; c < c_end; ++c) {
+        const float* __restrict__ p = xb + (int64_t)c * HWs;
+        float e[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* __restrict__ q = p + roff[r];
+            const f32x4 v = *reinterpret_cast<const f32x4*>(q);
+            const float l = q[lf ? -1 : 0], rr = q[rt ? 4 : 3];
+            e[r][0] = (rowok[r] && lf) ? l : 0.f;
+            e[r][5] = (rowok[r] && rt) ? rr : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[r][1 + j] = rowok[r] ? v[j] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if (m < d.M) {                                    // uniform
+                const float* __restrict__ wm = Wp + (int64_t)m * d.lda + (int64_t)c * 9;      // wave-uniform: scalar loads
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int q3 = 0; q3 < 3; ++q3) {
+                        const float w = wm[r * 3 + q3];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(w, e[r][q3 + j], acc[m][j]);
+                    }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave - 1][m][j][lane] = acc[m][j];
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if (m < d.M) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = ((acc[m][j] + red[0][m][j][lane]) + (red[1][m][j][lane] + red[2][m][j][lane])) * d.alpha;   // fixed order
+                    if (d.bias) v += d.bias[m];
+                    o[j] = v;
+                }
+                *reinterpret_cast<f32x4*>(d.D + (int64_t)b * d.d_bstride + (int64_t)m * d.ldd + y * W + 4 * x4) = o;
+            }
+        }
+    }
+}
+
+static bool fewout_eligible(const vd_gemm_desc& d) {
+    return d.W % 4 == 0 && d.C >= 16 && (d.b_bstride & 3) == 0 && (d.d_bstride & 3) == 0 && (d.ldd & 3) == 0 &&
+           ((((uintptr_t)d.B) | ((uintptr_t)d.D)) & 15) == 0 && (int64_t)d.H * d.W == d.NP;
+}
+
 static bool smallm_eligible(const vd_gemm_desc& d) {
     if (d.b_mode != VD_B_CONV3 || d.a_mode != VD_A_ROW || d.M > 4 || d.tile != 0 || d.debug != 0) return false;
     if (d.rowadd || d.residual || d.d_trans || d.accumulate || d.bias_on_n || d.nb2 > 1 || d.a_bstride != 0 || d.gn_ss) return false;
@@ -831,6 +919,12 @@ static bool smallm_eligible(const vd_gemm_desc& d) {
 
 static int launch_smallm(const vd_gemm_desc& d, hipStream_t st) {
     const int nb = d.N / d.NP;
+    static const int fewout_off = getenv("VD_FEWOUT_OFF") ? atoi(getenv("VD_FEWOUT_OFF")) : 0;
+    if (!fewout_off && fewout_eligible(d)) {
+        const int64_t quads = (int64_t)nb * d.H * (d.W / 4);
+        hipLaunchKernelGGL((conv3_fewout_kernel<4>), dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, d, quads);
+        return 0;
+    }
     if (d.W % 32 == 0) {
         dim3 grid((unsigned)(nb * (d.H / 8) * (d.W / 32)));
         hipLaunchKernelGGL((conv3_smallm_kernel<32, 4>), grid, dim3(256), 0, st, d);
