@@ -308,8 +308,10 @@ def main():
         return PEAK_BF16_MFMA_TFLOPS if ("bx3" in kname or "attn_core" in kname) else PEAK_F32_MFMA_TFLOPS
 
     def summarise(rec):
-        """Per kernel symbol: launches, summed event time, algorithmic TFLOP/s and GB/s, and the fraction of the BINDING roofline:
-        a kernel cannot beat min(MFMA peak, arithmetic intensity x HBM peak), so frac = max(frac of MFMA peak, frac of 8 TB/s)."""
+        """Per kernel symbol: launches, summed event time, algorithmic TFLOP/s and GB/s, and the fraction of the BINDING roofline.  Which
+        resource binds is decided on what the hardware does: the matrix pipe's occupancy is the EXECUTED MFMA work (three instructions per
+        split-precision product term) over the dtype's dense peak, HBM's is algorithmic bytes over 8 TB/s; `frac` is then quoted on
+        ALGORITHMIC work against that resource's peak (frac_mfma = algorithmic TFLOP/s / peak, frac_hbm = GB/s / 8000)."""
         agg = {}
         for r_ in rec:
             a = agg.setdefault(r_["name"], {"n": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "kind": r_["kind"]})
@@ -327,7 +329,9 @@ def main():
             rows.append({"kernel": k, "launches": v["n"], "ms": round(v["ms"], 3), "avg_us": round(1e3 * v["ms"] / v["n"], 1),
                          "tflops": round(tf, 2), "gbs": round(gbs, 1), "gflop": round(v["flops"] / 1e9, 1), "mbytes": round(v["bytes"] / 1e6, 1),
                          "frac_mfma": round(f_mfma, 4), "frac_mfma_executed": round((3 if split else 1) * f_mfma, 4), "frac_hbm": round(f_hbm, 4),
-                         "bound": "hbm" if f_hbm >= f_mfma else "mfma", "frac": round(max(f_mfma, f_hbm), 4), "mfma_peak": peak_of(k) if v["kind"] == "mfma" else None})
+                         "bound": "hbm" if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else "mfma",
+                         "frac": round(f_hbm if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else f_mfma, 4),
+                         "mfma_peak": peak_of(k) if v["kind"] == "mfma" else None})
         return sorted(rows, key=lambda r: -r["ms"])
 
     roofline, kernels, sample_kernels = None, None, None

@@ -43,8 +43,9 @@ def test_bench_line_schema():
     mf = [k for k in d["train_step_kernels"] if k["mfma_peak"]]
     assert d["roofline"]["kernel"] == max(mf, key=lambda k: k["ms"])["kernel"]
     assert d["roofline_largest_flops"]["kernel"] == max(mf, key=lambda k: k["gflop"])["kernel"]
-    for k in d["train_step_kernels"]:
-        assert k["frac"] == max(k["frac_mfma"], k["frac_hbm"]) and k["bound"] in ("hbm", "mfma")
+    for k in d["train_step_kernels"]:                    # binding resource: the matrix pipe by EXECUTED work (3 MFMAs per split-precision product) vs HBM
+        assert k["bound"] == ("hbm" if k["frac_hbm"] >= k["frac_mfma_executed"] else "mfma")
+        assert k["frac"] == (k["frac_hbm"] if k["bound"] == "hbm" else k["frac_mfma"])
     hbm = {k["kernel"].split(" ")[0]: k for k in d["train_step_kernels"] if k["mfma_peak"] is None}
     assert {"groupnorm_fwd", "groupnorm_bwd", "adam_step"} <= set(hbm)                   # HBM-bound families: bytes / us / 8 TB/s
     assert all(0 < hbm[n]["frac_hbm"] < 1 for n in ("groupnorm_fwd", "groupnorm_bwd", "adam_step"))
@@ -63,8 +64,9 @@ def test_training_kernels_agree_with_the_training_only_rocprof_summary():
     checked = 0
     for k in d["train_step_kernels"]:
         sym = k["kernel"].split("(+")[0]
-        if sym not in st or k["avg_us"] < 40 or "(+" in k["kernel"]:
-            continue                              # short kernels: the event pair's own overhead dominates; '(+x)': several symbols per call
+        if sym not in st or k["avg_us"] < 40 or "(+" in k["kernel"] or sym.startswith(("conv3_bx3_kernel<8,", "conv3_bx3_kernel<4,")):
+            continue                              # short kernels: the event pair's own overhead dominates; '(+x)' and the 8x8 / 4x4 convolutions
+                                                  # (split over channel chunks + splitk_epilogue_kernel): several symbols per bracketed call
         prof_us = st[sym][1]
         # the rocprof summary also covers the exact-f32 leg of the run for kernels both arithmetics use; the split-precision symbols are unique to it
         if "bx3" in sym or "attn_core" in sym:
@@ -84,7 +86,8 @@ def test_pmc_tables_cover_the_roofline_kernels():
     for key in ("roofline", "roofline_largest_flops"):
         sym = d[key]["kernel"].split("(+")[0]
         assert sym in tr and tr[sym]["traffic_bytes_per_launch"] > 0 and "hbm_gbs" in tr[sym], sym
-        assert d[key]["traffic"] == tr[sym]["traffic_bytes_per_launch"]
+        # the bench line quotes the PMC table committed BEFORE it ran; the table is then re-collected with the line: same kernel, two passes
+        assert abs(d[key]["traffic"] - tr[sym]["traffic_bytes_per_launch"]) / tr[sym]["traffic_bytes_per_launch"] < 0.02
     # MFMA-busy counter == executed flops / peak for an MFMA-bound kernel (a split-precision kernel executes 3 bf16 MFMAs per algorithmic
     # product term).  The counter ratio is per CYCLE, the bench's fraction per SECOND against the 2.4 GHz peak: convert with the kernel's
     # own cycles (GRBM) / measured duration.
