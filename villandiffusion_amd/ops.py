@@ -427,16 +427,16 @@ def sumpool2x2(dU, dX, accumulate=False):
     return dX
 
 
-def conv3x3_s2_dgrad(dy, w2d, dx, pad=0):
+def conv3x3_s2_dgrad(dy, w2d, dx, pad=0, a_packed=None):
     """Input gradient of the stride-2 (pad (0,1,0,1)) conv: plain GEMM G[b] = w2d^T @ dy[b] (no structural zeros, unlike
-    the dilated-gather GEMM), then the col2im gather."""
+    the dilated-gather GEMM), then the col2im gather.  a_packed: the [C*9, M] transpose packed as a one-tap split-precision operand."""
     Bn, M, OH, OW, dbs = _img(dy)
     Bx, Cc, H, W, xbs = _img(dx)
     assert Bx == Bn and w2d.shape == (M, Cc * 9) and w2d.is_contiguous()
     OHW = OH * OW
     G = torch.empty((Bn, Cc * 9, OHW), device=dy.device, dtype=torch.float32)
     gemm(w2d, dy, G, M=Cc * 9, N=Bn * OHW, K=M, a_mode=A_COL, b_mode=B_PLAIN, NP=OHW, lda=Cc * 9, ldb=OHW, b_bstride=dbs,
-         ldd=OHW, d_bstride=Cc * 9 * OHW)
+         ldd=OHW, d_bstride=Cc * 9 * OHW, a_packed=a_packed)
     L.check(_lib().vd_col2im_s2(_p(G), _p(dx), Bn, Cc, H, W, OH, OW, pad, Cc * 9 * OHW, xbs, _s()), "vd_col2im_s2")
     return dx
 

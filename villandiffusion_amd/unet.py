@@ -69,13 +69,20 @@ class _PackedConvWeights:
                 cands.append((prefix + "::qkv", (lambda k=prefix + "::qkv_w": net.Pq[k]), 3 * ch, ch, 1))
             if prefix + ".to_out.0.weight" in net.P:
                 cands.append((prefix + ".to_out.0", (lambda n=prefix + ".to_out.0.weight": net.P[n]), ch, ch, 1))
+        plan = []
         for key, get, cout, cin, T in cands:
             for bwd, (M, Cc, rs, cs) in ((False, (cout, cin, cin * T, T)), (True, (cin, cout, T, cin * T))):
-                if Cc % 16 == 0 and M >= 64:
-                    n = (M + 127) // 128 * 128 * Cc * T
-                    self.off[bwd][key] = (self.total, n)
-                    self.jobs[bwd].append((key, get, M, Cc, T, rs, cs))
-                    self.total += n
+                plan.append((key, get, bwd, M, Cc, T, rs, cs))
+            if T == 9 and ".downsamplers." in key:
+                # stride-2 input gradient = plain product G[c*9+t][pixel] = sum_m W[m][c*9+t] dY[m][pixel] followed by col2im (ops.conv3x3_s2_dgrad):
+                # its A operand is the [cin*9, cout] transpose of the weight matrix, packed as a one-tap operand
+                plan.append((key + "::s2g", get, True, cin * 9, cout, 1, 1, cin * 9))
+        for key, get, bwd, M, Cc, T, rs, cs in plan:
+            if Cc % 16 == 0 and M >= 64:
+                n = (M + 127) // 128 * 128 * Cc * T
+                self.off[bwd][key] = (self.total, n)
+                self.jobs[bwd].append((key, get, M, Cc, T, rs, cs))
+                self.total += n
         self.buf: Optional[torch.Tensor] = None
         self.tables = {}
         self.key = {False: None, True: None}
@@ -174,7 +181,8 @@ class _Conv:
         if dx is None:
             return None
         if self.mode == B_CONV3_S2:
-            return ops.conv3x3_s2_dgrad(dout, self.w2d(), dx, pad=self.pad)
+            pk = _bx3_packed_1x1(net, self.prefix + "::s2g", True, self.cin * 9, self.cout, dout.shape[2] * dout.shape[3], dout.shape[0])
+            return ops.conv3x3_s2_dgrad(dout, self.w2d(), dx, pad=self.pad, a_packed=pk)
         # split-precision dgrad reads the packed transposed operand; the f32 transposed copy is then only a shape carrier
         pk = _bx3_packed(net, self.prefix, True, self.cin, self.cout, dout.shape[2], dout.shape[3], B_CONV3_T) \
             if self.mode in (B_CONV3, B_CONV3_UP) else None
