@@ -248,8 +248,10 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
 // reused for dx -- 3 tensor reads (x, dy, extra) + 1 write instead of 5 + 1.
 // L = float4 per channel (HW/4): L >= 64 (multiple of 64): every (chunk, wave) lies in one channel; L < 64 (power of two):
 // channels are L-lane segments of a wave.
-template <int NV>
-__global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// NTH = 512 for the large groups (slab > 4096 elements): half the registers per lane (122 / 170 VGPRs at NV = 8 / 12 allowed only 4 / 2 waves per
+// SIMD, and with two resident workgroups per CU nothing overlapped a workgroup's reduce / write phase: 4.4 / 3.4 TB/s against 5.5 for NV <= 4).
+template <int NV, int NTH = 256>
+__global__ __launch_bounds__(NTH) void gn_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ extra, float* __restrict__ dx,
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float* __restrict
                                                          int HW, int G, int apply_silu, int64_t dy_bs, int64_t x_bs,
                                                          int64_t ex_bs, int64_t dx_bs) {
     __shared__ float ch_s1[64], ch_s2[64];
-    __shared__ float part1[NV * 4], part2[NV * 4];
+    __shared__ float part1[NV * (NTH / 64)], part2[NV * (NTH / 64)];
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int cpg = C / G;
     const int n4 = (cpg * HW) >> 2;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float* __restrict
     f32x4 xh[NV], dz[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTH;
         const bool in = idx < n4;
         const f32x4 xv = in ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 dv = in ? d4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -298,8 +300,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float* __restrict
             s1 = wave_sum(s1);
             s2 = wave_sum(s2);
             if (lane == 0) {
-                part1[i * 4 + wave] = s1;
-                part2[i * 4 + wave] = s2;
+                part1[i * (NTH / 64) + wave] = s1;
+                part2[i * (NTH / 64) + wave] = s2;
             }
         } else {
             for (int off = 1; off < L; off <<= 1) {          // butterfly inside the L-lane channel segment
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float* __restrict
     m2 *= inv_n;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTH;
         if (idx < n4) {
             const float ga = gamma[g * cpg + idx / L];
             f32x4 ev = {0.f, 0.f, 0.f, 0.f}, o;
@@ -646,8 +648,12 @@ extern "C" int vd_groupnorm_bwd(const float* dy, const float* x, const float* me
     if (reg_ok && slab <= 1024) VD_GN_BWD(1);
     else if (reg_ok && slab <= 2048) VD_GN_BWD(2);
     else if (reg_ok && slab <= 4096) VD_GN_BWD(4);
-    else if (reg_ok && slab <= 8192) VD_GN_BWD(8);
-    else if (reg_ok) VD_GN_BWD(12);
+    else if (reg_ok && slab <= 8192)
+        hipLaunchKernelGGL((gn_bwd_reg_kernel<4, 512>), dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta,
+                           extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
+    else if (reg_ok)
+        hipLaunchKernelGGL((gn_bwd_reg_kernel<6, 512>), dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta,
+                           extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
     else
         hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
                            dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
