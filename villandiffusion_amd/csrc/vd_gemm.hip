@@ -1849,38 +1849,56 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const vd_wgrad_desc d)
     const int x = threadIdx.x & 31, slot = threadIdx.x >> 5;
     const int Ncols = d.C * 9;
     float* __restrict__ part = d.ws + ((int64_t)b * tiles + tile) * d.M * Ncols;
-    for (int k = 0; k < 4; ++k) {
-        const int cb = cb0 + slot + 8 * k;                       // uniform per 32-lane group
-        if (cb >= CB) continue;
-        float acc[MAXS][9];
+    // the four big channels of a 32-lane group share every read of the small operand's patch: 27 LDS reads feed 4 x 27 FMAs per pixel
+    // (one channel at a time, the kernel was LDS-issue bound: 104 us for a 15 us read of the big operand)
+    float acc[4][MAXS][9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int cs = 0; cs < MAXS; ++cs)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[cs][t] = 0.f;
-        if (x < TW) {
-            const float* __restrict__ src = big + (int64_t)cb * HW + (int64_t)y0 * W + x0 + x;
-            for (int y = 0; y < TH; ++y) {
-                const float v = src[y * W];
+            for (int t = 0; t < 9; ++t) acc[k][cs][t] = 0.f;
+    if (x < TW) {
+        const float* __restrict__ src[4];
+        bool live[4];
 #pragma unroll
-                for (int cs = 0; cs < MAXS; ++cs) {
-                    if (cs < CS) {
-                        const float* __restrict__ sp = S + cs * PHW + (y + 1) * PW + (x + 1);
+        for (int k = 0; k < 4; ++k) {
+            const int cb = cb0 + slot + 8 * k;                   // uniform per 32-lane group
+            live[k] = cb < CB;
+            src[k] = big + (int64_t)(live[k] ? cb : 0) * HW + (int64_t)y0 * W + x0 + x;
+        }
+        for (int y = 0; y < TH; ++y) {
+            float v[4];
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) {
-                            const int r = t / 3, sx = t - 3 * r;
-                            const int dy = BIG_IS_X ? 1 - r : r - 1, dx = BIG_IS_X ? 1 - sx : sx - 1;
-                            acc[cs][t] = fmaf(v, sp[dy * PW + dx], acc[cs][t]);
-                        }
+            for (int k = 0; k < 4; ++k) v[k] = src[k][y * W];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = live[k] ? v[k] : 0.f;
+#pragma unroll
+            for (int cs = 0; cs < MAXS; ++cs) {
+                if (cs < CS) {
+                    const float* __restrict__ sp = S + cs * PHW + (y + 1) * PW + (x + 1);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int r = t / 3, sx = t - 3 * r;
+                        const int dy = BIG_IS_X ? 1 - r : r - 1, dx = BIG_IS_X ? 1 - sx : sx - 1;
+                        const float sv = sp[dy * PW + dx];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k][cs][t] = fmaf(v[k], sv, acc[k][cs][t]);
                     }
                 }
             }
         }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cb = cb0 + slot + 8 * k;
+        if (cb >= CB) continue;
 #pragma unroll
         for (int cs = 0; cs < MAXS; ++cs) {
             if (cs < CS) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    float v = acc[cs][t];
+                    float v = acc[k][cs][t];
 #pragma unroll
                     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
                     if (x == 0) {
