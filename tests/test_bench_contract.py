@@ -97,7 +97,7 @@ def test_pmc_tables_cover_the_roofline_kernels():
     util_time = m["MfmaUtil"] * m["kernel_us_at_2.4GHz"] / m["avg_us"]
     assert abs(util_time - k["frac_mfma_executed"]) < 0.04, (m["MfmaUtil"], util_time, k["frac_mfma_executed"])
     # HBM-bound kernels now have a reproducible GB/s: bytes of the PMC pass / duration of the SAME dispatch population
-    for sym in ("gn_fwd_reg_kernel<4>", "gn_bwd_reg_kernel<4>", "adam_kernel"):
+    for sym in ("gn_fwd_reg_kernel<4>", "gn_bwd_reg_kernel<4, 256>", "gn_bwd_reg_kernel<6, 512>", "adam_kernel"):
         assert sym in tr and 0 < tr[sym]["hbm_gbs"] < 8000, (sym, tr.get(sym))
 
 
