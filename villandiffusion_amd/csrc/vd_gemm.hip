@@ -166,6 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const vd_gemm_desc& d, f32x16 (&ac
                     const int m = mbase + (u & 3) + 8 * (u >> 2);
                     if (nok && m < d.M) d.D[dbase + (int64_t)m * dstr] = val[u];
                 }
+                if (WM * WN >= 8) __builtin_amdgcn_sched_barrier(0);   // 128 accumulator registers: one 8-row block's loads in flight at a time
             }
         }
     }
@@ -2021,7 +2022,8 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             int splits, c_per;
             bx3_plan(d, splits, c_per);
             static const int big_off = getenv("VD_BX3_BIG_OFF") ? atoi(getenv("VD_BX3_BIG_OFF")) : 0;
-            return (!big_off && bx3_big_tile(d, splits)) ? 12 : 8;     // 12: the 128 x 256 tile, eight waves
+            const int big = big_off ? 0 : bx3_big_tile(d, splits);
+            return big == 2 ? 15 : (big == 1 ? 12 : 8);                // 12 / 15: the 128 x 256 / 128 x 512 tile, eight waves
         }
         if (!gemm_bx3_eligible(d)) return -1;
         // >= 2 tiles per resident workgroup (512 slots): the persistent variant walks them with the next tile's loads in flight
@@ -2064,7 +2066,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, "
                            "C %% 16 == 0, M >= 64, or a VD_B_PLAIN product with shared A, NP %% 128 == 0, K %% 16 == 0, M >= 64; "
                            "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 32, M >= 64");
-    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12,
+    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     VD_REQUIRE(!d.pool2 || tile == 8, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
     hipStream_t st = (hipStream_t)stream;
@@ -2076,7 +2078,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 4:
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
-        case 8: case 12: rc = launch_bx3(d, st); break;
+        case 8: case 12: case 15: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 13:
             hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d);
