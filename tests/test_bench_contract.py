@@ -104,5 +104,5 @@ def test_pmc_tables_cover_the_roofline_kernels():
 def test_sampler_summary_is_sampler_only():
     st = _stats("r02_sample_kernel_stats.csv")
     assert not any("wgrad" in s or "gn_bwd" in s or "adam" in s for s in st)              # no training dispatches in the sampler's summary
-    assert any(s.startswith("conv3_bx3_kernel<32, 3, 2") for s in st) and any(s.startswith("attn_core_kernel") for s in st)
+    assert any(s.startswith("conv3_bx3_kernel<32, 3,") for s in st) and any(s.startswith("attn_core_kernel") for s in st)
     assert not any(s.startswith("softmax_col") for s in st)                              # the fused attention core replaced the column softmax
