@@ -2022,6 +2022,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             int splits, c_per;
             bx3_plan(d, splits, c_per);
             static const int big_off = getenv("VD_BX3_BIG_OFF") ? atoi(getenv("VD_BX3_BIG_OFF")) : 0;
+            if (bx3_big_split(d)) return 16;                           // 16: 8x8 layers, 128 x 256 tiles with the channel loop split
             const int big = big_off ? 0 : bx3_big_tile(d, splits);
             return big == 2 ? 15 : (big == 1 ? 12 : 8);                // 12 / 15: the 128 x 256 / 128 x 512 tile, eight waves
         }
@@ -2078,7 +2079,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 4:
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
-        case 8: case 12: case 15: rc = launch_bx3(d, st); break;
+        case 8: case 12: case 15: case 16: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 13:
             hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d);
