@@ -875,3 +875,41 @@ def test_split_precision_activation_products(a_row, b_kc):
     ops.gemm(dA[:, 1], dB[:, 1], D32, M=M, N=nb * Nn, K=K, a_mode=A_ROW if a_row else A_COL, b_mode=B_KCONTIG if b_kc else B_PLAIN, NP=Nn,
              lda=K if a_row else M, a_bstride=3 * M * K, ldb=K if b_kc else Nn, b_bstride=2 * K * Nn, ldd=Nn, d_bstride=M * Nn, alpha=0.37)
     assert float((D - D32).abs().max()) <= 5e-5 * float(D32.std())
+
+
+_TILE_PROBE = r"""
+import hashlib, math, sys, torch
+from villandiffusion_amd import ops
+from villandiffusion_amd.lib import B_CONV3, B_CONV3_T
+g = torch.Generator().manual_seed(11)
+out = []
+for (cin, cout, H) in ((128, 128, 32), (256, 256, 16), (256, 256, 8)):
+    x = torch.randn(128, cin, H, H, generator=g).cuda()
+    w = (torch.randn(cout, cin * 9, generator=g) / math.sqrt(cin * 9)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    y = torch.empty(128, cout, H, H, device="cuda")
+    ops.conv3x3(x, w, b, y, mode=B_CONV3, a_packed=ops.conv3_pack_weights(w, cout, cin))
+    dx = torch.empty_like(x)
+    ops.conv3x3(y, torch.empty(cin, cout * 9, device="cuda"), None, dx, mode=B_CONV3_T, a_packed=ops.conv3_pack_weights(w, cin, cout, transposed=True))
+    torch.cuda.synchronize()
+    out.append(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:16] + hashlib.sha256(dx.cpu().numpy().tobytes()).hexdigest()[:16])
+print("TILEHASH " + " ".join(out))
+"""
+
+
+def test_tile_choice_does_not_change_a_single_bit():
+    """The 128x128, 128x256 and 128x512 tiles (and the split 128x256 tiles at 8x8) only regroup output elements over workgroups: every element is still
+    accumulated chunk by chunk, tap by tap, in the same MFMA order, so the results are bit-identical whichever tile the planner picks (the planner is
+    steered through its environment switches, which are read once per process: one subprocess per setting)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = {}
+    for name, env in (("default", {}), ("small", {"VD_BX3_BIG_OFF": "1", "VD_BX3_BIGSPLIT_OFF": "1"}), ("no128x512", {"VD_BX3_HUGE_OFF": "1"})):
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        r = subprocess.run([sys.executable, "-c", _TILE_PROBE], capture_output=True, text=True, env=e, cwd=root, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("TILEHASH")][0]
+    print("[parity] output hashes per tile setting:", hashes)
+    assert hashes["default"] == hashes["small"] == hashes["no128x512"]
