@@ -51,4 +51,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// 1 / (1 + e^-z) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the IEEE division sequence (v_div_scale / v_rcp / 4 FMAs / v_div_fmas /
+// v_div_fixup): the GroupNorm-folding convolution loader evaluates it per staged element.  VD_EXACT_SIGMOID restores the division.
+#ifdef VD_EXACT_SIGMOID
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
+#else
+__device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+#endif
