@@ -59,15 +59,18 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 print(f"{name} B={B}: {ms:.1f} ms/step = {B / ms * 1e3:.1f} img/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+ws0, net.wgrad_stream = getattr(net, "wgrad_stream", False), False      # per-launch durations: weight gradients on the launch stream
 ops.profile_start()
 step()
-rec = ops.profile_stop()
 torch.cuda.synchronize()
+rec = ops.profile_stop()
+if hasattr(net, "wgrad_stream"):
+    net.wgrad_stream = ws0
 agg = {}
-for nm, fl, a, b in rec:
-    d = agg.setdefault(nm, [0, 0.0, 0.0])
-    d[0] += 1; d[1] += fl; d[2] += a.elapsed_time(b)
+for r in rec:                                                           # records of ops._timed / ops.gemm: dicts {name, flops, bytes, e0, e1, kind}
+    d = agg.setdefault(r["name"], [0, 0.0, 0.0])
+    d[0] += 1; d[1] += r["flops"]; d[2] += r["e0"].elapsed_time(r["e1"])
 tot = sum(v[2] for v in agg.values())
-print(f"MFMA kernels: {tot:.1f} ms, {sum(v[1] for v in agg.values()) / tot / 1e9:.1f} TF avg")
+print(f"profiled kernels: {tot:.1f} ms, {sum(v[1] for v in agg.values()) / tot / 1e9:.1f} TF avg")
 for nm, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:int(os.environ.get("STEP_BENCH_TOP", 14))]:
     print(f"  {nm:55s} n={v[0]:3d} {v[2]:8.2f} ms {v[1] / v[2] / 1e9:6.1f} TF")
