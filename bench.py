@@ -123,9 +123,16 @@ def main():
     if world > 1:
         # "nccl" IS RCCL on ROCm.  VD_BENCH_BACKEND=gloo exists only to exercise the multi-process path on a 1-GPU box.
         backend = os.environ.get("VD_BENCH_BACKEND", "nccl")
-        if backend == "nccl":                             # RCCL prints its communicator / ring set-up (rank count, transport) to stderr
+        rccl_log = None
+        if backend == "nccl":
+            # RCCL's own account of the communicator (rank count, transports): INFO lines of the INIT subsystem.  They go to a FILE per process --
+            # RCCL would otherwise write them to stdout, where the one JSON line of this script has to stand alone -- and rank 0 quotes the
+            # communicator lines in its stderr log and in the JSON (`process_group.rccl_init`).
             os.environ.setdefault("NCCL_DEBUG", "INFO")
             os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT")
+            if "NCCL_DEBUG_FILE" not in os.environ:
+                rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"villan_rccl_rank{rank}_{os.getpid()}.log")
+                os.environ["NCCL_DEBUG_FILE"] = rccl_log
         dist.init_process_group(backend, rank=rank, world_size=world)
         # proof that the collective really spans N ranks on N devices: every rank contributes (rank, device index, PCI bus id)
         prop = torch.cuda.get_device_properties(dev_id)
@@ -137,6 +144,10 @@ def main():
         ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted_by_all_reduce": int(tot[3]),
                       "rank_device_pci": [[int(v) for v in t_[:3]] for t_ in seen],
                       "distinct_devices": len({(int(t_[1]), int(t_[2])) for t_ in seen})}
+        if rank == 0 and rccl_log and os.path.exists(rccl_log):
+            with open(rccl_log, errors="replace") as f:
+                lines = [ln.strip() for ln in f if "nranks" in ln or "Init COMPLETE" in ln or "comm 0x" in ln]
+            ranks_seen["rccl_init"] = lines[:4]
         if rank == 0:
             print(f"[bench] process group: {ranks_seen}", file=sys.stderr, flush=True)
         assert ranks_seen["ranks_counted_by_all_reduce"] == world == ranks_seen["world_size"]
