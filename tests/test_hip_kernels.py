@@ -182,6 +182,7 @@ def test_linear_family():
 
 @pytest.mark.parametrize("B,C,H,silu", [(4, 128, 32, True), (2, 384, 32, True), (3, 256, 16, False), (8, 512, 4, True), (5, 256, 4, True),
                                         (2, 512, 8, True),
+                                        (2, 256, 32, True),          # 8 K-element groups: the 512-thread backward (as (2, 384, 32): 12 K)
                                         # groups of > 12 K elements: the multi-workgroup (chunked) kernels
                                         (1, 128, 256, True), (2, 256, 128, True), (2, 128, 64, False)])
 def test_groupnorm_silu(B, C, H, silu):
