@@ -681,7 +681,8 @@ def test_split_precision_conv3x3_on_unsplit_grids(B, Cin, Cout, H, mode):
         assert torch.equal(dx, dx2)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H", [(32, 256, 256, 16), (128, 128, 256, 8), (40, 200, 128, 16), (128, 64, 64, 8)])
+@pytest.mark.parametrize("B,Cin,Cout,H", [(32, 256, 256, 16), (128, 128, 256, 8), (40, 200, 128, 16), (128, 64, 64, 8),
+                                         (128, 256, 128, 8)])       # the first and the last land on the 128 x 256 tile (32x32 / 16x16 outputs)
 def test_upsample_conv_input_gradient_with_the_2x2_sum_in_the_epilogue(B, Cin, Cout, H):
     """Upsample2D = nearest 2x + conv3x3; its input gradient is the stride-1 dgrad at the OUTPUT resolution followed by 2x2 block sums.
     vd_gemm_desc.pool2 does the sums in the dgrad epilogue (H is the input side; outputs 16x16 / 32x32, unsplit grid)."""

@@ -2069,7 +2069,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
                            "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 32, M >= 64");
     VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
-    VD_REQUIRE(!d.pool2 || tile == 8, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
+    VD_REQUIRE(!d.pool2 || tile == 8 || tile == 12, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (tile) {
