@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-f32 leg (profiling runs: the summary then covers the default arithmetic only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the DDIM-50 / DPM-Solver++-20 / UniPC-20 legs (counter-collection passes)")
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight gradients on the launch stream for the WHOLE run (profiling: every kernel's duration is then its own; "
                          "the default overlaps them with the backward pass on a side stream)")
@@ -295,9 +296,10 @@ def main():
         from villandiffusion_amd.pipelines import DDIMPipeline, PNDMPipeline
         from villandiffusion_amd.schedulers import DDIMScheduler, DPMSolverMultistepScheduler, UniPCMultistepScheduler
         secondary = {}
-        for tag, mk, pcls, nst in (("ddim50", lambda: DDIMScheduler(clip_sample=False), DDIMPipeline, 50),
-                                   ("dpm_solver_pp_o2_20", lambda: DPMSolverMultistepScheduler(), PNDMPipeline, 20),
-                                   ("unipc20", lambda: UniPCMultistepScheduler(), PNDMPipeline, 20)):
+        for tag, mk, pcls, nst in (() if args.no_secondary else
+                                   (("ddim50", lambda: DDIMScheduler(clip_sample=False), DDIMPipeline, 50),
+                                    ("dpm_solver_pp_o2_20", lambda: DPMSolverMultistepScheduler(), PNDMPipeline, 20),
+                                    ("unipc20", lambda: UniPCMultistepScheduler(), PNDMPipeline, 20))):
             p2 = pcls(net, mk())
             c0 = init[:B]
             p2(batch_size=len(c0), init=c0, num_inference_steps=nst, return_tensor=True)          # warm-up

@@ -87,7 +87,7 @@ def test_pmc_tables_cover_the_roofline_kernels():
         sym = d[key]["kernel"].split("(+")[0]
         assert sym in tr and tr[sym]["traffic_bytes_per_launch"] > 0 and "hbm_gbs" in tr[sym], sym
         # the bench line quotes the PMC table committed BEFORE it ran; the table is then re-collected with the line: same kernel, two passes
-        assert abs(d[key]["traffic"] - tr[sym]["traffic_bytes_per_launch"]) / tr[sym]["traffic_bytes_per_launch"] < 0.02
+        assert abs(d[key]["traffic"] - tr[sym]["traffic_bytes_per_launch"]) / tr[sym]["traffic_bytes_per_launch"] < 0.05
     # MFMA-busy counter == executed flops / peak for an MFMA-bound kernel (a split-precision kernel executes 3 bf16 MFMAs per algorithmic
     # product term).  The counter ratio is per CYCLE, the bench's fraction per SECOND against the 2.4 GHz peak: convert with the kernel's
     # own cycles (GRBM) / measured duration.

@@ -26,6 +26,16 @@ if [ -z "${SKIP_PMC:-}" ]; then
   python3 tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma.json
   rm -rf $O/pmc_mfma
 fi
+if [ -z "${SKIP_PMC:-}" ]; then          # the sampler's dispatches: traffic and MFMA counters of a 30-step DDPM loop (eager launches: one dispatch per kernel)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmcs_$c -- python3 bench.py --mode sample --sample-steps 30 --sample-images 128 --no-cpu --no-roofline --no-secondary > /dev/null 2> $O/pmcs_$c.err
+    python3 tools/pmc_summary.py $O/pmcs_$c > $O/pmc_sample_$c.json
+    rm -rf $O/pmcs_$c
+  done
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcs_mfma -- python3 bench.py --mode sample --sample-steps 30 --sample-images 128 --no-cpu --no-roofline --no-secondary > /dev/null 2> $O/pmcs_mfma.err
+  python3 tools/pmc_summary.py $O/pmcs_mfma > $O/pmc_sample_mfma.json
+  rm -rf $O/pmcs_mfma
+fi
 python3 tools/shape_probe.py > $O/shape_probe.txt 2>&1
 # sustained matrix-pipe rates from registers / from LDS / with random operand bits (hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o build/mfma_peak)
 if [ -x build/mfma_peak ]; then timeout 120 build/mfma_peak > $O/mfma_sustained.txt 2>&1; fi

@@ -10,6 +10,7 @@ per-kernel tables:
                                          where the bench line knows the algorithmic bytes, traffic / algorithmic
   r02_pmc_mfma.json                      MFMA-busy counters per launch -> MfmaUtil per kernel (training dispatches)
   r02_pmc_sq_wait.json                   SQ wait / LDS counters per launch (their own pass)
+  r02_pmc_sample.json                    the sampler's dispatches: traffic and MfmaUtil per kernel (30-step DDPM loop)
   r02_shape_probe.txt                    tools/shape_probe.py: per-SHAPE timings of the 1x1 / 3x3 convolutions, GroupNorm and the attention core
   r02_mfma_sustained.txt                 tools/mfma_peak.hip: what the matrix pipe sustains from registers / from LDS / with random operand bits
 
@@ -120,6 +121,31 @@ if os.path.exists(mp):
             e["avg_us"] = round(dur[k][1], 2)
         om["kernels"][k] = e
     json.dump(om, open(os.path.join(dst, "r02_pmc_mfma.json"), "w"), indent=1)
+
+# sampler dispatches: per-kernel traffic (2 * FETCH + WRITE) and MfmaUtil, joined with the sampler-only durations
+sdur = {}
+p = os.path.join(dst, "r02_sample_kernel_stats.csv")
+if os.path.exists(p):
+    for r_ in csv.DictReader(open(p)):
+        sdur[norm(r_["Name"])] = float(r_["AverageNs"]) / 1e3
+sf, sw, sm = (os.path.join(src, n) for n in ("pmc_sample_FETCH_SIZE.json", "pmc_sample_WRITE_SIZE.json", "pmc_sample_mfma.json"))
+if all(os.path.exists(x) and os.path.getsize(x) for x in (sf, sw, sm)):
+    f, w, m = json.load(open(sf)), json.load(open(sw)), json.load(open(sm))
+    outs = {"_how": "as r02_pmc_traffic.json / r02_pmc_mfma.json, over `bench.py --mode sample --sample-steps 30 --sample-images 128` (the sampler's dispatches only; "
+                    "the HIP graph replays kernel by kernel under the profiler); avg_us from r02_sample_kernel_stats.csv", "kernels": {}}
+    for k in sorted(set(f) | set(w) | set(m)):
+        a, b = f.get(k, {}).get("FETCH_SIZE", {}), w.get(k, {}).get("WRITE_SIZE", {})
+        e = {"dispatches": a.get("dispatches") or b.get("dispatches"), "traffic_bytes_per_launch": int((2 * a.get("avg", 0) + b.get("avg", 0)) * 1024)}
+        v = m.get(k, {})
+        g = v.get("GRBM_GUI_ACTIVE", {}).get("avg", 0)
+        if g and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            e["MfmaUtil"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (g / 8 * 1024), 4)
+            e["kernel_us_at_2.4GHz"] = round(g / 8 / 2400, 1)
+        if k in sdur:
+            e["avg_us"] = round(sdur[k], 2)
+            e["hbm_gbs"] = round(e["traffic_bytes_per_launch"] / sdur[k] / 1e3, 1)
+        outs["kernels"][k] = e
+    json.dump(outs, open(os.path.join(dst, "r02_pmc_sample.json"), "w"), indent=1)
 
 r = bench["roofline"]
 print(f"value {bench['value']} img/s, {bench['ms_per_step']} ms/step; sample {bench['sample_ddpm1000_images_per_sec']} img/s ({bench['sample_seconds']} s, "
