@@ -418,6 +418,9 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
         if rank == 0:
             if (epoch + 1) % cfg.save_image_epochs == 0 or epoch == cfg.epoch - 1:
                 sampling(cfg, epoch, pipeline, dsl)
+                if dsl.image_size >= 128:                              # the captured forwards pin their peak memory: release it before training resumes
+                    from villandiffusion_amd.pipelines import drop_sampler_graphs
+                    drop_sampler_graphs(model)
             if (epoch + 1) % cfg.save_model_epochs == 0 or epoch == cfg.epoch - 1:
                 checkpoint(cfg, trainer, pipeline, epoch, step)
     if rank == 0:                                                      # reference :1192-1195
@@ -428,11 +431,24 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
 
 def main(argv: Optional[List[str]] = None):
     args = parse_args(argv)
-    cfg = setup(args, preflight=True)
     rank, world, _ = _dist()
-    if world > 1:                                                      # rank 0 has created the run directory and its side files
+    err = None
+    try:
+        cfg = setup(args, preflight=True)
+    except Exception as e:                                             # noqa: BLE001  (re-raised below, on every rank)
+        err = e
+    if world > 1:
+        # rank 0 alone checks / creates the run directory and writes its side files; if it fails there (directory exists without
+        # --overwrite, dataset not found) every rank must exit, not sit in a collective until the RCCL timeout: agree on a flag first
+        import torch
         import torch.distributed as dist
-        dist.barrier()
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([0 if err is None else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag) and err is None:
+            raise SystemExit(f"rank {rank}: another rank failed in setup(); exiting")
+    if err is not None:
+        raise err
     dsl = get_data_loader(cfg)
     if cfg.mode in (MODE_TRAIN, MODE_RESUME, MODE_TRAIN_MEASURE):
         pipeline = train_loop(cfg, dsl, rank, world)

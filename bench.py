@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-f32 leg (profiling runs: the summary then covers the default arithmetic only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager-sample", action="store_true", help="also time the sampling loop with eager launches instead of the HIP-graph replay")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DDIM-50 / DPM-Solver++-20 / UniPC-20 legs (counter-collection passes)")
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight gradients on the launch stream for the WHOLE run (profiling: every kernel's duration is then its own; "
@@ -56,11 +57,16 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int = 128, n_steps: int = 3):
+def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=None):
     """The oracle (plain torch fp32 = what the reference's diffusers path executes on a CPU) on the host cores:
-    fwd + bwd + clip(1.0) + Adam on a bounded sample of the same workload."""
+    fwd + bwd + clip(1.0) + Adam on a bounded sample of the same workload.
+
+    With `state_dict` (the product network's current weights) and `gpu_side` (callables that run the product path on
+    the same inputs) the same CPU work doubles as the parity gate printed with the number (SURVEY.md §8d, BASELINE.md §2;
+    workload VillanDiffusion.py:1141-1176): the oracle's FIRST step at batch `batch` gives loss and gradient norm on
+    identical weights / batch / timesteps / noise, its 20 DDPM steps on 8 images give the denoised images."""
     from oracle.loss_ref import LossFnRef, SDE_VP
-    from oracle.schedulers_ref import DDPMSchedulerRef
+    from oracle.schedulers_ref import DDPMSchedulerRef, sample_loop
     from oracle.unet_ref import UNet2DModelRef
     # cores this process may run on, capped at 32: on the 256-thread GPU host oneDNN gets SLOWER beyond ~32 threads for
     # these 32x32 convolutions (measured: 8 thr 0.28 s, 32 thr 0.39 s, 64 thr 0.79 s per B=8 fwd+bwd)
@@ -68,42 +74,70 @@ def cpu_baseline(batch: int = 128, n_steps: int = 3):
     torch.set_num_threads(max(1, ncpu))
     torch.manual_seed(0)
     net = UNet2DModelRef()
+    if state_dict is not None:
+        net.load_state_dict(state_dict)
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
     sched = DDPMSchedulerRef()
     lf = LossFnRef(sched, SDE_VP, psi=1, solver_type="sde")
 
-    def step(b):
-        g = torch.Generator().manual_seed(b)
+    def make_batch(b, seed):
+        g = torch.Generator().manual_seed(seed)
         x0 = torch.rand(b, 3, 32, 32, generator=g) * 2 - 1
-        R = torch.zeros_like(x0)
+        R = torch.rand(b, 3, 32, 32, generator=g) * 2 - 1
+        R[: b - max(1, b // 10)] = 0            # poison_rate 0.1: ~10 % of the rows carry a trigger residual, the rest are clean (R = 0)
         t = torch.randint(0, 1000, (b,), generator=g)
-        loss = lf.p_loss(net, x0, R, t, noise=torch.randn(x0.shape, generator=g))
+        return x0, R, t, torch.randn(x0.shape, generator=g)
+
+    def step(b, seed):
+        x0, R, t, eps = make_batch(b, seed)
+        loss = lf.p_loss(net, x0, R, t, noise=eps)
         opt.zero_grad()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)     # returns the norm BEFORE clipping
         opt.step()
+        return float(loss), float(gnorm)
 
-    step(2)                                     # warm-up (allocator, oneDNN primitives)
+    parity = None
+    if gpu_side is not None:                     # the product runs the very same step-0 inputs first (weights not yet touched by `opt`)
+        parity = gpu_side["train"](*make_batch(batch, 1000))
+    warm = torch.optim.Adam(net.parameters(), lr=0.0)        # warm-up (allocator, oneDNN primitives) that leaves the weights alone
+    opt, opt_real = warm, opt
+    step(2, 1)
+    opt = opt_real
     t0 = time.perf_counter()
-    for _ in range(n_steps):
-        step(batch)
+    for i in range(n_steps):
+        l_, g_ = step(batch, 1000 + i)
+        if i == 0 and parity is not None:
+            parity["loss_step0_rel_err"] = abs(parity.pop("loss") - l_) / abs(l_)
+            parity["grad_norm_rel_err"] = abs(parity.pop("grad_norm") - g_) / g_
     dt_train = time.perf_counter() - t0
     train_ips = n_steps * batch / dt_train
-    # sampling: 8 images x 20 DDPM steps, extrapolated x50 to 1000 steps (stated in "sample")
-    sched.set_timesteps(1000)
-    x = torch.randn(8, 3, 32, 32)
+    # sampling: 8 images x the last 20 steps of the 1000-step DDPM chain, extrapolated x50 (stated in "sample")
+    if state_dict is not None:
+        net.load_state_dict(state_dict)          # the denoising parity runs on the product's weights, not on the 3-steps-older ones
+    init = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(11))
     with torch.no_grad():
         t0 = time.perf_counter()
-        for t in sched.timesteps[:20]:
-            eps = net(x, torch.full((8,), int(t)))[0]
-            x = sched.step(eps, t, x).prev_sample
+        x = sample_loop(net, sched, init.clone(), 1000, generator=torch.Generator().manual_seed(5), start_from=980)
         dt_s = time.perf_counter() - t0
     sample_ips = 8 / (dt_s * 50.0)
-    return {"value": round(train_ips, 3), "unit": "train images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_steps} optimiser steps at batch {batch} (fwd+bwd+clip+Adam, fp32 torch CPU oracle); "
-                      f"sampling: 8 images x 20 DDPM steps extrapolated x50",
-            "sample_ddpm1000_images_per_sec": round(sample_ips, 5), "host_cpus": os.cpu_count(),
-            "affinity": len(os.sched_getaffinity(0))}
+    if parity is not None:
+        img_ref = (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+        img, ts_equal = gpu_side["sample"](init, 5, 980, sched.timesteps)
+        parity["denoised_max_rel_err"] = float(abs(img - img_ref).max() / abs(img_ref).max())
+        parity["timestep_indices_bit_exact"] = bool(ts_equal)
+        parity = {k: (v if isinstance(v, bool) else float(f"{v:.3e}")) for k, v in parity.items()}
+        parity["gates"] = {"loss_step0_rel_err": 1e-5, "grad_norm_rel_err": 1e-4, "denoised_max_rel_err": 1e-3}
+        parity["pass"] = bool(parity["loss_step0_rel_err"] <= 1e-5 and parity["grad_norm_rel_err"] <= 1e-4
+                              and parity["denoised_max_rel_err"] <= 1e-3 and parity["timestep_indices_bit_exact"])
+        parity["what"] = (f"product vs CPU oracle on identical weights and inputs: one fwd+bwd at batch {batch} (loss, gradient norm); "
+                          "8 images x the last 20 steps of DDPM-1000 with the same CPU-generator noise (denoised images); DDPM-1000 timestep table")
+    cpu = {"value": round(train_ips, 3), "unit": "train images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n_steps} optimiser steps at batch {batch} (fwd+bwd+clip+Adam, fp32 torch CPU oracle); "
+                     f"sampling: 8 images x 20 DDPM steps extrapolated x50",
+           "sample_ddpm1000_images_per_sec": round(sample_ips, 5), "host_cpus": os.cpu_count(),
+           "affinity": len(os.sched_getaffinity(0))}
+    return cpu, parity
 
 
 def log(msg):
@@ -111,15 +145,40 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1, no torchrun around it): start N fresh rank processes -- one per GPU -- BEFORE this process makes any
+    GPU call (it never does: it only waits), relay their output (rank 0 prints the one JSON line on the inherited stdout) and exit with the
+    launcher's code.  The reference's multi-GPU entry is `--gpu "0,1,..."` (VillanDiffusion.py:241-244, 440)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus}: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
+    if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', 1)}: launch with "
+                 f"`python bench.py --gpus N` or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     ndev = torch.cuda.device_count()
     dev_id = local_rank % max(1, ndev)                    # one GPU per rank on a real node (local_rank < ndev)
-    torch.cuda.set_device(dev_id)
-    dev = torch.device("cuda", dev_id)
+    rendezvous_only = os.environ.get("VD_BENCH_RENDEZVOUS_ONLY") == "1"      # launcher test on a box without GPUs: process group proof, no compute
+    if not rendezvous_only:
+        torch.cuda.set_device(dev_id)
+    dev = torch.device("cpu") if rendezvous_only else torch.device("cuda", dev_id)
     ranks_seen = None
     if world > 1:
         # "nccl" IS RCCL on ROCm.  VD_BENCH_BACKEND=gloo exists only to exercise the multi-process path on a 1-GPU box.
@@ -136,8 +195,8 @@ def main():
                 os.environ["NCCL_DEBUG_FILE"] = rccl_log
         dist.init_process_group(backend, rank=rank, world_size=world)
         # proof that the collective really spans N ranks on N devices: every rank contributes (rank, device index, PCI bus id)
-        prop = torch.cuda.get_device_properties(dev_id)
-        mine = torch.tensor([rank, dev_id, int(getattr(prop, "pci_bus_id", -1)), 1], device=dev, dtype=torch.int64)
+        pci = -1 if rendezvous_only else int(getattr(torch.cuda.get_device_properties(dev_id), "pci_bus_id", -1))
+        mine = torch.tensor([rank, dev_id, pci, 1], device=dev, dtype=torch.int64)
         seen = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(seen, mine)
         tot = mine.clone()
@@ -152,6 +211,13 @@ def main():
         if rank == 0:
             print(f"[bench] process group: {ranks_seen}", file=sys.stderr, flush=True)
         assert ranks_seen["ranks_counted_by_all_reduce"] == world == ranks_seen["world_size"]
+    if rendezvous_only:
+        if rank == 0:
+            print(json.dumps({"metric": "rendezvous only (VD_BENCH_RENDEZVOUS_ONLY=1): no compute ran", "value": None, "n_gpus": world,
+                              "process_group": ranks_seen}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from villandiffusion_amd import ops
     from villandiffusion_amd.dataset import DatasetLoader
@@ -284,7 +350,7 @@ def main():
         sample_ips = world * n_img / sample_s
         assert bool(torch.isfinite(pp).all())
         log(f"sample: {sample_ips:.4f} img/s ({sample_s:.2f} s for {n_img} images x {args.sample_steps} steps; hip graph = {net.sampler_graph})")
-        if net.sampler_graph and args.mode == "all":      # the same loop launched eagerly (what the graph replay replaces), reported beside it
+        if net.sampler_graph and args.eager_sample:      # the same loop launched eagerly (what the graph replay replaces), reported beside it
             net.sampler_graph = False
             sched._rng_offset = 0
             s_eager = timed_sampling()
@@ -372,7 +438,7 @@ def main():
         net.sampler_graph = g0
         if rank == 0:
             sample_kernels = summarise(rec_s)
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
 
     def traffic_of(kname):      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
@@ -390,7 +456,7 @@ def main():
         else:
             e = {"bound": "hbm", "kernel": k["kernel"], "achieved": k["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k["frac_hbm"],
                  "tflops": k["tflops"], "frac_mfma_executed": k["frac_mfma_executed"]}
-        e.update({"traffic": tr, "traffic_source": "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc passes)" if tr else None,
+        e.update({"traffic": tr, "traffic_source": (os.path.relpath(pmc_file, ROOT) + " (separate rocprofv3 --pmc passes)") if tr else None,
                   "launches_per_step": k["launches"], "avg_launch_us": k["avg_us"], "ms_per_step": k["ms"],
                   "algorithmic_mbytes_per_launch": round(k["mbytes"] / k["launches"], 2), "algorithmic_gflop_per_launch": round(k["gflop"] / k["launches"], 2),
                   "selection_rule": rule})
@@ -407,39 +473,65 @@ def main():
         roofline_by_flops = roof_entry(max(mf, key=lambda r: r["gflop"]), "the MFMA kernel symbol carrying the most algorithmic FLOPs in the profiled step")
 
     log("roofline leg done")
-    cpu = None
+
+    # ---- CPU oracle on the host cores (rank 0, N = 1): the reported baseline AND the parity gates printed with the number ----
+    def gpu_train_side(x0, R, t, eps):
+        net.zero_grad()
+        batch = {"target": x0.to(dev), "pixel_values": R.to(dev)}
+        loss = loss_fn.p_loss_by_keys(batch, net, "target", "pixel_values", t.to(dev), noise=eps.to(dev))
+        loss.backward()
+        gn = float(torch.sqrt((net.flat_grad.double() ** 2).sum()))
+        net.zero_grad()
+        return {"loss": float(loss), "grad_norm": gn}
+
+    def gpu_sample_side(init_cpu, seed, start_from, ref_timesteps):
+        sch = DDPMScheduler(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02)
+        o = DDPMPipeline(net, sch)(batch_size=len(init_cpu), generator=torch.Generator().manual_seed(seed), init=init_cpu,
+                                   num_inference_steps=1000, start_from=start_from, output_type=None)
+        return o.images, torch.equal(sch.timesteps.cpu(), ref_timesteps) and sch.timesteps.dtype == torch.int64
+
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        cpu, parity = cpu_baseline(args.cpu_batch, args.cpu_steps, state_dict=sd,
+                                   gpu_side={"train": gpu_train_side, "sample": gpu_sample_side})
         log(f"cpu baseline: {cpu}")
+        log(f"parity: {parity}")
 
     if rank == 0:
         split = net.conv_math == "bf16x3"
         ms = None if dt is None else 1e3 * dt / args.steps
+        slim = ("bound", "kernel", "achieved", "peak", "unit", "frac", "executed_tflops", "frac_executed", "traffic", "launches_per_step",
+                "avg_launch_us", "ms_per_step", "algorithmic_gflop_per_launch", "algorithmic_mbytes_per_launch", "all_mfma_kernels_ms")
+
+        def slim_roof(r):
+            return None if r is None else {k: r[k] for k in slim if k in r}
+
+        pg = None if ranks_seen is None else {k: v for k, v in ranks_seen.items() if k != "rccl_init"}
+        top = None if not kernels else [{"kernel": k["kernel"], "launches": k["launches"], "ms": k["ms"], "bound": k["bound"], "frac": k["frac"]}
+                                        for k in kernels[:5]]
+        non_mfma_ms = None if not kernels else round(sum(k["ms"] for k in kernels if not k["mfma_peak"]), 3)
         out = {
             "metric": "train imgs/sec + 1000-step DDPM sample imgs/sec, CIFAR10 bs128",
             "value": None if train_ips is None else round(train_ips, 2), "unit": "train images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": None if ms is None else round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3/f32" if split else "f32", "data": "synthetic",
-            "dtype_note": ("f32 tensors and accumulation; 3x3 / 1x1 convolutions and the attention contractions (forward, input and weight "
-                           "gradients) as hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32 per contraction; the "
-                           "reference trains this config under fp16 autocast); stride-2 convolutions, linears, conv_in / conv_out on the "
-                           "exact f32 MFMA") if split else
-                          "every contraction on the f32-input MFMA (exact f32)",
-            "exact_f32_mode": exact,
-            "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), "
-                                   "per-GPU batch %d; + %d-step DDPM sampling of %d images/GPU" % (B, args.sample_steps, args.sample_images),
+            "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), per-GPU batch %d; "
+                                   "+ %d-step DDPM sampling of %d images/GPU in chunks of %d (SURVEY 8d: 1024 = 8 such chunks, same per-chunk work)"
+                                   % (B, args.sample_steps, args.sample_images, B),
                        "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}", "mode": args.mode},
+            "exact_f32_mode": None if exact is None else {k: exact[k] for k in ("train_images_per_sec", "ms_per_step")},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
             "sample_seconds": None if sample_s is None else round(sample_s, 2),
-            "sample_hip_graph": bool(net.sampler_graph), "sample_eager_launches": sample_eager,
+            "sample_hip_graph": bool(net.sampler_graph),
             "sample_secondary_images_per_sec": secondary,
             "train_tflops": None if train_ips is None else round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
             "sample_tflops": None if sample_ips is None else round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3, 2),
             "final_loss": None if final_loss is None else round(final_loss, 5),
             "host_submit_ms_per_step": None if host_submit_ms is None else round(host_submit_ms, 3),
-            "host_drained_step_ms": None if host_sync_ms is None else round(host_sync_ms, 3),
-            "roofline": roofline, "roofline_largest_flops": roofline_by_flops,
-            "train_step_kernels": kernels, "sampler_step_kernels": sample_kernels, "cpu_baseline": cpu, "process_group": ranks_seen,
+            "non_mfma_ms_per_step": non_mfma_ms,
+            "roofline": slim_roof(roofline), "roofline_largest_flops": slim_roof(roofline_by_flops), "top_kernels": top,
+            "cpu_baseline": cpu, "parity": parity, "process_group": pg,
         }
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS          # whole-job fractions against the peak of the arithmetic that ran
         key = "bf16" if split else "f32"
@@ -447,7 +539,30 @@ def main():
             out[f"train_frac_of_{key}_peak"] = round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3 / (peak * world), 4)
         if sample_ips is not None:
             out[f"sample_frac_of_{key}_peak"] = round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3 / (peak * world), 4)
-        print(json.dumps(out))
+        # everything that does not fit a short line (per-kernel tables of the training and the sampler step, selection rules, notes, RCCL's
+        # communicator lines) goes to a side file and to stderr: the driver keeps only the tail of stdout, and the ONE line must survive it
+        detail = dict(out)
+        detail.update({"roofline": roofline, "roofline_largest_flops": roofline_by_flops, "train_step_kernels": kernels,
+                       "sampler_step_kernels": sample_kernels, "exact_f32_mode": exact, "sample_eager_launches": sample_eager,
+                       "process_group": ranks_seen,
+                       "dtype_note": ("f32 tensors and accumulation; 3x3 / 1x1 convolutions and the attention contractions (forward, input and weight "
+                                      "gradients) as hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32 per contraction; the "
+                                      "reference trains this config under fp16 autocast); stride-2 convolutions, linears, conv_in / conv_out on the "
+                                      "exact f32 MFMA") if split else "every contraction on the f32-input MFMA (exact f32)"})
+        path = os.environ.get("VD_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(detail, f)
+            out["detail_file"] = os.path.relpath(path, ROOT)
+        except OSError as e:
+            log(f"detail file not written: {e}")
+        for tag, rows in (("train", kernels), ("sampler", sample_kernels)):
+            for k in (rows or [])[:12]:
+                log(f"{tag:7s} {k['ms']:8.3f} ms {k['launches']:4d}x {k['avg_us']:8.1f} us  {k['bound']:4s} frac {k['frac']:.3f}  {k['kernel']}")
+        line = json.dumps(out)
+        assert len(line) < 4096, len(line)
+        print(line, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -106,3 +106,27 @@ def test_sampler_summary_is_sampler_only():
     assert not any("wgrad" in s or "gn_bwd" in s or "adam" in s for s in st)              # no training dispatches in the sampler's summary
     assert any(s.startswith("conv3_bx3_kernel<32, 3,") for s in st) and any(s.startswith("attn_core_kernel") for s in st)
     assert not any(s.startswith("softmax_col") for s in st)                              # the fused attention core replaced the column softmax
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 rank processes itself (before any GPU call) and rank 0 must
+    print a line with n_gpus = 2 whose all-reduce counted 2 ranks.  Here on CPU: rendezvous + process-group proof only (gloo)."""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"VD_BENCH_BACKEND": "gloo", "VD_BENCH_RENDEZVOUS_ONLY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["process_group"]["ranks_counted_by_all_reduce"] == 2 and d["process_group"]["world_size"] == 2
+    assert [x[0] for x in d["process_group"]["rank_device_pci"]] == [0, 1]
+
+
+def test_gpus_flag_disagreeing_with_world_size_fails_loudly():
+    r = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "VD_BENCH_RENDEZVOUS_ONLY": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -753,6 +753,11 @@ GROUPS = [
     (64, B_CONV3, [(2, 64, 128), (1, 72, 64)]),
     (16, B_PLAIN, [(16, 256, 768), (16, 512, 256), (3, 80, 64), (16, 256, 256)]),
     (32, B_PLAIN, [(8, 384, 128), (8, 256, 128), (2, 128, 256)]),
+    # the headline batch: at B = 128 a layer has K = 131 072 (32x32) / 32 768 (16x16) pixels and is split over 3-12 K ranges of <= 128 K-steps
+    (32, B_CONV3, [(128, 128, 128), (128, 384, 128), (128, 256, 128)]),
+    (16, B_CONV3, [(128, 256, 256), (128, 512, 256), (128, 128, 256)]),
+    (32, B_PLAIN, [(128, 384, 128), (128, 256, 128)]),
+    (16, B_PLAIN, [(128, 256, 768), (128, 512, 256)]),
 ]
 
 

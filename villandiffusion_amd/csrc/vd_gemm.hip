@@ -2306,7 +2306,12 @@ static int wgrad_group_class(const vd_wgrad_desc& d) {
     if (d.T != 9 || wgrad_patch_kind(d) != 4) return 0;
     const int up = d.mode == VD_B_CONV3_UP ? 2 : 0;
     if (d.OW >= 64) return 4 * 32 + up + 1;
-    return 4 * d.OW + up;
+    const int cls = 4 * d.OW + up;
+    // only the classes vd_conv_wgrad_group_launch has a kernel for (4x4 through the fused upsample -- a 2x2 input -- has none: single-layer path)
+    switch (cls) {
+        case 4 * 32 + 0: case 4 * 32 + 2: case 4 * 16 + 0: case 4 * 16 + 2: case 4 * 8 + 0: case 4 * 8 + 2: case 4 * 4 + 0: return cls;
+        default: return 0;
+    }
 }
 
 extern "C" int vd_conv_wgrad_group_class(const vd_wgrad_desc* desc) { return desc ? wgrad_group_class(*desc) : 0; }

@@ -55,12 +55,13 @@ class GraphedForward:
         torch.cuda.synchronize()
         self._keep = (ops._GEMM_WS.get(dev), getattr(unet, "_packed", None))     # buffers whose addresses are baked into the graph
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a HIP call from ANOTHER thread during capture (the RCCL watchdog of a DDP run whose rank 0 samples) must not abort it
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = unet._run_forward(self.x, self.t, save=False)[0]
 
     def _key(self):
         u = self.unet
-        return (u.conv_math, u.fuse_gn_inference, getattr(u, "fused_attention", None))
+        return (u.conv_math, u.fuse_gn_inference, getattr(u, "fused_attention", None), u.sample_size, u.in_channels, u.flat_param.data_ptr())
 
     def valid(self) -> bool:
         return self.key == self._key() and self._keep[0] is ops._GEMM_WS.get(self.unet.device)
@@ -82,10 +83,23 @@ def sampler_forward(unet, batch):
     if not use:
         return lambda x, t: unet(x, t, return_dict=False)[0]
     cache = unet.__dict__.setdefault("_fwd_graphs", {})
-    g = cache.get(batch)
+    g = cache.pop(batch, None)
     if g is None or not g.valid():
-        g = cache[batch] = GraphedForward(unet, batch)
+        g = None
+        while len(cache) >= MAX_CACHED_GRAPHS:            # each graph's private pool pins the peak memory of a no-grad forward: keep the newest few
+            cache.pop(next(iter(cache)))
+        g = GraphedForward(unet, batch)
+    cache[batch] = g                                      # (re-)inserted last: the dict is the LRU order
     return g
+
+
+MAX_CACHED_GRAPHS = 2
+
+
+def drop_sampler_graphs(unet):
+    """Release the captured forwards (and the memory pools they pin) -- called when training resumes after a periodic sampling() pass:
+    for the 256x256 models the pinned forward peak can otherwise make the next training step run out of memory."""
+    unet.__dict__.pop("_fwd_graphs", None)
 
 
 class DiffusionPipeline:

@@ -807,7 +807,7 @@ class UNet2DModel(nn.Module):
             # orders reuse on the allocating stream only.
             if self._wg_side is None:
                 self._wg_side = torch.cuda.Stream(device=self._dev)
-            main = torch.cuda.current_stream()
+            main = torch.cuda.current_stream(self._dev)
             self._wg_side.wait_stream(main)
             with torch.cuda.stream(self._wg_side):
                 for x, ws, ld in self._rs_jobs:
@@ -826,7 +826,7 @@ class UNet2DModel(nn.Module):
     def _wg_join(self):
         """The main stream waits for the side-stream weight gradients (before anything reads the flat gradient)."""
         if self._wg_keep:
-            torch.cuda.current_stream().wait_stream(self._wg_side)
+            torch.cuda.current_stream(self._dev).wait_stream(self._wg_side)
             self._wg_keep = []
 
     def _cs_flush(self):
@@ -863,6 +863,10 @@ class UNet2DModel(nn.Module):
         return self._wt_buf[off:off + M * Cc * T].view(Cc, M * T)
 
     def _prepare_backward(self, B):
+        # a backward pass that raised midway leaves queued weight-gradient / row-sum jobs behind: they must never run in THIS pass
+        if self._wg_keep:
+            self._wg_join()
+        self._wg_jobs, self._rs_jobs = {}, []
         if self._wt_buf is None:
             self._wt_buf = torch.empty(self._wt_total, device=self._dev, dtype=torch.float32)
         self._wt_fresh = set()
