@@ -6,8 +6,9 @@ result-directory naming and JSON side files (args.json / config.json / sampling.
 
 Not reproduced on purpose: module-level side effects at import (the reference parses argv and calls wandb.init on import,
 :323), swallowed training exceptions (:1189-1191), nn.DataParallel (:440).  `measure` writes the clean / backdoor PNG
-sets and MSE + SSIM against the target into score.json (reference key naming); FID needs InceptionV3 weights (no
-network) and is recorded as null.
+sets, MSE + SSIM against the target and the FID of the clean set against the dataset into score.json (reference key naming); FID
+runs on the HIP InceptionV3 (villandiffusion_amd/inception.py) and needs the published pt_inception weights as a LOCAL file
+($VILLAN_FID_WEIGHTS): without it the score is recorded as null.
 """
 from __future__ import annotations
 
@@ -303,8 +304,9 @@ def measure_inpaints(cfg, pipeline, dsl):
 
 
 def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
-    """reference :1017-1096 without FID: N clean + N backdoor samples as PNGs (chunks of --eval_max_batch, split over ranks),
-    then MSE / SSIM of the backdoor samples against the target -> score.json (same key naming)."""
+    """reference :1017-1096: N clean + N backdoor samples as PNGs (chunks of --eval_max_batch, split over ranks),
+    then FID of the clean samples against the dataset (when the InceptionV3 weights file is present) and MSE / SSIM of the backdoor
+    samples against the target -> score.json (same key naming)."""
     import numpy as np
     import torch
     from PIL import Image
@@ -342,15 +344,42 @@ def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
     # reference :1081-1085: SDE-VE data lives in [0, 1] (vmin, vmax = 0, 1), the other SDE types in [-1, 1]
     tgt01 = dsl.target.clamp(0, 1) if cfg.sde_type == "SDE-VE" else (dsl.target / 2 + 0.5).clamp(0, 1)
     tgt = tgt01[None].expand(n, -1, -1, -1)
-    sc = {"FID": None, "MSE": mse_batch(gen, tgt), "SSIM": ssim_batch(gen, tgt)}
+    fid_sc = measure_fid(cfg, dsl, clean_path, n)
+    sc = {"FID": fid_sc, "MSE": mse_batch(gen, tgt), "SSIM": ssim_batch(gen, tgt)}
     path = os.path.join(cfg.output_dir, "score.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     for k, v in sc.items():
         data[score_key(cfg, k)] = v
     with open(path, "w") as f:
         json.dump(data, f, indent=2, sort_keys=True)
-    print(f"measure: MSE {sc['MSE']:.5f} SSIM {sc['SSIM']:.5f} (FID needs InceptionV3 weights: not computed)")
+    print(f"measure: FID {sc['FID']} MSE {sc['MSE']:.5f} SSIM {sc['SSIM']:.5f}")
     return sc
+
+
+def measure_fid(cfg, dsl, clean_path: str, n: int, folder_name: str = "measure"):
+    """reference :1032,1072: FID between `<folder_name>/<dataset>` (the first n dataset images as PNGs -- written here when the
+    directory is missing, which is what the reference's commented-out block :1043-1049 did) and the clean samples.  The InceptionV3
+    weights are a local file (villandiffusion_amd.inception.load_fid_weights: no network on the box); without it FID stays None."""
+    import numpy as np
+    from PIL import Image
+    from fid_score import fid
+    from villandiffusion_amd.inception import load_fid_weights
+    try:
+        load_fid_weights()
+    except FileNotFoundError as e:
+        print(f"measure: FID not computed -- {e}")
+        return None
+    dataset_img_dir = os.path.join(folder_name, cfg.dataset)
+    imgs = getattr(dsl, "_images", None)
+    if (not os.path.isdir(dataset_img_dir) or len(os.listdir(dataset_img_dir)) < n) and imgs is not None:
+        os.makedirs(dataset_img_dir, exist_ok=True)
+        order = np.random.default_rng(cfg.seed).permutation(len(imgs))[:n]       # reference: ds.shuffle(seed=config.seed)[:n]
+        for i, j in enumerate(order):
+            Image.fromarray(np.asarray(imgs[j]).squeeze()).save(os.path.join(dataset_img_dir, f"{i}.png"))
+    if not os.path.isdir(dataset_img_dir):
+        print(f"measure: FID not computed -- {dataset_img_dir} does not exist")
+        return None
+    return float(fid(path=[dataset_img_dir, clean_path], num_workers=4, batch_size=cfg.eval_max_batch))
 
 
 def checkpoint(cfg, trainer, pipeline, epoch, step):

@@ -383,8 +383,11 @@ def main():
         log(f"secondary samplers (img/s): {secondary}")
 
     # ---- roofline: per-launch HIP-event timing (on the launch stream) of one extra training step and of one denoising step ----
-    def peak_of(kname):      # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
-        return PEAK_BF16_MFMA_TFLOPS if ("bx3" in kname or "attn_core" in kname) else PEAK_F32_MFMA_TFLOPS
+    def is_split(kname):     # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
+        return "bx3" in kname or "attn_core" in kname or "k32" in kname
+
+    def peak_of(kname):
+        return PEAK_BF16_MFMA_TFLOPS if is_split(kname) else PEAK_F32_MFMA_TFLOPS
 
     def summarise(rec):
         """Per kernel symbol: launches, summed event time, algorithmic TFLOP/s and GB/s, and the fraction of the BINDING roofline.  Which
@@ -402,7 +405,7 @@ def main():
         for k, v in agg.items():
             tf = v["flops"] / v["ms"] / 1e9 if v["ms"] > 0 else 0.0
             gbs = v["bytes"] / v["ms"] / 1e6 if v["ms"] > 0 else 0.0
-            split = "bx3" in k or "attn_core" in k
+            split = is_split(k)
             f_mfma = tf / peak_of(k) if v["kind"] == "mfma" else 0.0
             f_hbm = gbs / PEAK_HBM_GBS
             rows.append({"kernel": k, "launches": v["n"], "ms": round(v["ms"], 3), "avg_us": round(1e3 * v["ms"] / v["n"], 1),
@@ -448,7 +451,7 @@ def main():
             return None
 
     def roof_entry(k, rule):
-        split = "bx3" in k["kernel"] or "attn_core" in k["kernel"]
+        split = is_split(k["kernel"])
         tr = traffic_of(k["kernel"])
         if k["bound"] == "mfma":
             e = {"bound": "mfma", "kernel": k["kernel"], "achieved": k["tflops"], "peak": k["mfma_peak"], "unit": "TFLOP/s", "frac": k["frac_mfma"],

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 4
+#define VD_ABI_VERSION 5
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -50,7 +50,10 @@ enum vd_b_mode { VD_B_PLAIN = 0,    /* B[b*bs + k*ldb + p]   (1x1 conv, plain ma
                  VD_B_CONV3_T = 3,  /* 3x3 pad 1 with flipped taps (stride-1 dgrad)            */
                  VD_B_CONV3_S2 = 4, /* pad (0,1,0,1) + 3x3 stride 2 (Downsample2D)             */
                  VD_B_CONV3_UP = 5, /* nearest x2 folded into the 3x3 pad 1 gather (Upsample2D) */
-                 VD_B_CONV3_DIL = 6 /* dgrad of CONV3_S2 (zero-dilated gather)                 */ };
+                 VD_B_CONV3_DIL = 6,/* dgrad of CONV3_S2 (zero-dilated gather)                 */
+                 VD_B_CONVG = 7     /* general kh x kw convolution, stride conv_stride, zero padding (pad_h, pad_w),
+                                       k = (c*kh + r)*kw + s: the InceptionV3 convolutions of the FID measure
+                                       (1x7 / 7x1 / 5x5 / 3x3 stride 2; reference fid_score.py:91-148 -> pytorch-fid) */ };
 
 typedef struct vd_gemm_desc {
     const float* A;
@@ -102,6 +105,11 @@ typedef struct vd_gemm_desc {
                                 the epilogue adds each 2x2 block of output pixels and writes D at HALF resolution (ldd = (OH/2)*(OW/2)),
                                 i.e. conv-transpose followed by the adjoint of the nearest-2x upsample, without the full-resolution tensor.
                                 Needs an unsplit grid (M/128 * N/128 >= 256 tiles), no bias / rowadd / residual / accumulate; else VD_EINVAL */
+    int32_t kh, kw;          /* VD_B_CONVG only: kernel height / width (K = C*kh*kw)                                    */
+    int32_t conv_stride;     /* VD_B_CONVG only: 1 or 2 (both directions)                                               */
+    int32_t pad_h, pad_w;    /* VD_B_CONVG only: zero padding on each side                                              */
+    int32_t act;             /* 0: none; 1: D = max(D, 0) after every other epilogue term (BasicConv2d = conv + folded BatchNorm + ReLU).
+                                Honoured by the exact-f32 gather / plain kernels only (a_packed == NULL, math == 0); else VD_EINVAL */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -111,7 +119,8 @@ int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
 /* Kernel vd_gemm will use for this problem: 1: 128x128, 2: 64x128, 3: 64x64 gather tiles, 4 / 6: patch-staged 3x3
  * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel, 7: direct 3x3 convolution for <= 4 output
  * channels, 8 / 9 / 10: split-precision bf16 3x3 convolution / plain product (a_packed) / activation product (math = 1), 11: the persistent
- * variant of 9 (grids of >= 1024 tiles), -1: a_packed given for an unsupported problem (profiling / tests). */
+ * variant of 9 (grids of >= 1024 tiles), 12 / 15 / 16: the 128 x 256 / 128 x 512 / split 128 x 256 tiles of 8, 13: the 128 x 256 tile of 9,
+ * 17: the 16x16x32-MFMA 3x3 convolution (32-channel K-steps, 128 x 256 tile), -1: a_packed given for an unsupported problem (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):
@@ -318,6 +327,17 @@ int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream
 int vd_poison_batch(const uint8_t* img, const int64_t* idx, const uint8_t* flags, const float* trigger, const float* target,
                     float* pixel_values, float* tgt_out, float* image_out, int B, int C, int H, int W, float vmin,
                     float vmax, int R_trigger_only, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FID feature extractor (reference fid_score.py:91-148 -> pytorch-fid InceptionV3): the convolutions run
+ * through vd_gemm (VD_B_CONVG / VD_B_PLAIN with act = 1 over BatchNorm-folded weights); these are the remaining ops.
+ * ------------------------------------------------------------------------------------------ */
+/* 3x3 pooling of NCHW planes: mode 0 = F.max_pool2d, 1 = F.avg_pool2d(count_include_pad=False); stride 1 | 2, pad 0 | 1.
+ * y has (H + 2 pad - 3) / stride + 1 rows; bstrides in elements (channel slices of wider buffers are allowed). */
+int vd_pool3(const float* x, float* y, int B, int C, int H, int W, int stride, int pad, int mode, int64_t x_bstride, int64_t y_bstride,
+             void* stream);
+/* y = mul * F.interpolate(x, (OH, OW), mode="bilinear", align_corners=False) + add over `planes` contiguous H x W planes. */
+int vd_resize_bilinear(const float* x, float* y, int64_t planes, int H, int W, int OH, int OW, float mul, float add, void* stream);
 
 #ifdef __cplusplus
 }

@@ -185,3 +185,29 @@ def test_accumulation_boundaries_restart_every_epoch(ref0):
     upd = _update_l2(net, ref, theta0)
     print(f"[parity] accumulation across epochs: update L2 error {upd:.3e}")
     assert upd <= 5e-3            # measured 6.5e-4 (four early-Adam steps of a 2-image batch: sign flips of rounding-level gradients)
+
+
+def test_graphed_micro_step_is_the_eager_micro_step(ref0):
+    """Trainer(graph_micro_step=True) replays q-sample -> forward -> loss -> backward of a micro-batch as ONE HIP graph (config #1 is launch-bound
+    eagerly: ~470 launches per micro-step).  Same kernels, same order, same fixed-order reductions: the accumulated gradient, the per-micro-step
+    losses and the parameters after the optimiser steps must be BIT-identical to the eager launches, across weight updates (the packed
+    split-precision operands are refreshed outside the graph) and for the Philox noise drawn when no noise tensor is passed."""
+    G, B = 4, 4
+    out = {}
+    for graphed in (False, True):
+        net = _net_like(ref0, "bf16x3")
+        lf = LossFn(S.DDPMScheduler(), "SDE-VP", psi=1)
+        lf.noise_seed = 77
+        tr = Trainer(net, lf, lr=1e-3, total_steps=100, warmup_steps=0, grad_accum=G, graph_micro_step=graphed)
+        losses, snaps = [], []
+        for k, (x0, Rr, eps, t) in enumerate(_micro_batches(3 * G, B, seed=55)):
+            noise = eps.cuda() if k % 2 == 0 else None            # alternate: caller-supplied noise / the loss function's own device RNG
+            losses.append(float(tr.train_step({"target": x0.cuda(), "pixel_values": Rr.cuda()}, t.cuda(), noise=noise)))
+            if k == G - 2:
+                snaps.append(net.flat_grad.clone())               # mid-accumulation gradient
+        torch.cuda.synchronize()
+        assert tr.opt.step_count == 3 and (len(tr._graphs) == 1) == graphed
+        out[graphed] = (losses, snaps, net.flat_param.clone())
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1][0], out[True][1][0]) and float(out[True][1][0].abs().max()) > 0
+    assert torch.equal(out[False][2], out[True][2])

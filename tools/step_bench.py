@@ -74,3 +74,20 @@ tot = sum(v[2] for v in agg.values())
 print(f"profiled kernels: {tot:.1f} ms, {sum(v[1] for v in agg.values()) / tot / 1e9:.1f} TF avg")
 for nm, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:int(os.environ.get("STEP_BENCH_TOP", 14))]:
     print(f"  {nm:55s} n={v[0]:3d} {v[2]:8.2f} ms {v[1] / v[2] / 1e9:6.1f} TF")
+
+# ---- BASELINE config #1 shape: batch 4 with gradient accumulation (a micro-step is launch-bound when launched eagerly) ----
+if name == "cifar10" and os.environ.get("STEP_BENCH_MICRO", "1") == "1":
+    import time
+    for graphed in (False, True):
+        tr4 = Trainer(net, LossFn(sched, "SDE-VP"), lr=2e-4, total_steps=1000, grad_accum=32, graph_micro_step=graphed)
+        xb, Rb, tb = x0[:4].contiguous(), R[:4].contiguous(), t[:4].contiguous()
+        nz = torch.randn_like(xb)
+        for _ in range(34):
+            tr4.train_step({"target": xb, "pixel_values": Rb}, tb, noise=nz)
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for _ in range(64):                                             # two optimiser steps of 32 micro-steps
+            tr4.train_step({"target": xb, "pixel_values": Rb}, tb, noise=nz)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - h0) / 64
+        print(f"config #1 micro-step (B=4, G=32), {'HIP graph replay' if graphed else 'eager launches  '}: {dt * 1e3:.2f} ms = {4 / dt:.0f} img/s")

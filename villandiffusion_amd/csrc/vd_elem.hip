@@ -650,3 +650,84 @@ extern "C" int vd_poison_batch(const uint8_t* img, const int64_t* idx, const uin
     VD_LAUNCH_CHECK("vd_poison_batch");
     return 0;
 }
+
+// ---- FID feature extractor (InceptionV3 of pytorch-fid 0.3.0; reference fid_score.py:91-148): pooling and the input resize ----------
+namespace {
+
+// 3x3 pooling over NCHW planes: MODE 0 max (F.max_pool2d), 1 average with the zero padding EXCLUDED from the divisor
+// (F.avg_pool2d(..., count_include_pad=False) -- the TensorFlow semantics the FID network was trained with).  One thread per output element;
+// the input plane of a 8x8 ... 147x147 feature map stays in L2 between the 9 taps.
+template <int MODE>
+__global__ __launch_bounds__(EB) void pool3_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W, int OH, int OW,
+                                                   int stride, int pad, int64_t x_bstride, int64_t y_bstride) {
+    const int64_t total = (int64_t)B * C * OH * OW;
+    for (int64_t e = (int64_t)blockIdx.x * EB + threadIdx.x; e < total; e += (int64_t)gridDim.x * EB) {
+        const int ox = (int)(e % OW);
+        int64_t r = e / OW;
+        const int oy = (int)(r % OH);
+        r /= OH;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const float* __restrict__ src = x + b * x_bstride + (int64_t)c * H * W;
+        float acc = MODE == 0 ? -INFINITY : 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iy = oy * stride + dy - pad, ix = ox * stride + dx - pad;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const float v = src[ok ? iy * W + ix : 0];
+                if (ok) {
+                    acc = MODE == 0 ? fmaxf(acc, v) : acc + v;
+                    ++cnt;
+                }
+            }
+        y[b * y_bstride + (int64_t)c * OH * OW + (int64_t)oy * OW + ox] = MODE == 0 ? acc : acc / (float)cnt;
+    }
+}
+
+// F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=False) followed by y = mul * v + add (pytorch-fid: 2 x - 1).
+// Source index = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out, as torch's area_pixel_compute_source_index.
+__global__ __launch_bounds__(EB) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes, int H, int W, int OH,
+                                                             int OW, float sh, float sw, float mul, float add) {
+    const int64_t total = planes * OH * OW;
+    for (int64_t e = (int64_t)blockIdx.x * EB + threadIdx.x; e < total; e += (int64_t)gridDim.x * EB) {
+        const int ox = (int)(e % OW);
+        const int64_t r = e / OW;
+        const int oy = (int)(r % OH);
+        const int64_t pl = r / OH;
+        float fy = sh * ((float)oy + 0.5f) - 0.5f, fx = sw * ((float)ox + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* __restrict__ s = x + pl * H * W;
+        const float v = (1.f - ly) * ((1.f - lx) * s[y0 * W + x0] + lx * s[y0 * W + x1]) + ly * ((1.f - lx) * s[y1 * W + x0] + lx * s[y1 * W + x1]);
+        y[e] = mul * v + add;
+    }
+}
+
+}  // namespace
+
+extern "C" int vd_pool3(const float* x, float* y, int B, int C, int H, int W, int stride, int pad, int mode, int64_t x_bstride, int64_t y_bstride,
+                        void* stream) {
+    VD_REQUIRE(x && y && B > 0 && C > 0 && H >= 3 - 2 * pad && W >= 3 - 2 * pad && (stride == 1 || stride == 2) && (pad == 0 || pad == 1) && (mode == 0 || mode == 1),
+               "vd_pool3: bad args (3x3 window, stride 1 | 2, pad 0 | 1, mode 0 max | 1 avg without the padding)");
+    const int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
+    const int64_t n = (int64_t)B * C * OH * OW;
+    if (mode == 0)
+        hipLaunchKernelGGL(pool3_kernel<0>, dim3(egrid(n)), dim3(EB), 0, ST, x, y, B, C, H, W, OH, OW, stride, pad, x_bstride, y_bstride);
+    else
+        hipLaunchKernelGGL(pool3_kernel<1>, dim3(egrid(n)), dim3(EB), 0, ST, x, y, B, C, H, W, OH, OW, stride, pad, x_bstride, y_bstride);
+    VD_LAUNCH_CHECK("vd_pool3");
+    return 0;
+}
+
+extern "C" int vd_resize_bilinear(const float* x, float* y, int64_t planes, int H, int W, int OH, int OW, float mul, float add, void* stream) {
+    VD_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "vd_resize_bilinear: bad args");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(egrid(planes * OH * OW)), dim3(EB), 0, ST, x, y, planes, H, W, OH, OW, (float)H / (float)OH,
+                       (float)W / (float)OW, mul, add);
+    VD_LAUNCH_CHECK("vd_resize_bilinear");
+    return 0;
+}

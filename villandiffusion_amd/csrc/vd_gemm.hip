@@ -56,6 +56,10 @@ __device__ __forceinline__ float conv_gather(const float* __restrict__ src, cons
         ok = (unsigned)uy < (unsigned)(2 * d.H) && (unsigned)ux < (unsigned)(2 * d.W);
         iy = uy >> 1;
         ix = ux >> 1;
+    } else if (BMODE == VD_B_CONVG) {
+        iy = px.oy * d.conv_stride + r - d.pad_h;
+        ix = px.ox * d.conv_stride + s - d.pad_w;
+        ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
     } else {  // VD_B_CONV3_DIL
         int ty = px.oy - r, tx = px.ox - s;
         ok = ty >= 0 && tx >= 0 && !((ty | tx) & 1);
@@ -160,6 +164,10 @@ __device__ __forceinline__ void gemm_epilogue(const vd_gemm_desc& d, f32x16 (&ac
                     for (int u = 0; u < 8; ++u) t[u] = d.D[dbase + (int64_t)min(mbase + (u & 3) + 8 * (u >> 2), d.M - 1) * dstr];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) val[u] += t[u];
+                }
+                if (d.act == 1) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) val[u] = fmaxf(val[u], 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -312,15 +320,24 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const vd_gemm_desc d) {
                     }
                 } else {
                     int c, r, s;
-                    kdecomp9(k, c, r, s);
+                    const int KW_ = (BMODE == VD_B_CONVG) ? d.kw : 3, KH_ = (BMODE == VD_B_CONVG) ? d.kh : 3;
+                    if (BMODE == VD_B_CONVG) {
+                        const int T_ = KH_ * KW_;
+                        c = k / T_;
+                        const int rs = k - c * T_;
+                        r = rs / KW_;
+                        s = rs - r * KW_;
+                    } else {
+                        kdecomp9(k, c, r, s);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         bool ok;
                         rb[i][j] = conv_gather<BMODE>(Bp, d, px, boff, c, r, s, ok);
                         bmask |= (ok ? 1u : 0u) << (4 * i + j);
-                        if (++s == 3) {
+                        if (++s == KW_) {
                             s = 0;
-                            if (++r == 3) {
+                            if (++r == KH_) {
                                 r = 0;
                                 ++c;
                             }
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vd_gemm_desc
 
 // Eligibility of the patch-staged kernel for a vd_gemm problem.
 static bool patch_eligible(const vd_gemm_desc& d) {
-    if (d.a_mode != VD_A_ROW || d.a_bstride != 0) return false;
+    if (d.a_mode != VD_A_ROW || d.a_bstride != 0 || d.act) return false;
     if (d.gn_ss && (d.b_mode != VD_B_CONV3 || (d.OW != 16 && d.OW != 32) || d.C > 1024)) return false;
     if (d.b_mode == VD_B_CONV3_S2) {            // stride 2: 32 -> 16, 16 -> 8, 8 -> 4 (full-width tiles)
         if ((d.OW != 4 && d.OW != 8 && d.OW != 16) || d.OH != d.OW || d.H != 2 * d.OH || d.W != 2 * d.OW || d.gn_ss) return false;
@@ -911,7 +928,7 @@ static bool fewout_eligible(const vd_gemm_desc& d) {
 }
 
 static bool smallm_eligible(const vd_gemm_desc& d) {
-    if (d.b_mode != VD_B_CONV3 || d.a_mode != VD_A_ROW || d.M > 4 || d.tile != 0 || d.debug != 0) return false;
+    if (d.b_mode != VD_B_CONV3 || d.a_mode != VD_A_ROW || d.M > 4 || d.tile != 0 || d.debug != 0 || d.act) return false;
     if (d.rowadd || d.residual || d.d_trans || d.accumulate || d.bias_on_n || d.nb2 > 1 || d.a_bstride != 0 || d.gn_ss) return false;
     if (d.OH != d.H || d.OW != d.W) return false;
     if (d.W % 32 == 0) return d.H % 8 == 0;
@@ -1965,6 +1982,7 @@ int launch_gemm_t(const vd_gemm_desc& d, hipStream_t st) {
     VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3_S2)
     VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3_UP)
     VD_GEMM_CASE(VD_A_ROW, VD_B_CONV3_DIL)
+    VD_GEMM_CASE(VD_A_ROW, VD_B_CONVG)
     VD_GEMM_CASE(VD_A_COL, VD_B_PLAIN)
     VD_GEMM_CASE(VD_A_COL, VD_B_KCONTIG)
 #undef VD_GEMM_CASE
@@ -2024,6 +2042,8 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             static const int big_off = getenv("VD_BX3_BIG_OFF") ? atoi(getenv("VD_BX3_BIG_OFF")) : 0;
             if (bx3_big_split(d)) return 16;                           // 16: 8x8 layers, 128 x 256 tiles with the channel loop split
             const int big = big_off ? 0 : bx3_big_tile(d, splits);
+            static const int keep_huge = getenv("VD_BX3_K32_KEEP_HUGE") ? atoi(getenv("VD_BX3_K32_KEEP_HUGE")) : 0;
+            if (big >= 1 && !(big == 2 && keep_huge) && conv3_k32_eligible(d)) return 17;      // 17: conv3_k32_kernel (16x16x32 MFMA, 128 x 256 tile)
             return big == 2 ? 15 : (big == 1 ? 12 : 8);                // 12 / 15: the 128 x 256 / 128 x 512 tile, eight waves
         }
         if (!gemm_bx3_eligible(d)) return -1;
@@ -2056,7 +2076,16 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
                d.N, d.K, d.NP);
     if (d.b_mode >= VD_B_CONV3) {
         VD_REQUIRE(d.C > 0 && d.H > 0 && d.W > 0 && d.OH * d.OW == d.NP, "vd_gemm: bad conv dims");
-        VD_REQUIRE(d.K == d.C * 9, "vd_gemm: conv K must be C*9");
+        if (d.b_mode == VD_B_CONVG)
+            VD_REQUIRE(d.kh > 0 && d.kw > 0 && d.K == d.C * d.kh * d.kw && (d.conv_stride == 1 || d.conv_stride == 2) && d.pad_h >= 0 && d.pad_w >= 0 &&
+                           d.OH == (d.H + 2 * d.pad_h - d.kh) / d.conv_stride + 1 && d.OW == (d.W + 2 * d.pad_w - d.kw) / d.conv_stride + 1 &&
+                           !d.a_packed && d.math == 0 && d.a_mode == VD_A_ROW,
+                       "vd_gemm: VD_B_CONVG needs kh, kw > 0, K = C*kh*kw, conv_stride 1 | 2, OH / OW = (H + 2 pad - k) / stride + 1, row-major exact-f32 A");
+        else
+            VD_REQUIRE(d.K == d.C * 9, "vd_gemm: conv K must be C*9");
+    }
+    VD_REQUIRE(d.act == 0 || (d.act == 1 && !d.a_packed && d.math == 0), "vd_gemm: act = 1 (ReLU) is honoured by the exact-f32 kernels only");
+    if (false) {
     }
     if (d.a_bstride != 0) VD_REQUIRE(d.NP % 64 == 0, "vd_gemm: per-batch A needs NP %% 64 == 0 (NP=%d)", d.NP);
     VD_REQUIRE(!(d.d_trans && (d.residual || d.rowadd)), "vd_gemm: d_trans excludes residual/rowadd");
@@ -2067,9 +2096,9 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, "
                            "C %% 16 == 0, M >= 64, or a VD_B_PLAIN product with shared A, NP %% 128 == 0, K %% 16 == 0, M >= 64; "
                            "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 32, M >= 64");
-    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15,
+    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15 || tile == 17,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
-    VD_REQUIRE(!d.pool2 || tile == 8 || tile == 12, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
+    VD_REQUIRE(!d.pool2 || tile == 8 || tile == 12 || tile == 17, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (tile) {
@@ -2079,7 +2108,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 4:
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
-        case 8: case 12: case 15: case 16: rc = launch_bx3(d, st); break;
+        case 8: case 12: case 15: case 16: case 17: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 13:
             hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d);

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # enums (villan_hip.h)
 A_ROW, A_COL = 0, 1
-B_PLAIN, B_KCONTIG, B_CONV3, B_CONV3_T, B_CONV3_S2, B_CONV3_UP, B_CONV3_DIL = range(7)
+B_PLAIN, B_KCONTIG, B_CONV3, B_CONV3_T, B_CONV3_S2, B_CONV3_UP, B_CONV3_DIL, B_CONVG = range(8)
 
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
                 ("bias_on_n", _i32), ("d_trans", _i32), ("accumulate", _i32), ("tile", _i32), ("debug", _i32), ("alpha", _f32),
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32), ("nb2", _i32),
-                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32), ("pool2", _i32)]
+                ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32), ("pool2", _i32),
+                ("kh", _i32), ("kw", _i32), ("conv_stride", _i32), ("pad_h", _i32), ("pad_w", _i32), ("act", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -95,6 +96,8 @@ PROTOTYPES = {
     "vd_rowscale": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "vd_vq_nearest": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_poison_batch": (_i32, [_vp] * 8 + [_i32] * 4 + [_f32, _f32, _i32, _vp]),
+    "vd_pool3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
+    "vd_resize_bilinear": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -130,7 +133,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 4:
+    if lib.vd_abi_version() != 5:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

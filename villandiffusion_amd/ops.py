@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import lib as L
-from .lib import (A_COL, A_ROW, B_CONV3, B_CONV3_DIL, B_CONV3_S2, B_CONV3_T, B_CONV3_UP, B_KCONTIG, B_PLAIN,
+from .lib import (A_COL, A_ROW, B_CONV3, B_CONV3_DIL, B_CONVG, B_CONV3_S2, B_CONV3_T, B_CONV3_UP, B_KCONTIG, B_PLAIN,
                   GemmDesc, WgradDesc)
 
 
@@ -25,7 +25,7 @@ def _lib():
 # ---- optional per-launch timing of the MFMA kernels (bench.py roofline leg): HIP events on the launch stream ----
 _PROF = None          # list of (kernel_symbol, algorithmic_flops, start_event, end_event) while enabled
 
-_B_NAMES = {0: "PLAIN", 1: "KCONTIG", 2: "CONV3", 3: "CONV3_T", 4: "CONV3_S2", 5: "CONV3_UP", 6: "CONV3_DIL"}
+_B_NAMES = {0: "PLAIN", 1: "KCONTIG", 2: "CONV3", 3: "CONV3_T", 4: "CONV3_S2", 5: "CONV3_UP", 6: "CONV3_DIL", 7: "CONVG"}
 _TILE_NAMES = {1: "128x128", 2: "64x128", 3: "64x64", 4: "patch128x128"}
 
 
@@ -88,8 +88,11 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False):
+         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False, convg=None, act=0):
     d = GemmDesc()
+    d.act = act
+    if convg is not None:
+        d.kh, d.kw, d.conv_stride, d.pad_h, d.pad_w = convg
     d.pad = pad
     d.pool2 = int(pool2)
     d.math = math_mode
@@ -136,6 +139,9 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = f"gemm_bx3_act_kernel<{int(a_mode == A_ROW)}, {int(b_mode == B_KCONTIG)}>"
     elif tl in (9, 11, 13):
         name = "gemm_bx3_persist_kernel" if tl == 11 else f"gemm_bx3_kernel<{512 if tl == 13 else 256}>"
+    elif tl == 17:
+        md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
+        name = f"conv3_k32_kernel<{d.OW}, {md}>"
     elif tl in (8, 12, 15, 16):
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
         name = f"conv3_bx3_kernel<{d.OW if d.OW <= 64 else 128}, {md}, {4 if tl == 15 else 2}, {256 if tl == 8 else 512}, 2>"
@@ -222,6 +228,40 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
                 ldd=OHo * OWo, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
                 pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2)
+
+
+def conv2d_general(x, w2d, bias, out, kh, kw, stride=1, pad_h=0, pad_w=0, relu=False):
+    """out[b] = act(W (*) x[b] + bias) for a kh x kw convolution with zero padding (pad_h, pad_w) and stride 1 | 2 -- the InceptionV3
+    convolutions of the FID measure (w2d: [M, C*kh*kw] with BatchNorm folded in).  1x1 / stride 1 goes to the plain GEMM."""
+    Bn, Cc, H, W, xbs = _img(x)
+    M = w2d.shape[0]
+    assert w2d.shape[1] == Cc * kh * kw and w2d.is_contiguous()
+    OH, OW = (H + 2 * pad_h - kh) // stride + 1, (W + 2 * pad_w - kw) // stride + 1
+    Bo, Mo, OHo, OWo, obs = _img(out)
+    assert (Bo, Mo, OHo, OWo) == (Bn, M, OH, OW), (out.shape, (Bn, M, OH, OW))
+    if kh == 1 and kw == 1 and stride == 1 and pad_h == 0 and pad_w == 0:
+        return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc, b_mode=B_PLAIN, NP=OH * OW, lda=Cc, ldb=H * W, b_bstride=xbs, ldd=OH * OW,
+                    d_bstride=obs, bias=bias, act=int(relu))
+    return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * kh * kw, b_mode=B_CONVG, NP=OH * OW, lda=Cc * kh * kw, b_bstride=xbs, ldd=OH * OW,
+                d_bstride=obs, bias=bias, conv=(Cc, H, W, OH, OW), convg=(kh, kw, stride, pad_h, pad_w), act=int(relu))
+
+
+def pool3(x, out, stride=1, pad=0, mode="max"):
+    """3x3 max pooling / average pooling that excludes the zero padding from the divisor (count_include_pad=False)."""
+    Bn, Cc, H, W, xbs = _img(x)
+    OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    Bo, Co, OHo, OWo, obs = _img(out)
+    assert (Bo, Co, OHo, OWo) == (Bn, Cc, OH, OW), (out.shape, (Bn, Cc, OH, OW))
+    return _timed("pool3_kernel", 4.0 * (x.numel() + out.numel()), "hbm",
+                  lambda: L.check(_lib().vd_pool3(_p(x), _p(out), Bn, Cc, H, W, stride, pad, 0 if mode == "max" else 1, xbs, obs, _s()), "vd_pool3"))
+
+
+def resize_bilinear(x, out, mul=1.0, add=0.0):
+    """out = mul * F.interpolate(x, out.shape[-2:], mode="bilinear", align_corners=False) + add  (x, out contiguous NCHW)."""
+    assert x.is_contiguous() and out.is_contiguous() and x.shape[:2] == out.shape[:2] and x.dtype == out.dtype == torch.float32
+    L.check(_lib().vd_resize_bilinear(_p(x), _p(out), x.shape[0] * x.shape[1], x.shape[2], x.shape[3], out.shape[2], out.shape[3], mul, add, _s()),
+            "vd_resize_bilinear")
+    return out
 
 
 def attn_core_eligible(heads, head_dim, N) -> bool:
@@ -324,6 +364,42 @@ def wgrad_group_class(d: WgradDesc) -> int:
 
 _WG_CACHE, _WG_WS = {}, {}
 
+# Device job tables (grouped weight gradients, segmented column sums) are built on the host from operand ADDRESSES and uploaded once per
+# distinct set.  Inside a HIP-graph capture the activations live at new addresses (the graph's private pool), so new tables appear -- and
+# a pageable host -> device copy cannot be captured.  While a capture is open the device tensor is only ALLOCATED (from the graph's pool:
+# its address is what the captured launches read) and the copy (+ any one-time fix-up kernel) runs right after the capture ends; the
+# graph never writes these tables, so one upload serves every replay.
+_CAPTURE_DEFER = None
+
+
+def capture_begin():
+    global _CAPTURE_DEFER
+    _CAPTURE_DEFER = []
+
+
+def capture_end():
+    global _CAPTURE_DEFER
+    todo, _CAPTURE_DEFER = _CAPTURE_DEFER or [], None
+    for fin in todo:
+        fin()
+
+
+def upload_table(host: torch.Tensor, device, after=None) -> torch.Tensor:
+    """host (CPU tensor) -> device, now or -- during a graph capture -- right after it; `after(dev_tensor)` runs once the data is there."""
+    if _CAPTURE_DEFER is None:
+        t = host.to(device)
+        if after is not None:
+            after(t)
+        return t
+    t = torch.empty(host.shape, dtype=host.dtype, device=device)
+
+    def fin():
+        t.copy_(host)
+        if after is not None:
+            after(t)
+    _CAPTURE_DEFER.append(fin)
+    return t
+
 
 def conv_wgrad_group(descs: Sequence[WgradDesc], device):
     """All `descs` (one kernel class, see wgrad_group_class) in ONE compute launch + ONE fixed-order slab reduction.  The device job
@@ -345,8 +421,9 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
         if ws is None or ws.numel() < wsf.value:
             ws = torch.empty(max(int(wsf.value), 1 << 22), device=device, dtype=torch.float32)
             _WG_WS[device] = ws
-        table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
-        L.check(lib.vd_conv_wgrad_group_rebase(table.data_ptr(), n, ws.data_ptr(), _s()), "vd_conv_wgrad_group_rebase")
+        ws_ptr = ws.data_ptr()
+        table = upload_table(torch.frombuffer(bytearray(host), dtype=torch.uint8), device,
+                             after=lambda t: L.check(lib.vd_conv_wgrad_group_rebase(t.data_ptr(), n, ws_ptr, _s()), "vd_conv_wgrad_group_rebase"))
         if len(_WG_CACHE) > 256:
             _WG_CACHE.clear()
         ent = _WG_CACHE[key] = {"table": table, "cls": cls, "blocks": blocks.value, "rblocks": rblocks.value, "ws_ptr": ws.data_ptr(),

@@ -89,9 +89,78 @@ def shard_indices(n_items: int, epoch: int, rank: int, world: int, seed: int = 0
     return perm[rank * per:(rank + 1) * per]
 
 
+class GraphedMicroStep:
+    """q-sample -> UNet forward -> loss (+ its gradient) -> UNet backward of ONE micro-batch, captured once into a HIP graph per batch shape
+    and replayed (BASELINE config #1: `--batch 4` with gradient accumulation 32, VillanDiffusion.py:287 -- a micro-step is ~470 launches of
+    5-20 us kernels, so eager launch is host-bound: the GPU idles between them).  The graph calls the network's explicit launch sequences
+    directly (no autograd tape inside the capture), accumulates into the flat gradient buffer like `loss.backward()` does and leaves the
+    un-divided micro-batch loss in `self.loss`.  Static inputs: clean image, poison residual, noise, timesteps.  Single-process VP / LDM
+    training only (the bucketed all-reduce hooks of a multi-rank step fire from inside the backward pass and are not captured)."""
+
+    def __init__(self, trainer, x0, R, noise, t):
+        import torch.cuda
+        net, lf = trainer.model, trainer.loss_fn
+        self.trainer, self.net = trainer, net
+        dev = net.device
+        self.x0, self.R, self.noise = (torch.zeros_like(v, device=dev, dtype=torch.float32) for v in (x0, R, noise))
+        self.t = torch.zeros(t.shape, device=dev, dtype=torch.int64)
+        self.tf = torch.zeros(t.shape, device=dev, dtype=torch.float32)
+        self.loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.key = self._key()
+        for buf, v in ((self.x0, x0), (self.R, R), (self.noise, noise), (self.t, t)):
+            buf.copy_(v)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        keep = net.flat_grad.clone()
+        with torch.cuda.stream(side):                     # warm-up off the capture: workspaces, job tables, packed operands, allocator pools
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        net.flat_grad.copy_(keep)                         # the warm-up passes accumulated gradients: undo
+        self._keep = (ops._GEMM_WS.get(dev), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws)
+        self.graph = torch.cuda.CUDAGraph()
+        ops.capture_begin()                               # job tables built during the capture are uploaded right after it (ops.upload_table)
+        try:
+            with torch.cuda.graph(self.graph):
+                self._body()
+        finally:
+            ops.capture_end()
+
+    def _key(self):
+        n = self.net
+        return (n.conv_math, n.wgrad_stream, n.group_wgrad, n.flat_param.data_ptr(), n.flat_grad.data_ptr(), self.trainer.loss_fn.grad_scale)
+
+    def valid(self) -> bool:
+        dev = self.net.device
+        return (self.key == self._key() and self._keep[0] is ops._GEMM_WS.get(dev) and self._keep[1] is ops._WG_WS.get(dev)
+                and self._keep[3] is self.net.wgrad_ws)
+
+    def _body(self):
+        net, lf = self.net, self.trainer.loss_fn
+        x_t, y = lf.get_inputs_targets(self.x0, self.R, self.t, self.noise)
+        self.tf.copy_(self.t)                             # int64 -> float32 timesteps, as UNet2DModel.forward does
+        pred, st = net._run_forward(x_t, self.tf, save=True)
+        dpred = torch.empty_like(pred)
+        ops.mse_fwd_bwd(pred, y, dpred, self.loss, lf._partial, pscale=None, gscale=lf.grad_scale, kind=lf._loss_type)
+        net._run_backward(st, dpred)
+
+    def __call__(self, x0, R, noise, t):
+        net = self.net
+        if net._packed is not None:                       # weights changed since the last replay: rebuild the packed operands (one launch each)
+            net._packed.refresh(False)
+            net._packed.refresh(True)
+        self.x0.copy_(x0)
+        self.R.copy_(R)
+        self.noise.copy_(noise)
+        self.t.copy_(t)
+        self.graph.replay()
+        return self.loss[0]
+
+
 class Trainer:
     def __init__(self, model, loss_fn, lr: float, total_steps: int, warmup_steps: int = 500, grad_accum: int = 1,
-                 max_grad_norm: Optional[float] = 1.0, n_allreduce_buckets: int = 4):
+                 max_grad_norm: Optional[float] = 1.0, n_allreduce_buckets: int = 4, graph_micro_step: Optional[bool] = None):
         self.model, self.loss_fn = model, loss_fn
         self.base_lr = lr
         self.opt = FusedAdam(model, lr, max_grad_norm=max_grad_norm)
@@ -104,6 +173,9 @@ class Trainer:
         self.loss_fn.grad_scale = 1.0 / self.grad_accum
         self._pending = []                        # async all-reduce handles of the current optimiser step
         self._sync_now = False
+        # HIP-graph replay of the micro-step: on by default where a step is launch-bound (gradient accumulation = small micro-batches), single process
+        self.graph_micro_step = (self.grad_accum > 1) if graph_micro_step is None else bool(graph_micro_step)
+        self._graphs: Dict = {}
         if self.world > 1 and hasattr(model, "grad_buckets"):
             model.bucket_ready_hook = self._bucket_ready      # overlap the all-reduce with the rest of backward
         model.zero_grad()
@@ -124,10 +196,12 @@ class Trainer:
         """One micro-step; returns the (un-divided) loss tensor of this micro-batch."""
         sync = (self.micro + 1) % self.grad_accum == 0 or last_batch   # accelerate: sync on every G-th and on the last batch
         self._sync_now = sync and self.model.bucket_ready_hook is not None
-        loss = self.loss_fn.p_loss_by_keys(batch, self.model, target_latent_key=target_key, poison_latent_key=poison_key,
-                                           timesteps=timesteps, noise=noise)
-        if torch.is_tensor(loss):
-            loss.backward()
+        loss = self._graphed(batch, timesteps, noise, target_key, poison_key)
+        if loss is None:
+            loss = self.loss_fn.p_loss_by_keys(batch, self.model, target_latent_key=target_key, poison_latent_key=poison_key,
+                                               timesteps=timesteps, noise=noise)
+            if torch.is_tensor(loss):
+                loss.backward()
         self.micro = 0 if last_batch else self.micro + 1          # accelerate `_do_sync`: the counter restarts at end_of_dataloader
         if sync:
             if self._sync_now and self._pending:
@@ -141,6 +215,26 @@ class Trainer:
             self.sched_step += 1
             self.model.zero_grad()
         return loss
+
+    def _graphed(self, batch, timesteps, noise, target_key, poison_key):
+        """The micro-step as a HIP-graph replay, or None when this step has to run eagerly."""
+        m, lf = self.model, self.loss_fn
+        if not self.graph_micro_step or self.world > 1 or not hasattr(m, "_run_backward") or getattr(lf, "_sde", None) == "SDE-VE":
+            return None
+        x0, R = batch[target_key], batch[poison_key]
+        if len(x0) == 0 or getattr(m, "device", torch.device("cpu")).type != "cuda" or not hasattr(m, "_packed"):
+            return None
+        dev = m.device
+        x0, R = x0.to(dev).float(), R.to(dev).float()
+        if noise is None:
+            noise = lf._noise(x0)
+        lf._tables(dev)
+        key = (tuple(x0.shape),)
+        g = self._graphs.get(key)
+        if g is None or not g.valid():
+            self._graphs.clear()                          # one shape at a time: a graph's private pool pins the activations of a whole step
+            g = self._graphs[key] = GraphedMicroStep(self, x0, R, noise.to(dev), timesteps.to(dev))
+        return g(x0, R, noise.to(dev), timesteps.to(dev))
 
     def state_dict(self) -> Dict:
         return {"optimizer": self.opt.state_dict(), "micro": self.micro, "sched_step": self.sched_step}

@@ -838,7 +838,7 @@ class UNet2DModel(nn.Module):
         key = tuple(jobs)
         tab = self._cs_tables.get(key)
         if tab is None:                                          # same job list every step: uploaded once
-            tab = torch.tensor(jobs, dtype=torch.int64).to(self._dev)
+            tab = ops.upload_table(torch.tensor(jobs, dtype=torch.int64), self._dev)
             self._cs_tables[key] = tab
         ops.colsum_segmented(tab, len(jobs), self._cs_B)
         self._cs_jobs = []
