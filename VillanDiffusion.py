@@ -268,7 +268,7 @@ def measure_inpaints(cfg, pipeline, dsl):
     their corrupted version (start at --infer_start, init * --inpaint_mul) and score MSE / SSIM against the task's target.
     Reproduced as written: the unpoisoned tasks compare the recovered [0,1] images with the dataset tensors in their
     NORMALISED range (reference passes `target_imgs=imgs`), the poisoned ones with the backdoor target mapped to [0,1].
-    LPIPS needs AlexNet weights (no network): None."""
+    LPIPS runs on the HIP AlexNet taps when its two weight files are present locally, else None."""
     import numpy as np
     import torch
     from villandiffusion_amd.metrics import mse_batch, ssim_batch
@@ -300,7 +300,22 @@ def measure_inpaints(cfg, pipeline, dsl):
                        num_inference_steps=cfg.infer_steps, start_from=int(cfg.infer_start), save_every_step=False)
         rec.append(out.images)
     recover = torch.from_numpy(np.vstack(rec)).permute(0, 3, 1, 2).float()
-    return {"LPIPS": None, "MSE": mse_batch(recover, target_imgs.float()), "SSIM": ssim_batch(recover, target_imgs.float())}
+    return {"LPIPS": measure_lpips(recover, target_imgs.float(), cfg.eval_max_batch), "MSE": mse_batch(recover, target_imgs.float()),
+            "SSIM": ssim_batch(recover, target_imgs.float())}
+
+
+def measure_lpips(recover, target, max_batch: int = 256):
+    """reference :892  float(torch.mean(lpips.LPIPS(net='alex')(recover_imgs, target_imgs))) -- on the HIP AlexNet taps
+    (villandiffusion_amd/lpips.py); None when the two weight files are not present locally (no network on the box)."""
+    import torch
+    import lpips
+    try:
+        model = lpips.LPIPS(net="alex")
+    except FileNotFoundError as e:
+        print(f"measure: LPIPS not computed -- {e}")
+        return None
+    vals = [model(recover[s:s + max_batch], target[s:s + max_batch]).flatten().cpu() for s in range(0, len(recover), max_batch)]
+    return float(torch.cat(vals).mean())
 
 
 def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
@@ -322,7 +337,7 @@ def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
             data[score_key(cfg, k)] = v
         with open(path, "w") as f:
             json.dump(data, f, indent=2, sort_keys=True)
-        print(f"measure[{cfg.task}]: MSE {sc['MSE']:.5f} SSIM {sc['SSIM']:.5f} (LPIPS needs AlexNet weights: not computed)")
+        print(f"measure[{cfg.task}]: LPIPS {sc['LPIPS']} MSE {sc['MSE']:.5f} SSIM {sc['SSIM']:.5f}")
         return sc
     n = cfg.measure_sample_n
     step = f"{cfg.sample_ep}" if cfg.sample_ep is not None else ""

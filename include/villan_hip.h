@@ -106,7 +106,7 @@ typedef struct vd_gemm_desc {
                                 i.e. conv-transpose followed by the adjoint of the nearest-2x upsample, without the full-resolution tensor.
                                 Needs an unsplit grid (M/128 * N/128 >= 256 tiles), no bias / rowadd / residual / accumulate; else VD_EINVAL */
     int32_t kh, kw;          /* VD_B_CONVG only: kernel height / width (K = C*kh*kw)                                    */
-    int32_t conv_stride;     /* VD_B_CONVG only: 1 or 2 (both directions)                                               */
+    int32_t conv_stride;     /* VD_B_CONVG only: 1 .. 4 (both directions)                                               */
     int32_t pad_h, pad_w;    /* VD_B_CONVG only: zero padding on each side                                              */
     int32_t act;             /* 0: none; 1: D = max(D, 0) after every other epilogue term (BasicConv2d = conv + folded BatchNorm + ReLU).
                                 Honoured by the exact-f32 gather / plain kernels only (a_packed == NULL, math == 0); else VD_EINVAL */
@@ -338,6 +338,16 @@ int vd_pool3(const float* x, float* y, int B, int C, int H, int W, int stride, i
              void* stream);
 /* y = mul * F.interpolate(x, (OH, OW), mode="bilinear", align_corners=False) + add over `planes` contiguous H x W planes. */
 int vd_resize_bilinear(const float* x, float* y, int64_t planes, int H, int W, int OH, int OW, float mul, float add, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LPIPS (reference VillanDiffusion.py:892 -> lpips.LPIPS(net='alex')): the AlexNet convolutions run through vd_gemm
+ * (VD_B_CONVG with act = 1) and vd_pool3; these are the remaining ops.
+ * ------------------------------------------------------------------------------------------ */
+/* y[b][c][:] = x[b][c][:] * mul[c] + add[c] over contiguous [B][C][HW] tensors (the input ScalingLayer). */
+int vd_channel_affine(const float* x, const float* mul, const float* add, float* y, int B, int C, int HW, void* stream);
+/* One tap of the metric on contiguous [N][C][HW] feature maps: out[n] (+)= mean_p sum_c w[c] * (unit(f0)[n][c][p] - unit(f1)[n][c][p])^2,
+ * unit(f) = f / (sqrt(sum_c f^2) + 1e-10). */
+int vd_lpips_layer(const float* f0, const float* f1, const float* w, float* out, int N, int C, int HW, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

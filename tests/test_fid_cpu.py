@@ -69,3 +69,25 @@ def test_fid_module_surface_and_missing_weights_error(tmp_path, monkeypatch):
     assert m.shape == (4,) and s.shape == (4, 4)
     with pytest.raises(RuntimeError, match="Invalid path"):
         F0.calculate_fid_given_paths([str(tmp_path / "nope"), str(tmp_path)], 8, "cuda", 2048, model=object())
+
+
+def test_lpips_oracle_known_answers(tmp_path, monkeypatch):
+    """lpips.LPIPS(net='alex') restated (oracle/lpips_ref.py; reference VillanDiffusion.py:892): AlexNet feature widths / parameter count,
+    d(x, x) = 0, symmetry, non-negativity with non-negative lin weights, and the loud failure of the product loader without local weights."""
+    from oracle.lpips_ref import CHNS, LPIPSRef
+    m = LPIPSRef().randomize(0)
+    assert sum(p.numel() for p in m.net.parameters()) == 61_100_840 - 58_631_144 == 2_469_696       # torchvision AlexNet minus its classifier
+    x, y = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(0)), torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    assert [t.shape[1] for t in m.net(x)] == list(CHNS) and [t.shape[-1] for t in m.net(x)] == [15, 7, 3, 3, 3]
+    dxy, dyx, dxx = m(x, y), m(y, x), m(x, x)
+    assert tuple(dxy.shape) == (3, 1, 1, 1) and float(dxx.abs().max()) == 0.0
+    assert torch.allclose(dxy, dyx, rtol=1e-6) and float(dxy.min()) > 0
+    assert set(m.flat_state_dict()) == {f"features.{i}.{k}" for i in (0, 3, 6, 8, 10) for k in ("weight", "bias")} | {f"lin{k}.model.1.weight" for k in range(5)}
+    import lpips as L0                                # the package name the reference imports
+    monkeypatch.setenv("VILLAN_CKPT_ROOT", str(tmp_path))
+    monkeypatch.delenv("VILLAN_ALEXNET_WEIGHTS", raising=False)
+    monkeypatch.delenv("VILLAN_LPIPS_WEIGHTS", raising=False)
+    with pytest.raises(FileNotFoundError, match="alexnet-owt-7be5be79.pth"):
+        L0.load_lpips_weights()
+    with pytest.raises(NotImplementedError):
+        L0.LPIPS(net="vgg", state_dict={})

@@ -126,3 +126,22 @@ def test_fid_of_two_png_directories_matches_the_oracle(tmp_path):
     print(f"[parity] FID {got:.6f} vs oracle {want:.6f}")
     assert want > 1e-3 and abs(got - want) <= 1e-3 * abs(want)
     assert fid_score.fid([str(tmp_path / "a"), str(tmp_path / "a")], batch_size=64, dims=192, model=model) == pytest.approx(0.0, abs=1e-6 * max(1.0, want))
+
+
+def test_lpips_matches_oracle_on_random_weights():
+    """lpips.LPIPS(net='alex')(a, b) on the HIP kernels (11x11 stride-4 / 5x5 / 3x3 convolutions + ReLU, max pooling, per-tap normalise /
+    difference / lin / mean in one kernel) against oracle/lpips_ref.py, 32x32 (the CIFAR10 measure) and 64x64 inputs in [0, 1]."""
+    from oracle.lpips_ref import LPIPSRef
+    from villandiffusion_amd.lpips import LPIPS
+    ref = LPIPSRef().randomize(3)
+    net = LPIPS(net="alex", state_dict=ref.flat_state_dict())
+    for S in (32, 64, 96):
+        a, b = torch.rand(5, 3, S, S, generator=g(7)), torch.rand(5, 3, S, S, generator=g(8))
+        want, got = ref(a, b), net(a, b)
+        assert tuple(got.shape) == (5, 1, 1, 1)
+        e = rel(got, want)
+        print(f"[parity] LPIPS {S}x{S}: rel_err {e:.2e}")
+        assert e < 1e-4 and float(net(a, a).abs().max()) == 0.0
+    fa, fr = net.features(torch.rand(2, 3, 64, 64, generator=g(9)).cuda()), ref.net((torch.rand(2, 3, 64, 64, generator=g(9)) - ref.shift) / ref.scale)
+    for k, (x, y) in enumerate(zip(fa, fr)):
+        assert rel(x, y) < 2e-5, k

@@ -731,3 +731,66 @@ extern "C" int vd_resize_bilinear(const float* x, float* y, int64_t planes, int 
     VD_LAUNCH_CHECK("vd_resize_bilinear");
     return 0;
 }
+
+// ---- LPIPS (lpips.LPIPS(net='alex'), reference VillanDiffusion.py:892): the ops around the AlexNet convolutions -----------------------
+namespace {
+
+// y[b][c][p] = x[b][c][p] * mul[c] + add[c]   (the ScalingLayer: (x - shift) / scale as x * (1/scale) + (-shift/scale))
+__global__ __launch_bounds__(EB) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ mul, const float* __restrict__ add,
+                                                            float* __restrict__ y, int64_t total, int C, int HW) {
+    for (int64_t e = (int64_t)blockIdx.x * EB + threadIdx.x; e < total; e += (int64_t)gridDim.x * EB) {
+        const int c = (int)((e / HW) % C);
+        y[e] = x[e] * mul[c] + add[c];
+    }
+}
+
+// One LPIPS tap: out[n] (+)= (1 / HW) * sum_p sum_c w[c] * (f0[n][c][p] / (|f0[n][:, p]| + eps) - f1[n][c][p] / (|f1[n][:, p]| + eps))^2.
+// One workgroup per image; a thread owns pixels p, p + 256, ... and walks the channels twice (norms, then the weighted squared
+// differences); the per-pixel sums meet in a fixed-order tree.  The feature maps are at most 64 x 55 x 55 floats per image.
+__global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ w,
+                                                          float* __restrict__ out, int C, int HW, int accumulate) {
+    const int n = blockIdx.x;
+    const float* __restrict__ a = f0 + (int64_t)n * C * HW;
+    const float* __restrict__ b = f1 + (int64_t)n * C * HW;
+    float acc = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        float sa = 0.f, sb = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float va = a[(int64_t)c * HW + p], vb = b[(int64_t)c * HW + p];
+            sa += va * va;
+            sb += vb * vb;
+        }
+        const float ia = 1.f / (sqrtf(sa) + 1e-10f), ib = 1.f / (sqrtf(sb) + 1e-10f);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float dlt = a[(int64_t)c * HW + p] * ia - b[(int64_t)c * HW + p] * ib;
+            s += w[c] * (dlt * dlt);
+        }
+        acc += s;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = (accumulate ? out[n] : 0.f) + red[0] / (float)HW;
+}
+
+}  // namespace
+
+extern "C" int vd_channel_affine(const float* x, const float* mul, const float* add, float* y, int B, int C, int HW, void* stream) {
+    VD_REQUIRE(x && mul && add && y && B > 0 && C > 0 && HW > 0, "vd_channel_affine: bad args");
+    const int64_t n = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, mul, add, y, n, C, HW);
+    VD_LAUNCH_CHECK("vd_channel_affine");
+    return 0;
+}
+
+extern "C" int vd_lpips_layer(const float* f0, const float* f1, const float* w, float* out, int N, int C, int HW, int accumulate, void* stream) {
+    VD_REQUIRE(f0 && f1 && w && out && N > 0 && C > 0 && HW > 0, "vd_lpips_layer: bad args");
+    hipLaunchKernelGGL(lpips_layer_kernel, dim3(N), dim3(256), 0, ST, f0, f1, w, out, C, HW, accumulate);
+    VD_LAUNCH_CHECK("vd_lpips_layer");
+    return 0;
+}

@@ -2077,10 +2077,10 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     if (d.b_mode >= VD_B_CONV3) {
         VD_REQUIRE(d.C > 0 && d.H > 0 && d.W > 0 && d.OH * d.OW == d.NP, "vd_gemm: bad conv dims");
         if (d.b_mode == VD_B_CONVG)
-            VD_REQUIRE(d.kh > 0 && d.kw > 0 && d.K == d.C * d.kh * d.kw && (d.conv_stride == 1 || d.conv_stride == 2) && d.pad_h >= 0 && d.pad_w >= 0 &&
+            VD_REQUIRE(d.kh > 0 && d.kw > 0 && d.K == d.C * d.kh * d.kw && d.conv_stride >= 1 && d.conv_stride <= 4 && d.pad_h >= 0 && d.pad_w >= 0 &&
                            d.OH == (d.H + 2 * d.pad_h - d.kh) / d.conv_stride + 1 && d.OW == (d.W + 2 * d.pad_w - d.kw) / d.conv_stride + 1 &&
                            !d.a_packed && d.math == 0 && d.a_mode == VD_A_ROW,
-                       "vd_gemm: VD_B_CONVG needs kh, kw > 0, K = C*kh*kw, conv_stride 1 | 2, OH / OW = (H + 2 pad - k) / stride + 1, row-major exact-f32 A");
+                       "vd_gemm: VD_B_CONVG needs kh, kw > 0, K = C*kh*kw, conv_stride 1 .. 4, OH / OW = (H + 2 pad - k) / stride + 1, row-major exact-f32 A");
         else
             VD_REQUIRE(d.K == d.C * 9, "vd_gemm: conv K must be C*9");
     }
@@ -2238,7 +2238,10 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
                 const bool up = d.mode == VD_B_CONV3_UP;
 #define VD_WBX3(WW)                                                                                     \
     do {                                                                                                \
-        if (up) hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 2>), grid, dim3(NT), 0, st, d, kk_per);        \
+        if (wgrad_k32_enabled()) {                                                                      \
+            if (up) hipLaunchKernelGGL((wgrad_k32_kernel<WW, 2>), grid, dim3(NT), 0, st, d, kk_per);    \
+            else hipLaunchKernelGGL((wgrad_k32_kernel<WW, 0>), grid, dim3(NT), 0, st, d, kk_per);       \
+        } else if (up) hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 2>), grid, dim3(NT), 0, st, d, kk_per); \
         else hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 0>), grid, dim3(NT), 0, st, d, kk_per);           \
     } while (0)
                 if (d.OW >= 64 && up) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 2, true>), grid, dim3(NT), 0, st, d, kk_per);
@@ -2435,14 +2438,18 @@ extern "C" int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls,
     const dim3 grid(blocks);
     switch (cls) {
         case 1000: hipLaunchKernelGGL(wgrad1x1_bx3_group_kernel, grid, dim3(NT), 0, st, jobs, n); break;
-        case 4 * 32 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 0>), grid, dim3(NT), 0, st, jobs, n); break;
-        case 4 * 32 + 2: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 2>), grid, dim3(NT), 0, st, jobs, n); break;
+#define VD_WG_K32(WW, MD)                                                                                   \
+    if (wgrad_k32_enabled()) hipLaunchKernelGGL((wgrad_k32_group_kernel<WW, MD>), grid, dim3(NT), 0, st, jobs, n); \
+    else hipLaunchKernelGGL((wgrad_bx3_group_kernel<WW, MD>), grid, dim3(NT), 0, st, jobs, n);
+        case 4 * 32 + 0: VD_WG_K32(32, 0) break;
+        case 4 * 32 + 2: VD_WG_K32(32, 2) break;
         case 4 * 32 + 1: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 0, true>), grid, dim3(NT), 0, st, jobs, n); break;
         case 4 * 32 + 3: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 2, true>), grid, dim3(NT), 0, st, jobs, n); break;
-        case 4 * 16 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<16, 0>), grid, dim3(NT), 0, st, jobs, n); break;
-        case 4 * 16 + 2: hipLaunchKernelGGL((wgrad_bx3_group_kernel<16, 2>), grid, dim3(NT), 0, st, jobs, n); break;
-        case 4 * 8 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<8, 0>), grid, dim3(NT), 0, st, jobs, n); break;
-        case 4 * 8 + 2: hipLaunchKernelGGL((wgrad_bx3_group_kernel<8, 2>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 4 * 16 + 0: VD_WG_K32(16, 0) break;
+        case 4 * 16 + 2: VD_WG_K32(16, 2) break;
+        case 4 * 8 + 0: VD_WG_K32(8, 0) break;
+        case 4 * 8 + 2: VD_WG_K32(8, 2) break;
+#undef VD_WG_K32
         case 4 * 4 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<4, 0>), grid, dim3(NT), 0, st, jobs, n); break;
         default: vd_set_error("vd_conv_wgrad_group_launch: unknown kernel class %d", cls); return VD_EINVAL;
     }

@@ -98,6 +98,8 @@ PROTOTYPES = {
     "vd_poison_batch": (_i32, [_vp] * 8 + [_i32] * 4 + [_f32, _f32, _i32, _vp]),
     "vd_pool3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_resize_bilinear": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
+    "vd_channel_affine": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_lpips_layer": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -264,6 +264,22 @@ def resize_bilinear(x, out, mul=1.0, add=0.0):
     return out
 
 
+def channel_affine(x, mul, add, out):
+    """out[b, c] = x[b, c] * mul[c] + add[c]  (contiguous NCHW)."""
+    B, C, H, W = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape and mul.numel() == C and add.numel() == C
+    L.check(_lib().vd_channel_affine(_p(x), _p(mul), _p(add), _p(out), B, C, H * W, _s()), "vd_channel_affine")
+    return out
+
+
+def lpips_layer(f0, f1, w, out, accumulate=False):
+    """out[n] (+)= mean_p sum_c w[c] (unit(f0) - unit(f1))^2 for one tap of the LPIPS metric (contiguous [N, C, H, W] feature maps)."""
+    N, C, H, W = f0.shape
+    assert f0.is_contiguous() and f1.is_contiguous() and f1.shape == f0.shape and w.numel() == C and out.numel() == N
+    L.check(_lib().vd_lpips_layer(_p(f0), _p(f1), _p(w), _p(out), N, C, H * W, int(accumulate), _s()), "vd_lpips_layer")
+    return out
+
+
 def attn_core_eligible(heads, head_dim, N) -> bool:
     """Shapes the fused attention core takes (vd_attn_core_fwd / _bwd): 256 tokens, head_dim 32 / 64 / 128 or a multiple of 256."""
     return N == 256 and heads >= 1 and (head_dim in (32, 64, 128) or (head_dim > 0 and head_dim % 256 == 0))
@@ -370,18 +386,29 @@ _WG_CACHE, _WG_WS = {}, {}
 # its address is what the captured launches read) and the copy (+ any one-time fix-up kernel) runs right after the capture ends; the
 # graph never writes these tables, so one upload serves every replay.
 _CAPTURE_DEFER = None
+_CAPTURE_TABLES = None
+_CAPTURE_ARENA = None      # [uint8 device buffer, bytes used]
 
 
-def capture_begin():
-    global _CAPTURE_DEFER
-    _CAPTURE_DEFER = []
+def capture_begin(device, arena_bytes: int = 1 << 20):
+    """Open a graph capture for table uploads.  The tables must NOT come from the graph's private memory pool: a block the capture hands to
+    a table may have belonged to an activation EARLIER in capture order, and every replay would then overwrite the uploaded table with that
+    activation before the launches that read it run.  They are carved out of an arena allocated here, before the capture starts."""
+    global _CAPTURE_DEFER, _CAPTURE_TABLES, _CAPTURE_ARENA
+    _CAPTURE_DEFER, _CAPTURE_TABLES = [], []
+    _CAPTURE_ARENA = [torch.empty(arena_bytes, dtype=torch.uint8, device=device), 0]
 
 
 def capture_end():
-    global _CAPTURE_DEFER
+    """Runs the deferred uploads; returns the device tables (and their arena) the captured launches read -- the graph's owner must keep them
+    alive (the look-up caches that also hold them are bounded and may drop them)."""
+    global _CAPTURE_DEFER, _CAPTURE_TABLES, _CAPTURE_ARENA
     todo, _CAPTURE_DEFER = _CAPTURE_DEFER or [], None
+    tables, _CAPTURE_TABLES = _CAPTURE_TABLES or [], None
+    arena, _CAPTURE_ARENA = _CAPTURE_ARENA, None
     for fin in todo:
         fin()
+    return tables + ([arena[0]] if arena else [])
 
 
 def upload_table(host: torch.Tensor, device, after=None) -> torch.Tensor:
@@ -391,7 +418,14 @@ def upload_table(host: torch.Tensor, device, after=None) -> torch.Tensor:
         if after is not None:
             after(t)
         return t
-    t = torch.empty(host.shape, dtype=host.dtype, device=device)
+    nbytes = host.numel() * host.element_size()
+    arena, used = _CAPTURE_ARENA
+    start = (used + 255) // 256 * 256
+    if start + nbytes > arena.numel():
+        raise L.VillanHipError(f"graph capture: job-table arena exhausted ({start + nbytes} > {arena.numel()} bytes)")
+    _CAPTURE_ARENA[1] = start + nbytes
+    t = arena[start:start + nbytes].view(host.dtype).view(host.shape)
+    _CAPTURE_TABLES.append(t)
 
     def fin():
         t.copy_(host)
@@ -428,6 +462,8 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
             _WG_CACHE.clear()
         ent = _WG_CACHE[key] = {"table": table, "cls": cls, "blocks": blocks.value, "rblocks": rblocks.value, "ws_ptr": ws.data_ptr(),
                                 "ws_floats": int(wsf.value)}
+    if _CAPTURE_TABLES is not None:
+        _CAPTURE_TABLES.append(ent["table"])              # a cache hit inside a capture: the graph reads this table too
     flops = sum(2.0 * d.M * d.C * d.T * d.nb * d.NP for d in descs)
     nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
     name = (f"wgrad1x1_bx3_group_kernel(+group_reduce)" if ent["cls"] == 1000 else       # symbol names as rocprofv3 prints them

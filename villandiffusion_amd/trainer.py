@@ -89,6 +89,9 @@ def shard_indices(n_items: int, epoch: int, rank: int, world: int, seed: int = 0
     return perm[rank * per:(rank + 1) * per]
 
 
+_DEBUG = bool(__import__("os").environ.get("VD_GRAPH_DEBUG"))
+
+
 class GraphedMicroStep:
     """q-sample -> UNet forward -> loss (+ its gradient) -> UNet backward of ONE micro-batch, captured once into a HIP graph per batch shape
     and replayed (BASELINE config #1: `--batch 4` with gradient accumulation 32, VillanDiffusion.py:287 -- a micro-step is ~470 launches of
@@ -117,15 +120,20 @@ class GraphedMicroStep:
                 self._body()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if _DEBUG:
+            print("[graph] warm-up done", flush=True)
         net.flat_grad.copy_(keep)                         # the warm-up passes accumulated gradients: undo
         self._keep = (ops._GEMM_WS.get(dev), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws)
         self.graph = torch.cuda.CUDAGraph()
-        ops.capture_begin()                               # job tables built during the capture are uploaded right after it (ops.upload_table)
+        ops.capture_begin(dev)                            # job tables built during the capture are uploaded right after it (ops.upload_table)
         try:
             with torch.cuda.graph(self.graph):
                 self._body()
         finally:
-            ops.capture_end()
+            self._tables = ops.capture_end()              # device job tables the captured launches read: owned by this graph from now on
+        if _DEBUG:
+            torch.cuda.synchronize(dev)
+            print(f"[graph] captured; {len(self._tables)} job tables", flush=True)
 
     def _key(self):
         n = self.net
@@ -155,6 +163,9 @@ class GraphedMicroStep:
         self.noise.copy_(noise)
         self.t.copy_(t)
         self.graph.replay()
+        if _DEBUG:
+            torch.cuda.synchronize(net.device)
+            print("[graph] replayed", flush=True)
         return self.loss[0]
 
 

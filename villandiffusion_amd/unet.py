@@ -840,6 +840,8 @@ class UNet2DModel(nn.Module):
         if tab is None:                                          # same job list every step: uploaded once
             tab = ops.upload_table(torch.tensor(jobs, dtype=torch.int64), self._dev)
             self._cs_tables[key] = tab
+        if ops._CAPTURE_TABLES is not None:
+            ops._CAPTURE_TABLES.append(tab)
         ops.colsum_segmented(tab, len(jobs), self._cs_B)
         self._cs_jobs = []
 
