@@ -108,6 +108,71 @@ def test_sampler_summary_is_sampler_only():
     assert not any(s.startswith("softmax_col") for s in st)                              # the fused attention core replaced the column softmax
 
 
+
+# ---- round 3: the stdout line is short (the driver keeps a ~9.5 KB stdout tail; round 2's 20.8 KB line arrived truncated), carries the parity
+# gates, and the per-kernel tables live in the side file of the same run ----
+def test_r03_bench_line_is_short_and_self_proving():
+    raw = open(os.path.join(P, "r03_bench_default.json")).read().strip().splitlines()[-1]
+    assert len(raw) < 4096, len(raw)
+    d = json.loads(raw)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert "train_step_kernels" not in d and "sampler_step_kernels" not in d            # those tables are what made the line too long
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "bf16x3/f32"
+    assert "workload" in d["config"] and "model" not in d["config"] and "chunks of 128" in d["config"]["workload"]
+    assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    for k in ("kernel", "unit", "traffic", "launches_per_step", "avg_launch_us", "algorithmic_gflop_per_launch", "frac_executed"):
+        assert k in r, k
+    assert r["peak"] == 2500.0 and r["unit"] == "TFLOP/s" and r["kernel"].startswith("conv3_k32_kernel<32")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "batch 128" in c["sample"] and c["unit"] == d["unit"]
+    p = d["parity"]                                    # SURVEY 8d gates, computed in the CPU leg on the same weights / batch
+    assert p["pass"] is True and p["timestep_indices_bit_exact"] is True
+    assert p["loss_step0_rel_err"] <= 1e-5 and p["grad_norm_rel_err"] <= 1e-4 and p["denoised_max_rel_err"] <= 1e-3
+    assert d["exact_f32_mode"]["train_images_per_sec"] < d["value"] and d["sample_ddpm1000_images_per_sec"] > 0 and d["sample_hip_graph"] is True
+    assert len(d["top_kernels"]) == 5 and d["top_kernels"][0]["kernel"] == r["kernel"]
+
+
+def test_r03_detail_tables_agree_with_the_rocprof_summary_and_the_pmc_passes():
+    d = _line("r03_bench_default.json")
+    with open(os.path.join(P, "r03_bench_detail.json")) as f:
+        det = json.load(f)
+    assert det["value"] == d["value"] and det["roofline"]["kernel"] == d["roofline"]["kernel"] and "selection_rule" in det["roofline"]
+    mf = [k for k in det["train_step_kernels"] if k["mfma_peak"]]
+    assert d["roofline"]["kernel"] == max(mf, key=lambda k: k["ms"])["kernel"]
+    for k in det["train_step_kernels"]:
+        assert k["bound"] == ("hbm" if k["frac_hbm"] >= k["frac_mfma_executed"] else "mfma")
+    st = _stats("r03_train_kernel_stats.csv")
+    checked = 0
+    for k in det["train_step_kernels"]:
+        sym = k["kernel"].split("(+")[0]
+        if sym not in st or k["avg_us"] < 40 or "(+" in k["kernel"] or sym.startswith(("conv3_bx3_kernel<8,", "conv3_bx3_kernel<4,")):
+            continue
+        if "bx3" in sym or "attn_core" in sym or "k32" in sym:
+            # same code, two boxes of the pool (the bench line is re-taken after the PMC tables are committed): the boxes differ by a few per cent
+            assert abs(st[sym][1] - k["avg_us"]) / st[sym][1] < 0.12, (sym, st[sym][1], k["avg_us"])
+            checked += 1
+    assert checked >= 6
+    with open(os.path.join(P, "r03_pmc_traffic.json")) as f:
+        tr = json.load(f)["kernels"]
+    with open(os.path.join(P, "r03_pmc_mfma.json")) as f:
+        mfm = json.load(f)["kernels"]
+    sym = d["roofline"]["kernel"]
+    assert sym in tr and tr[sym]["traffic_bytes_per_launch"] > 0 and tr[sym]["traffic_over_algorithmic"] < 1.5
+    if d["roofline"]["traffic"] is not None:
+        assert abs(d["roofline"]["traffic"] - tr[sym]["traffic_bytes_per_launch"]) / tr[sym]["traffic_bytes_per_launch"] < 0.05
+    # MFMA-busy counter (per cycle) x the kernel's own clock == the bench's executed fraction (per second against the 2.4 GHz peak)
+    k = next(k for k in det["train_step_kernels"] if k["kernel"] == sym)
+    m = mfm[sym]
+    util_time = m["MfmaUtil"] * m["kernel_us_at_2.4GHz"] / m["avg_us"]
+    assert abs(util_time - k["frac_mfma_executed"]) < 0.05, (m["MfmaUtil"], util_time, k["frac_mfma_executed"])
+    sst = _stats("r03_sample_kernel_stats.csv")
+    assert not any("wgrad" in s or "gn_bwd" in s or "adam" in s for s in sst) and any(s.startswith("conv3_k32_kernel<32, 3>") for s in sst)
+
+
 def _run_bench(args, env_extra, timeout=300):
     import subprocess
     import sys

@@ -71,3 +71,28 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
     err = float((ddp - single).abs().max() / single.abs().max())
     print(f"[parity] 2-rank DDP vs single process after 2 optimiser steps: rel_err {err:.3e}")
     assert err < 1e-3
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_flag_runs_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` (no launcher around it): the parent starts two rank processes before touching the GPU, both train on their shard
+    with the bucketed all-reduce and sample their own images, rank 0 prints ONE short JSON line with n_gpus = 2 whose collective counted two ranks.
+    Here the two ranks share the one GPU of the test box and talk over gloo; on a node they get one GPU each and RCCL (backend "nccl")."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, VD_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--sample-steps", "20", "--no-secondary",
+                        "--no-exact"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 256 and d["scaling"] == "weak" and d["value"] > 0
+    pg = d["process_group"]
+    assert pg["world_size"] == 2 and pg["ranks_counted_by_all_reduce"] == 2 and [x[0] for x in pg["rank_device_pci"]] == [0, 1]
+    assert abs(d["value"] - 256 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3            # whole-job images over the MAX-over-ranks time
+    assert d["cpu_baseline"] is None and d["parity"] is None                              # rank 0 at N = 1 only (task contract)
+    assert d["roofline"]["bound"] in ("mfma", "hbm") and d["sample_ddpm1000_images_per_sec"] > 0
