@@ -162,6 +162,8 @@ int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits);
  *   launch : the two launches.  Deterministic (fixed reduction order); results agree with vd_conv_wgrad to summation order. */
 int vd_conv_wgrad_group_class(const vd_wgrad_desc* desc);
 int64_t vd_conv_wgrad_group_job_bytes(void);
+/* Kernel family a class runs on: 9 = all nine taps per workgroup (plain 3x3 at 16x16 / 32x32), 32 = opt-in 16x16x32 one-tap-row kernel, 0 = default. */
+int vd_conv_wgrad_group_variant(int cls);
 int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void* table_out, int64_t* ws_floats, int* blocks, int* rblocks);
 int vd_conv_wgrad_group_rebase(void* dev_table, int n, float* ws, void* stream);
 int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls, int blocks, int rblocks, void* stream);

@@ -947,20 +947,27 @@ for (B, Cin, Cout, H, mode) in [(4, 128, 128, 32, B_CONV3), (3, 192, 64, 32, B_C
     dw = torch.zeros(Cout, Cin * 9, device="cuda")
     ops.conv_wgrad(dy.cuda(), x.cuda(), dw, mode, ws, accumulate=False, math_mode=1)
     e = float((dw.cpu() - w.grad.view(Cout, -1)).abs().max() / w.grad.abs().max())
-    d = ops.wgrad_desc(dy.cuda(), x.cuda(), torch.zeros(Cout, Cin * 9, device="cuda"), mode, None, accumulate=True, math_mode=1)
     worst = max(worst, e)
+    if mode == B_CONV3 and H in (16, 32):          # the grouped launch: with VD_WGRAD9=1 the nine-taps-per-workgroup kernel
+        dw2 = torch.zeros(Cout, Cin * 9, device="cuda")
+        dyd, xd = dy.cuda(), x.cuda()
+        d = ops.wgrad_desc(dyd, xd, dw2, mode, None, accumulate=True, math_mode=1)
+        assert ops.wgrad_group_class(d) != 0
+        ops.conv_wgrad_group([d], torch.device("cuda"))
+        worst = max(worst, float((dw2.cpu() - w.grad.view(Cout, -1)).abs().max() / w.grad.abs().max()))
 print("WK32 %.3e" % worst)
 """
 
 
 def test_opt_in_16x16x32_weight_gradient_kernel_stays_correct():
-    """vd_wgrad_k32.inc (VD_WGRAD_K32=1: X staged once, shifted fragments built in registers, one barrier per K-step) is not the default -- it
-    measured 0.93-1.04 x of the three-copy kernel -- but it stays built: hold it to the same bound in a process that selects it."""
+    """vd_wgrad_k32.inc (VD_WGRAD_K32=1: X staged once, shifted fragments built in registers, one barrier per K-step) and vd_wgrad9.inc
+    (VD_WGRAD9=1: all nine taps per workgroup from a ring of X rows) are not the defaults -- they measured 0.93-1.04 x of the three-copy
+    kernel -- but they stay built: hold them to the same bound in a process that selects them."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, PYTHONPATH=root, VD_WGRAD_K32="1")
+    e = dict(os.environ, PYTHONPATH=root, VD_WGRAD_K32="1", VD_WGRAD9="1")
     r = subprocess.run([sys.executable, "-c", _WK32_PROBE], capture_output=True, text=True, env=e, cwd=root, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WK32")][0].split()[1])

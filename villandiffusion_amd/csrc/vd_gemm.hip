@@ -2348,6 +2348,13 @@ static int wgrad_group_class(const vd_wgrad_desc& d) {
 
 extern "C" int vd_conv_wgrad_group_class(const vd_wgrad_desc* desc) { return desc ? wgrad_group_class(*desc) : 0; }
 extern "C" int64_t vd_conv_wgrad_group_job_bytes(void) { return (int64_t)sizeof(vd_wgrad_job); }
+// Which kernel vd_conv_wgrad_group_launch runs for a class: 9 = wgrad9_group_kernel (all nine taps per workgroup), 32 = wgrad_k32_group_kernel
+// (opt-in 16x16x32 one-tap-row kernel), 0 = wgrad_bx3_group_kernel / wgrad1x1_bx3_group_kernel (profiling names, tests).
+extern "C" int vd_conv_wgrad_group_variant(int cls) {
+    if (wgrad9_class(cls)) return 9;
+    if (cls != 1000 && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled()) return 32;
+    return 0;
+}
 
 // Plan: fills the HOST image of the device job table (n * vd_conv_wgrad_group_job_bytes() bytes) with ws OFFSETS (floats) in d.ws,
 // so the image does not depend on where the workspace lives; vd_conv_wgrad_group_launch adds the base.  Every workgroup of the
@@ -2358,12 +2365,13 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     VD_REQUIRE(cls != 0, "vd_conv_wgrad_group_plan: job 0 is not a split-precision (math = 1) 3x3 / 1x1 weight gradient");
     vd_wgrad_job* jobs = reinterpret_cast<vd_wgrad_job*>(table_out);
     const bool one = cls == 1000;
+    const bool nine = wgrad9_class(cls);                         // one workgroup (512 threads, one per CU) per tile produces all nine taps
     int64_t work = 0;
     for (int j = 0; j < n; ++j) {
         const vd_wgrad_desc& d = descs[j];
         VD_REQUIRE(d.dY && d.X && d.dW && wgrad_group_class(d) == cls, "vd_conv_wgrad_group_plan: job %d is of another kernel class (%d vs %d)", j,
                    wgrad_group_class(d), cls);
-        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
+        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * (nine ? 1 : 3);
         const int64_t ks = one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32);
         work += base * ks;
     }
@@ -2376,10 +2384,33 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     static const int t1 = getenv("VD_W1X1_GROUP_TARGET") ? atoi(getenv("VD_W1X1_GROUP_TARGET")) : 512;
     static const int cap3 = getenv("VD_WGRAD_GROUP_KCAP") ? atoi(getenv("VD_WGRAD_GROUP_KCAP")) : 128;
     static const int cap1 = getenv("VD_W1X1_GROUP_KCAP") ? atoi(getenv("VD_W1X1_GROUP_KCAP")) : 32;
-    const int target = one ? t1 : t3;
+    static const int t9 = getenv("VD_WGRAD9_TARGET") ? atoi(getenv("VD_WGRAD9_TARGET")) : 256;
+    static const int cap9 = getenv("VD_WGRAD9_KCAP") ? atoi(getenv("VD_WGRAD9_KCAP")) : 128;
+    const int target = one ? t1 : (nine ? t9 : t3);
     const int min_ks = one ? 4 : 8;
     int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
-    if (per > (one ? cap1 : cap3)) per = one ? cap1 : cap3;
+    if (nine) {
+        // One workgroup per CU: the launch runs in ROUNDS of t9 workgroups, and a partly filled last round costs a whole one (with the
+        // target / cap rule above, config #2 at 32x32 gets 896 workgroups = 3.5 rounds of 256).  Choose the K-steps per workgroup that minimise
+        // rounds * (K-steps + a per-round charge for the slabs every workgroup writes and the reduce grid re-reads).
+        static const int slab9 = getenv("VD_WGRAD9_SLAB_STEPS") ? atoi(getenv("VD_WGRAD9_SLAB_STEPS")) : 16;
+        int64_t best_cost = -1, best_per = per;
+        for (int64_t p = min_ks; p <= cap9; ++p) {
+            int64_t total = 0;
+            for (int j = 0; j < n; ++j) {
+                const vd_wgrad_desc& d = descs[j];
+                const int64_t ks = ((int64_t)d.nb * d.NP + 31) / 32;
+                total += (int64_t)vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * ((ks + p - 1) / p);
+            }
+            const int64_t rounds = (total + t9 - 1) / t9;
+            const int64_t cost = rounds * (p + slab9);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best_per = p;
+            }
+        }
+        per = best_per;
+    } else if (per > (one ? cap1 : cap3)) per = one ? cap1 : cap3;
     if (per < min_ks) per = min_ks;
     int64_t off = 0;
     int blk = 0, rblk = 0;
@@ -2388,7 +2419,7 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
         memset(&jb, 0, sizeof(jb));
         jb.d = descs[j];
         const vd_wgrad_desc& d = descs[j];
-        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
+        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * (nine ? 1 : 3);
         const int ks = (int)(one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32));
         int splits = (int)((ks + per - 1) / per);
         if (splits < 1) splits = 1;
@@ -2441,11 +2472,17 @@ extern "C" int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls,
 #define VD_WG_K32(WW, MD)                                                                                   \
     if (wgrad_k32_enabled()) hipLaunchKernelGGL((wgrad_k32_group_kernel<WW, MD>), grid, dim3(NT), 0, st, jobs, n); \
     else hipLaunchKernelGGL((wgrad_bx3_group_kernel<WW, MD>), grid, dim3(NT), 0, st, jobs, n);
-        case 4 * 32 + 0: VD_WG_K32(32, 0) break;
+        case 4 * 32 + 0:
+            if (wgrad9_class(cls)) hipLaunchKernelGGL((wgrad9_group_kernel<32>), grid, dim3(512), 0, st, jobs, n, wgrad9_flags());
+            else { VD_WG_K32(32, 0) }
+            break;
         case 4 * 32 + 2: VD_WG_K32(32, 2) break;
         case 4 * 32 + 1: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 0, true>), grid, dim3(NT), 0, st, jobs, n); break;
         case 4 * 32 + 3: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 2, true>), grid, dim3(NT), 0, st, jobs, n); break;
-        case 4 * 16 + 0: VD_WG_K32(16, 0) break;
+        case 4 * 16 + 0:
+            if (wgrad9_class(cls)) hipLaunchKernelGGL((wgrad9_group_kernel<16>), grid, dim3(512), 0, st, jobs, n, wgrad9_flags());
+            else { VD_WG_K32(16, 0) }
+            break;
         case 4 * 16 + 2: VD_WG_K32(16, 2) break;
         case 4 * 8 + 0: VD_WG_K32(8, 0) break;
         case 4 * 8 + 2: VD_WG_K32(8, 2) break;

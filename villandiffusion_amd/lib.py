@@ -54,6 +54,7 @@ PROTOTYPES = {
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),
     "vd_conv_wgrad_group_class": (_i32, [C.POINTER(WgradDesc)]),
     "vd_conv_wgrad_group_job_bytes": (_i64, []),
+    "vd_conv_wgrad_group_variant": (_i32, [_i32]),
     "vd_conv_wgrad_group_plan": (_i32, [C.POINTER(WgradDesc), _i32, _vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)]),
     "vd_conv_wgrad_group_rebase": (_i32, [_vp, _i32, _vp, _vp]),
     "vd_conv_wgrad_group_launch": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),

@@ -466,8 +466,15 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
         _CAPTURE_TABLES.append(ent["table"])              # a cache hit inside a capture: the graph reads this table too
     flops = sum(2.0 * d.M * d.C * d.T * d.nb * d.NP for d in descs)
     nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
-    name = (f"wgrad1x1_bx3_group_kernel(+group_reduce)" if ent["cls"] == 1000 else       # symbol names as rocprofv3 prints them
-            f"wgrad_bx3_group_kernel<{ent['cls'] // 4}, {ent['cls'] & 2}, {'true' if ent['cls'] & 1 else 'false'}>(+group_reduce)")
+    var = lib.vd_conv_wgrad_group_variant(ent["cls"])
+    if ent["cls"] == 1000:                                       # symbol names as rocprofv3 prints them
+        name = "wgrad1x1_bx3_group_kernel(+group_reduce)"
+    elif var == 9:
+        name = f"wgrad9_group_kernel<{ent['cls'] // 4}>(+group_reduce)"
+    elif var == 32:
+        name = f"wgrad_k32_group_kernel<{ent['cls'] // 4}, {ent['cls'] & 2}>(+group_reduce)"
+    else:
+        name = f"wgrad_bx3_group_kernel<{ent['cls'] // 4}, {ent['cls'] & 2}, {'true' if ent['cls'] & 1 else 'false'}>(+group_reduce)"
     _timed(name, flops, "mfma", lambda: L.check(
         lib.vd_conv_wgrad_group_launch(ent["table"].data_ptr(), n, ent["cls"], ent["blocks"], ent["rblocks"], _s()), "vd_conv_wgrad_group_launch"),
         nbytes=nbytes)
