@@ -2389,28 +2389,35 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     const int target = one ? t1 : (nine ? t9 : t3);
     const int min_ks = one ? 4 : 8;
     int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
-    if (nine) {
-        // One workgroup per CU: the launch runs in ROUNDS of t9 workgroups, and a partly filled last round costs a whole one (with the
-        // target / cap rule above, config #2 at 32x32 gets 896 workgroups = 3.5 rounds of 256).  Choose the K-steps per workgroup that minimise
-        // rounds * (K-steps + a per-round charge for the slabs every workgroup writes and the reduce grid re-reads).
-        static const int slab9 = getenv("VD_WGRAD9_SLAB_STEPS") ? atoi(getenv("VD_WGRAD9_SLAB_STEPS")) : 16;
+    const int cap = one ? cap1 : (nine ? cap9 : cap3);
+    if (per > cap) per = cap;
+    // The grid runs in ROUNDS of `target` resident workgroups and a partly filled last round costs a whole one (config #2 at 32x32: 84 tiles x 32
+    // K ranges = 2688 workgroups = 3.5 rounds of 768).  VD_WGRAD_QUANT=1: among the K-range lengths up to the cap, take the one that minimises
+    // rounds * (K-steps + a per-round charge for the slabs each workgroup writes and the reduce grid re-reads).  MEASURED NEUTRAL (three interleaved
+    // rounds on one box: 1.46-1.50 ms at 32x32 either way, 20.3-20.7 ms per step either way), so it stays off: the grouped launches are not
+    // paced by their rounds of workgroups.  (Ranges LONGER than the cap lose a lot: the tiles of a K range stay together in L2 only over ~100
+    // steps -- profiles/r03_wgrad_variants.txt.)
+    static const int quant = getenv("VD_WGRAD_QUANT") ? atoi(getenv("VD_WGRAD_QUANT")) : 0;
+    static const int slab_steps = getenv("VD_WGRAD_SLAB_STEPS") ? atoi(getenv("VD_WGRAD_SLAB_STEPS")) : 8;
+    if (quant) {
         int64_t best_cost = -1, best_per = per;
-        for (int64_t p = min_ks; p <= cap9; ++p) {
+        for (int64_t p = per; p >= (per * 2) / 3 && p >= min_ks; --p) {
             int64_t total = 0;
             for (int j = 0; j < n; ++j) {
                 const vd_wgrad_desc& d = descs[j];
-                const int64_t ks = ((int64_t)d.nb * d.NP + 31) / 32;
-                total += (int64_t)vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * ((ks + p - 1) / p);
+                const int64_t base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * (nine ? 1 : 3);
+                const int64_t ks = one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32);
+                total += base * ((ks + p - 1) / p);
             }
-            const int64_t rounds = (total + t9 - 1) / t9;
-            const int64_t cost = rounds * (p + slab9);
+            const int64_t rounds = (total + target - 1) / target;
+            const int64_t cost = rounds * (p + slab_steps);
             if (best_cost < 0 || cost < best_cost) {
                 best_cost = cost;
                 best_per = p;
             }
         }
         per = best_per;
-    } else if (per > (one ? cap1 : cap3)) per = one ? cap1 : cap3;
+    }
     if (per < min_ks) per = min_ks;
     int64_t off = 0;
     int blk = 0, rblk = 0;
