@@ -333,8 +333,9 @@ def main():
             return final
 
         def timed_sampling():
-            with torch.no_grad():                             # short warm-up of the inference path (graph capture included)
-                pipe(batch_size=min(B, n_img), init=init[:B], num_inference_steps=1000, start_from=995, return_tensor=True)
+            with torch.no_grad():                             # short warm-up of the inference path: one graph capture per distinct chunk size
+                for nb_ in sorted({len(c) for c in torch.split(init, B)}):      # (a remainder chunk must not capture inside the timed region)
+                    pipe(batch_size=nb_, init=init[:nb_], num_inference_steps=1000, start_from=995, return_tensor=True)
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
