@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-f32 leg (profiling runs: the summary then covers the default arithmetic only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph-step", type=int, default=None, choices=(0, 1),
+                    help="1: replay q-sample + forward + loss + backward of the training step as ONE HIP graph (trainer.GraphedMicroStep; single process only); "
+                         "default: the library default (graphs only under gradient accumulation)")
     ap.add_argument("--eager-sample", action="store_true", help="also time the sampling loop with eager launches instead of the HIP-graph replay")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DDIM-50 / DPM-Solver++-20 / UniPC-20 legs (counter-collection passes)")
     ap.add_argument("--serial-wgrad", action="store_true",
@@ -242,7 +245,8 @@ def main():
     dsl = DatasetLoader("SYNTHETIC-CIFAR10", root=ROOT, batch_size=B, seed=0)
     dsl.set_poison("BOX_14", "HAT", poison_rate=0.1).prepare_dataset(mode="FIXED")
     n_batches = (len(dsl) + B * world - 1) // (B * world)
-    trainer = Trainer(net, loss_fn, lr=2e-4, total_steps=n_batches * 50, warmup_steps=500, grad_accum=1)
+    trainer = Trainer(net, loss_fn, lr=2e-4, total_steps=n_batches * 50, warmup_steps=500, grad_accum=1,
+                      graph_micro_step=None if args.graph_step is None else bool(args.graph_step))
     from villandiffusion_amd.trainer import shard_indices
     ids = shard_indices(len(dsl), 0, rank, world, seed=0)
     tgen = torch.Generator(device=dev).manual_seed(100 + rank)
