@@ -389,7 +389,7 @@ def main():
 
     # ---- roofline: per-launch HIP-event timing (on the launch stream) of one extra training step and of one denoising step ----
     def is_split(kname):     # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
-        return "bx3" in kname or "attn_core" in kname or "k32" in kname or "wgrad9" in kname
+        return "bx3" in kname or "attn_core" in kname or "k32" in kname or "wgrad9" in kname or "wgrad1x1_wide" in kname
 
     def peak_of(kname):
         return PEAK_BF16_MFMA_TFLOPS if is_split(kname) else PEAK_F32_MFMA_TFLOPS

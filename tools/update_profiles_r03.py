@@ -117,7 +117,7 @@ if os.path.exists(mp):
         if not n:
             continue
         ex = (mops32 + mops16) * 512 / 1e9
-        split = "bx3" in k or "attn_core" in k or "k32" in k or "wgrad9" in k
+        split = "bx3" in k or "attn_core" in k or "k32" in k or "wgrad9" in k or "wgrad1x1_wide" in k
         e = {"dispatches": v["GRBM_GUI_ACTIVE"]["dispatches"], "GRBM_GUI_ACTIVE": round(g), "SQ_VALU_MFMA_BUSY_CYCLES": round(mb),
              "SQ_INSTS_VALU_MFMA_F32": round(n32), "SQ_INSTS_VALU_MFMA_BF16": round(n16), "executed_gflop_per_launch": round(ex, 2),
              "gflop_per_launch": round(ex / 3 if split else ex, 2), "busy_cycles_per_mfma": round(mb / n, 1),

@@ -2352,6 +2352,7 @@ extern "C" int64_t vd_conv_wgrad_group_job_bytes(void) { return (int64_t)sizeof(
 // (opt-in 16x16x32 one-tap-row kernel), 0 = wgrad_bx3_group_kernel / wgrad1x1_bx3_group_kernel (profiling names, tests).
 extern "C" int vd_conv_wgrad_group_variant(int cls) {
     if (wgrad9_class(cls)) return 9;
+    if (cls == 1000) return wgrad1x1_wide_enabled() ? 256 : 0;
     if (cls != 1000 && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled()) return 32;
     return 0;
 }
@@ -2366,14 +2367,21 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     vd_wgrad_job* jobs = reinterpret_cast<vd_wgrad_job*>(table_out);
     const bool one = cls == 1000;
     const bool nine = wgrad9_class(cls);                         // one workgroup (512 threads, one per CU) per tile produces all nine taps
+    const bool wide1 = one && wgrad1x1_wide_enabled();           // 1x1: BM x 256 tiles, 32-pixel K-steps, one 512-thread workgroup per CU
+    auto job_base = [&](const vd_wgrad_desc& d) -> int64_t {
+        if (wide1) return (int64_t)vd_cdiv(d.M, wgrad1x1_wide_bm(d)) * vd_cdiv(d.C, 256);
+        return one ? (int64_t)vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : (int64_t)vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * (nine ? 1 : 3);
+    };
+    auto job_ks = [&](const vd_wgrad_desc& d) -> int64_t {
+        if (wide1) return ((int64_t)d.nb * (d.NP >> 3) + 3) >> 2;
+        return one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32);
+    };
     int64_t work = 0;
     for (int j = 0; j < n; ++j) {
         const vd_wgrad_desc& d = descs[j];
         VD_REQUIRE(d.dY && d.X && d.dW && wgrad_group_class(d) == cls, "vd_conv_wgrad_group_plan: job %d is of another kernel class (%d vs %d)", j,
                    wgrad_group_class(d), cls);
-        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * (nine ? 1 : 3);
-        const int64_t ks = one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32);
-        work += base * ks;
+        work += job_base(d) * job_ks(d);
     }
     // K-steps per workgroup: enough workgroups to fill the chip (768 / 512 slots), but no K range longer than `cap` steps: the tiles
     // that share a K range (3 tap rows x C/64 for dY, x M/128 for X) run side by side on one XCD and re-read it through that XCD's
@@ -2386,10 +2394,12 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     static const int cap1 = getenv("VD_W1X1_GROUP_KCAP") ? atoi(getenv("VD_W1X1_GROUP_KCAP")) : 32;
     static const int t9 = getenv("VD_WGRAD9_TARGET") ? atoi(getenv("VD_WGRAD9_TARGET")) : 256;
     static const int cap9 = getenv("VD_WGRAD9_KCAP") ? atoi(getenv("VD_WGRAD9_KCAP")) : 128;
-    const int target = one ? t1 : (nine ? t9 : t3);
-    const int min_ks = one ? 4 : 8;
+    static const int tw = getenv("VD_W1X1_WIDE_TARGET") ? atoi(getenv("VD_W1X1_WIDE_TARGET")) : 256;
+    static const int capw = getenv("VD_W1X1_WIDE_KCAP") ? atoi(getenv("VD_W1X1_WIDE_KCAP")) : 64;
+    const int target = wide1 ? tw : (one ? t1 : (nine ? t9 : t3));
+    const int min_ks = one ? (wide1 ? 8 : 4) : 8;
     int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
-    const int cap = one ? cap1 : (nine ? cap9 : cap3);
+    const int cap = wide1 ? capw : (one ? cap1 : (nine ? cap9 : cap3));
     if (per > cap) per = cap;
     // The grid runs in ROUNDS of `target` resident workgroups and a partly filled last round costs a whole one (config #2 at 32x32: 84 tiles x 32
     // K ranges = 2688 workgroups = 3.5 rounds of 768).  VD_WGRAD_QUANT=1: among the K-range lengths up to the cap, take the one that minimises
@@ -2404,10 +2414,7 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
         for (int64_t p = per; p >= (per * 2) / 3 && p >= min_ks; --p) {
             int64_t total = 0;
             for (int j = 0; j < n; ++j) {
-                const vd_wgrad_desc& d = descs[j];
-                const int64_t base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * (nine ? 1 : 3);
-                const int64_t ks = one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32);
-                total += base * ((ks + p - 1) / p);
+                total += job_base(descs[j]) * ((job_ks(descs[j]) + p - 1) / p);
             }
             const int64_t rounds = (total + target - 1) / target;
             const int64_t cost = rounds * (p + slab_steps);
@@ -2426,8 +2433,8 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
         memset(&jb, 0, sizeof(jb));
         jb.d = descs[j];
         const vd_wgrad_desc& d = descs[j];
-        const int base = one ? vd_cdiv(d.M, 128) * vd_cdiv(d.C, 128) : vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * (nine ? 1 : 3);
-        const int ks = (int)(one ? (((int64_t)d.nb * (d.NP >> 3) + 7) >> 3) : (((int64_t)d.nb * d.NP + 31) / 32));
+        const int base = (int)job_base(d);
+        const int ks = (int)job_ks(d);
         int splits = (int)((ks + per - 1) / per);
         if (splits < 1) splits = 1;
         const int ks_per = vd_cdiv(ks, splits);
@@ -2475,7 +2482,16 @@ extern "C" int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls,
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(blocks);
     switch (cls) {
-        case 1000: hipLaunchKernelGGL(wgrad1x1_bx3_group_kernel, grid, dim3(NT), 0, st, jobs, n); break;
+        case 1000:
+            if (wgrad1x1_wide_enabled()) {
+                static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_wide_group_kernel),
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, W1X1_WIDE_LDS);
+                VD_REQUIRE(attr == hipSuccess, "vd_conv_wgrad_group_launch: cannot reserve %d bytes of LDS", W1X1_WIDE_LDS);
+                hipLaunchKernelGGL(wgrad1x1_wide_group_kernel, grid, dim3(512), W1X1_WIDE_LDS, st, jobs, n);
+            } else {
+                hipLaunchKernelGGL(wgrad1x1_bx3_group_kernel, grid, dim3(NT), 0, st, jobs, n);
+            }
+            break;
 #define VD_WG_K32(WW, MD)                                                                                   \
     if (wgrad_k32_enabled()) hipLaunchKernelGGL((wgrad_k32_group_kernel<WW, MD>), grid, dim3(NT), 0, st, jobs, n); \
     else hipLaunchKernelGGL((wgrad_bx3_group_kernel<WW, MD>), grid, dim3(NT), 0, st, jobs, n);

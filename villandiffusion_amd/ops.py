@@ -468,7 +468,7 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
     nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
     var = lib.vd_conv_wgrad_group_variant(ent["cls"])
     if ent["cls"] == 1000:                                       # symbol names as rocprofv3 prints them
-        name = "wgrad1x1_bx3_group_kernel(+group_reduce)"
+        name = "wgrad1x1_wide_group_kernel(+group_reduce)" if var == 256 else "wgrad1x1_bx3_group_kernel(+group_reduce)"
     elif var == 9:
         name = f"wgrad9_group_kernel<{ent['cls'] // 4}>(+group_reduce)"
     elif var == 32:
