@@ -145,3 +145,45 @@ def test_lpips_matches_oracle_on_random_weights():
     fa, fr = net.features(torch.rand(2, 3, 64, 64, generator=g(9)).cuda()), ref.net((torch.rand(2, 3, 64, 64, generator=g(9)) - ref.shift) / ref.scale)
     for k, (x, y) in enumerate(zip(fa, fr)):
         assert rel(x, y) < 2e-5, k
+
+
+def test_measure_wiring_fills_fid_and_lpips_when_local_weights_exist(tmp_path, monkeypatch):
+    """measure() / measure_inpaints() of the drop-in driver (reference VillanDiffusion.py:1072 and :892): with the weight files present locally the
+    scores are numbers (here: seeded random weights in the published key layout), without them None plus the reason -- never a silent fallback."""
+    from types import SimpleNamespace
+    from PIL import Image
+    import VillanDiffusion as V
+    from oracle.lpips_ref import LPIPSRef
+    rng = np.random.default_rng(1)
+    clean = tmp_path / "clean"
+    clean.mkdir()
+    for i in range(24):
+        Image.fromarray(rng.integers(0, 255, size=(32, 32, 3), dtype=np.uint8)).save(clean / f"{i}.png")
+    data = rng.integers(0, 255, size=(64, 32, 32, 3), dtype=np.uint8)
+    cfg = SimpleNamespace(dataset="SYNTHETIC-CIFAR10", seed=0, eval_max_batch=8)
+    dsl = SimpleNamespace(_images=data)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("VILLAN_CKPT_ROOT", str(tmp_path / "nothing-here"))
+    for k in ("VILLAN_FID_WEIGHTS", "VILLAN_ALEXNET_WEIGHTS", "VILLAN_LPIPS_WEIGHTS"):
+        monkeypatch.delenv(k, raising=False)
+    assert V.measure_fid(cfg, dsl, str(clean), 24) is None
+    a, b = torch.rand(6, 3, 32, 32, generator=g(1)), torch.rand(6, 3, 32, 32, generator=g(2))
+    assert V.measure_lpips(a, b, 4) is None
+    # the published files' key layout, random values
+    ref = InceptionV3Ref((3,)).randomize(4)
+    sd = dict(ref.state_dict())
+    sd["fc.weight"], sd["fc.bias"] = torch.zeros(1008, 2048), torch.zeros(1008)          # present in pt_inception-2015-12-05: must be ignored
+    torch.save(sd, tmp_path / "inc.pth")
+    monkeypatch.setenv("VILLAN_FID_WEIGHTS", str(tmp_path / "inc.pth"))
+    fid_sc = V.measure_fid(cfg, dsl, str(clean), 24)
+    assert isinstance(fid_sc, float) and np.isfinite(fid_sc) and fid_sc >= -1e-3
+    assert len(os.listdir(tmp_path / "measure" / "SYNTHETIC-CIFAR10")) == 24              # the dataset side was written as PNGs (reference :1043-1049)
+    lp = LPIPSRef().randomize(5)
+    fsd = lp.flat_state_dict()
+    torch.save({k: v for k, v in fsd.items() if k.startswith("features.")}, tmp_path / "alexnet.pth")
+    torch.save({k: v for k, v in fsd.items() if k.startswith("lin")}, tmp_path / "lins.pth")
+    monkeypatch.setenv("VILLAN_ALEXNET_WEIGHTS", str(tmp_path / "alexnet.pth"))
+    monkeypatch.setenv("VILLAN_LPIPS_WEIGHTS", str(tmp_path / "lins.pth"))
+    got = V.measure_lpips(a, b, 4)
+    want = float(lp(a, b).mean())
+    assert abs(got - want) <= 1e-4 * abs(want)
