@@ -758,6 +758,10 @@ GROUPS = [
     (16, B_CONV3, [(128, 256, 256), (128, 512, 256), (128, 128, 256)]),
     (32, B_PLAIN, [(128, 384, 128), (128, 256, 128)]),
     (16, B_PLAIN, [(128, 256, 768), (128, 512, 256)]),
+    # tiny images: a 32-pixel K-step spans several images and the last step is partly empty (regression: its invalid octets must not address an
+    # image in front of the step's descriptor base)
+    (4, B_PLAIN, [(3, 128, 64), (5, 256, 192), (7, 64, 64)]),
+    (8, B_PLAIN, [(3, 64, 128), (1, 320, 72)]),
 ]
 
 
