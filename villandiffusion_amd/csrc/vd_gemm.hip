@@ -2043,7 +2043,8 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             if (bx3_big_split(d)) return 16;                           // 16: 8x8 layers, 128 x 256 tiles with the channel loop split
             const int big = big_off ? 0 : bx3_big_tile(d, splits);
             static const int keep_huge = getenv("VD_BX3_K32_KEEP_HUGE") ? atoi(getenv("VD_BX3_K32_KEEP_HUGE")) : 0;
-            if (big >= 1 && !(big == 2 && keep_huge) && conv3_k32_eligible(d)) return 17;      // 17: conv3_k32_kernel (16x16x32 MFMA, 128 x 256 tile)
+            static const int k32_up32 = getenv("VD_BX3_K32_UP32") ? atoi(getenv("VD_BX3_K32_UP32")) : 0;
+            if (big >= 1 && !(big == 2 && (keep_huge || (d.b_mode == VD_B_CONV3_UP && !k32_up32))) && conv3_k32_eligible(d)) return 17;      // 17: conv3_k32_kernel (16x16x32 MFMA, 128 x 256 tile)
             return big == 2 ? 15 : (big == 1 ? 12 : 8);                // 12 / 15: the 128 x 256 / 128 x 512 tile, eight waves
         }
         if (!gemm_bx3_eligible(d)) return -1;
