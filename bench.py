@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config #2)")
     ap.add_argument("--sample-steps", type=int, default=1000)
-    ap.add_argument("--sample-images", type=int, default=128, help="per-GPU images of the DDPM sampling leg (0 = skip)")
+    ap.add_argument("--sample-images", type=int, default=384, help="per-GPU images of the DDPM sampling leg, in chunks of --batch (0 = skip)")
+    ap.add_argument("--sample-streams", type=int, default=3,
+                    help="chunks denoised concurrently, each on its own stream / HIP graph (pipelines.sample_concurrent); 1: one after the other")
     ap.add_argument("--mode", choices=("all", "train", "sample"), default="all",
                     help="train: training legs only (no sampler) / sample: sampler only -- so that a rocprofv3 summary covers ONE dispatch population")
     ap.add_argument("--cpu-batch", type=int, default=128, help="batch of the CPU-oracle training baseline (SURVEY 8d: 128)")
@@ -331,7 +333,10 @@ def main():
 
         def sample_all(steps):
             chunks = torch.split(init, B)
-            outs = [pipe(batch_size=len(c), init=c, num_inference_steps=steps, return_tensor=True) for c in chunks]
+            if args.sample_streams > 1 and len(chunks) > 1 and net.sampler_graph:
+                outs = pipe.sample_concurrent(list(chunks), num_inference_steps=steps, n_streams=args.sample_streams)
+            else:
+                outs = [pipe(batch_size=len(c), init=c, num_inference_steps=steps, return_tensor=True) for c in chunks]
             final = torch.cat(outs)
             ops.postprocess(final, pp, 0.5, 0.5, 0.0, 1.0, True)      # (x/2+0.5).clamp(0,1), NHWC; PNG encode excluded
             return final
@@ -340,6 +345,8 @@ def main():
             with torch.no_grad():                             # short warm-up of the inference path: one graph capture per distinct chunk size
                 for nb_ in sorted({len(c) for c in torch.split(init, B)}):      # (a remainder chunk must not capture inside the timed region)
                     pipe(batch_size=nb_, init=init[:nb_], num_inference_steps=1000, start_from=995, return_tensor=True)
+                if args.sample_streams > 1 and n_img > B and net.sampler_graph:   # ... nor the second stream's graph
+                    pipe.sample_concurrent(list(torch.split(init, B))[:args.sample_streams], num_inference_steps=3, n_streams=args.sample_streams)
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -372,12 +379,19 @@ def main():
                                     ("dpm_solver_pp_o2_20", lambda: DPMSolverMultistepScheduler(), PNDMPipeline, 20),
                                     ("unipc20", lambda: UniPCMultistepScheduler(), PNDMPipeline, 20))):
             p2 = pcls(net, mk())
-            c0 = init[:B]
-            p2(batch_size=len(c0), init=c0, num_inference_steps=nst, return_tensor=True)          # warm-up
+            conc = args.sample_streams > 1 and n_img > B and net.sampler_graph
+            c0 = init if conc else init[:B]
+
+            def run2():
+                if conc:
+                    return torch.cat(p2.sample_concurrent(list(torch.split(c0, B)), num_inference_steps=nst, n_streams=args.sample_streams))
+                return p2(batch_size=len(c0), init=c0, num_inference_steps=nst, return_tensor=True)
+
+            run2()                                                                                 # warm-up
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            o = p2(batch_size=len(c0), init=c0, num_inference_steps=nst, return_tensor=True)
+            o = run2()
             ops.postprocess(o, pp[:len(c0)], 0.5, 0.5, 0.0, 1.0, True)
             torch.cuda.synchronize()
             barrier()
@@ -525,13 +539,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": None if ms is None else round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3/f32" if split else "f32", "data": "synthetic",
             "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), per-GPU batch %d; "
-                                   "+ %d-step DDPM sampling of %d images/GPU in chunks of %d (SURVEY 8d: 1024 = 8 such chunks, same per-chunk work)"
-                                   % (B, args.sample_steps, args.sample_images, B),
+                                   "+ %d-step DDPM sampling of %d images/GPU in chunks of %d, %d chunks at a time on their own streams (SURVEY 8d: 1024 = 8 such chunks)"
+                                   % (B, args.sample_steps, args.sample_images, B, args.sample_streams),
                        "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}", "mode": args.mode},
             "exact_f32_mode": None if exact is None else {k: exact[k] for k in ("train_images_per_sec", "ms_per_step")},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
             "sample_seconds": None if sample_s is None else round(sample_s, 2),
-            "sample_hip_graph": bool(net.sampler_graph),
+            "sample_hip_graph": bool(net.sampler_graph), "sample_streams": args.sample_streams if args.sample_images > B else 1,
             "sample_secondary_images_per_sec": secondary,
             "train_tflops": None if train_ips is None else round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
             "sample_tflops": None if sample_ips is None else round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3, 2),

@@ -74,14 +74,39 @@ def _img(t: torch.Tensor):
 
 # --------------------------------------------------------------------------------------------- GEMM family
 _GEMM_WS = {}
+_WS_SLOT = 0
+
+
+class ws_slot:
+    """Launch sequences that run CONCURRENTLY on different streams (the sampler's interleaved chunks, pipelines.sample_concurrent) must not share
+    the split-K workspace: each takes its own slot.  `with ops.ws_slot(k): ...` around everything that launches (or captures) on that stream."""
+
+    def __init__(self, slot: int):
+        self.slot, self.prev = int(slot), 0
+
+    def __enter__(self):
+        global _WS_SLOT
+        self.prev, _WS_SLOT = _WS_SLOT, self.slot
+        return self
+
+    def __exit__(self, *exc):
+        global _WS_SLOT
+        _WS_SLOT = self.prev
+        return False
+
+
+def gemm_ws_buffer(device, slot: int = None):
+    """The current split-K workspace tensor of (device, slot), or None (graph owners compare it by identity to know their capture is still valid)."""
+    return _GEMM_WS.get((device, _WS_SLOT if slot is None else slot))
 
 
 def _gemm_ws(n_floats: int, device):
-    """Per-device split-K workspace, grown on demand (launches on one stream are ordered, so it can be shared)."""
-    t = _GEMM_WS.get(device)
+    """Per-(device, slot) split-K workspace, grown on demand (launches on one stream are ordered, so one stream's launches share it)."""
+    key = (device, _WS_SLOT)
+    t = _GEMM_WS.get(key)
     if t is None or t.numel() < n_floats:
         t = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
-        _GEMM_WS[device] = t
+        _GEMM_WS[key] = t
     return t
 
 

@@ -40,31 +40,33 @@ class GraphedForward:
     valid across optimiser steps; the split-precision operands are refreshed (outside the graph) when the weights have changed.
     Inputs are copied into static buffers, the output out of one."""
 
-    def __init__(self, unet, batch, dtype=torch.float32):
+    def __init__(self, unet, batch, dtype=torch.float32, slot: int = 0):
         dev = unet.device
         self.unet = unet
+        self.slot = slot                                  # split-K workspace slot: graphs replayed concurrently must not share one (ops.ws_slot)
         self.x = torch.zeros((batch, unet.in_channels, unet.sample_size, unet.sample_size), device=dev, dtype=dtype)
         self.t = torch.zeros((batch,), device=dev, dtype=torch.float32)
         self.key = self._key()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                     # warm-up on a side stream: workspaces, packed operands, allocator pools
-            for _ in range(2):
-                unet._run_forward(self.x, self.t, save=False)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._keep = (ops._GEMM_WS.get(dev), getattr(unet, "_packed", None))     # buffers whose addresses are baked into the graph
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: a HIP call from ANOTHER thread during capture (the RCCL watchdog of a DDP run whose rank 0 samples) must not abort it
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = unet._run_forward(self.x, self.t, save=False)[0]
+        with ops.ws_slot(slot):
+            with torch.cuda.stream(side):                 # warm-up on a side stream: workspaces, packed operands, allocator pools
+                for _ in range(2):
+                    unet._run_forward(self.x, self.t, save=False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._keep = (ops.gemm_ws_buffer(dev, slot), getattr(unet, "_packed", None))     # buffers whose addresses are baked into the graph
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: a HIP call from ANOTHER thread during capture (the RCCL watchdog of a DDP run whose rank 0 samples) must not abort it
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.out = unet._run_forward(self.x, self.t, save=False)[0]
 
     def _key(self):
         u = self.unet
         return (u.conv_math, u.fuse_gn_inference, getattr(u, "fused_attention", None), u.sample_size, u.in_channels, u.flat_param.data_ptr())
 
     def valid(self) -> bool:
-        return self.key == self._key() and self._keep[0] is ops._GEMM_WS.get(self.unet.device)
+        return self.key == self._key() and self._keep[0] is ops.gemm_ws_buffer(self.unet.device, self.slot)
 
     def __call__(self, x, t):
         u = self.unet
@@ -76,24 +78,26 @@ class GraphedForward:
         return self.out.clone()          # multistep samplers keep model outputs across steps: never hand out the static buffer itself
 
 
-def sampler_forward(unet, batch):
+def sampler_forward(unet, batch, slot: int = 0):
     """eps = f(x, t) for the sampler loops: the HIP-graph replay where the network supports it (UNet2DModel, `unet.sampler_graph`), else
-    the eager launch sequence."""
+    the eager launch sequence.  `slot` > 0: a second, independent graph of the same batch size for a chunk that runs concurrently on another stream."""
     use = getattr(unet, "sampler_graph", False) and isinstance(unet, UNet2DModel) and unet.device.type == "cuda"
     if not use:
+        if slot:
+            raise RuntimeError("concurrent sampler chunks need the HIP-graph forward (UNet2DModel with sampler_graph)")
         return lambda x, t: unet(x, t, return_dict=False)[0]
     cache = unet.__dict__.setdefault("_fwd_graphs", {})
-    g = cache.pop(batch, None)
+    g = cache.pop((batch, slot), None)
     if g is None or not g.valid():
         g = None
         while len(cache) >= MAX_CACHED_GRAPHS:            # each graph's private pool pins the peak memory of a no-grad forward: keep the newest few
             cache.pop(next(iter(cache)))
-        g = GraphedForward(unet, batch)
-    cache[batch] = g                                      # (re-)inserted last: the dict is the LRU order
+        g = GraphedForward(unet, batch, slot=slot)
+    cache[(batch, slot)] = g                              # (re-)inserted last: the dict is the LRU order
     return g
 
 
-MAX_CACHED_GRAPHS = 2
+MAX_CACHED_GRAPHS = 4
 
 
 def drop_sampler_graphs(unet):
@@ -162,6 +166,64 @@ class DiffusionPipeline:
             from PIL import Image
             images = [Image.fromarray(im.squeeze()) for im in (images * 255).round().astype("uint8")]
         return SimpleNamespace(images=images, movie=movie)
+
+    @torch.no_grad()
+    def sample_concurrent(self, inits, num_inference_steps: Optional[int] = None, n_streams: int = 2, eta: Optional[float] = None):
+        """Throughput mode of the measure / sampling loops (reference VillanDiffusion.py:1062-1067 walks its chunks of `eval_max_batch` one after
+        the other): the chunks of `inits` are denoised `n_streams` at a time, each on its own HIP stream with its own captured forward, its own
+        split-K workspace and its own copy of the scheduler state, stepping in lock-step on the host.  A denoising step is ~250 kernels, a fifth
+        of them grids that cannot fill the chip (the 8x8 / 4x4 stages, GroupNorm of small maps, the time-embedding linears) plus a dependency gap
+        after every kernel: a second chunk's launches fill those holes.  Noise comes from the in-kernel Philox stream (`scheduler.device_rng_seed`
+        must be set); chunk c owns the offset range starting at `chunk_rng_offset(c, ...)`, so a chunk's result does not depend on what runs beside
+        it: it is bit-identical to a sequential `__call__` started at the same offset.  Returns the list of final states (device tensors)."""
+        import copy
+        unet, dev = self.unet, self.device
+        n = num_inference_steps if num_inference_steps is not None else self.default_steps
+        base = self.scheduler
+        if getattr(base, "device_rng_seed", None) is None and type(base).__name__ in ("DDPMScheduler", "ScoreSdeVeScheduler"):
+            raise RuntimeError("sample_concurrent draws its noise on the device: set scheduler.device_rng_seed")
+        base.set_timesteps(n)
+        sigma_space = float(base.init_noise_sigma) != 1.0
+        ts = base.timesteps
+        outs = [None] * len(inits)
+        off0 = getattr(base, "_rng_offset", 0)
+        main = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        for first in range(0, len(inits), n_streams):
+            group = list(range(first, min(first + n_streams, len(inits))))
+            states = []
+            for k, ci in enumerate(group):
+                sch = copy.deepcopy(base)
+                if hasattr(sch, "_rng_offset"):
+                    sch._rng_offset = off0 + self.chunk_rng_offset(ci, len(ts), max(c.numel() for c in inits))
+                x = inits[ci].to(dev).float().contiguous()
+                streams[k].wait_stream(main)
+                with torch.cuda.stream(streams[k]), ops.ws_slot(k):
+                    if sigma_space:
+                        x = ops.lincomb(torch.empty_like(x), [x], [float(sch.init_noise_sigma)])
+                    fwd = sampler_forward(unet, x.shape[0], slot=k)
+                    t_tab = ts.to(torch.float32).to(dev)[:, None].expand(len(ts), x.shape[0]).contiguous()
+                states.append([sch, x, fwd, t_tab])
+            kw = self._step_kwargs(None, eta)
+            for step, t in enumerate(ts if sigma_space else ts.tolist()):
+                for k, st in enumerate(states):
+                    sch, x, fwd, t_tab = st
+                    with torch.cuda.stream(streams[k]), ops.ws_slot(k):
+                        x_in = sch.scale_model_input(x, t) if sigma_space else x
+                        eps = fwd(x_in, t_tab[step])
+                        st[1] = sch.step(eps, t, x, **kw).prev_sample
+            for k, ci in enumerate(group):
+                main.wait_stream(streams[k])
+                outs[ci] = states[k][1]
+        if hasattr(base, "_rng_offset"):
+            base._rng_offset = off0 + self.chunk_rng_offset(len(inits), len(ts), max(c.numel() for c in inits))
+        return outs
+
+    @staticmethod
+    def chunk_rng_offset(chunk: int, n_steps: int, numel: int) -> int:
+        """First Philox offset of chunk `chunk` relative to the scheduler's offset at the call: disjoint ranges of 2 draws per step (no sampler
+        here draws more) of the largest chunk."""
+        return chunk * 2 * n_steps * ((numel + 3) // 4)
 
     # ---- diffusers on-disk layout ----
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True):

@@ -123,7 +123,7 @@ class GraphedMicroStep:
         if _DEBUG:
             print("[graph] warm-up done", flush=True)
         net.flat_grad.copy_(keep)                         # the warm-up passes accumulated gradients: undo
-        self._keep = (ops._GEMM_WS.get(dev), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws)
+        self._keep = (ops.gemm_ws_buffer(dev, 0), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws)
         self.graph = torch.cuda.CUDAGraph()
         ops.capture_begin(dev)                            # job tables built during the capture are uploaded right after it (ops.upload_table)
         try:
@@ -141,7 +141,7 @@ class GraphedMicroStep:
 
     def valid(self) -> bool:
         dev = self.net.device
-        return (self.key == self._key() and self._keep[0] is ops._GEMM_WS.get(dev) and self._keep[1] is ops._WG_WS.get(dev)
+        return (self.key == self._key() and self._keep[0] is ops.gemm_ws_buffer(dev, 0) and self._keep[1] is ops._WG_WS.get(dev)
                 and self._keep[3] is self.net.wgrad_ws)
 
     def _body(self):
