@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 5
+#define VD_ABI_VERSION 6
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -219,6 +219,16 @@ int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const f
                      const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws,
                      int B, int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride,
                      int64_t extra_bstride, int64_t dx_bstride, float* ws, void* stream);
+/* The same with a second residual gradient (extra2: the gradient a skip connection carries into x -- replaces the
+ * vd_add_strided pass after the block, VillanDiffusion's UNet concatenates skips: SURVEY 3.4) and, when rowsum != NULL,
+ * rowsum[b*rowsum_ld + c] = sum_p dx[b][c][p]: the per-image bias-gradient rows of the layer that produced x (autograd's
+ * conv2d bias gradient is the sum of its dY = this dx over batch and pixels; the per-image rows also are the
+ * time_emb_proj output gradient of a ResnetBlock2D).  NULL extra / extra2 / rowsum are skipped. */
+int vd_groupnorm_bwd_fused(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, const float* extra, const float* extra2, float* dx, float* dgamma_ws,
+                           float* dbeta_ws, float* rowsum, int B, int C, int HW, int G, int apply_silu,
+                           int64_t dy_bstride, int64_t x_bstride, int64_t extra_bstride, int64_t extra2_bstride,
+                           int64_t dx_bstride, int64_t rowsum_ld, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4 -- attention softmax.  S is [nb][N][N] stored key-major: S[b][j][i] = k_j . q_i * scale;

@@ -215,6 +215,21 @@ def test_groupnorm_silu(B, C, H, silu):
     ops.colsum(wb, db, B, C)
     check(dg, gamma.grad, 3e-5, "groupnorm dgamma")
     check(db, beta.grad, 3e-5, "groupnorm dbeta")
+    # vd_groupnorm_bwd_fused: a second residual gradient (a channel slice of a wider buffer, like a skip connection's) and the per-image
+    # channel sums of the dx written (rows of a wider matrix) from the same pass; every kernel family (register-resident, chunked, generic)
+    e2buf = torch.randn(B, C + 64, H, H, generator=g(5)).to(DEV)
+    e2 = e2buf[:, 64:]
+    rs = torch.full((B, C + 8), -7.0, device=DEV)
+    dx2 = torch.empty(B, C, H, H, device=DEV)
+    ops.groupnorm_bwd(dy.to(DEV), xv, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV), dx2, wg, wb, 32, silu,
+                      extra=extra.to(DEV), extra2=e2, rowsum=rs[:, 8:], rowsum_ld=C + 8)
+    want = x.grad + extra + e2.cpu()
+    check(dx2, want, 3e-5, "groupnorm dx(+extra+extra2)")
+    check(rs[:, 8:], want.sum((2, 3)), 3e-5, "groupnorm fused row sums")
+    assert torch.all(rs[:, :8] == -7.0)
+    ops.groupnorm_bwd(dy.to(DEV), xv, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV), dx2, wg, wb, 32, silu, rowsum=rs[:, 8:],
+                      rowsum_ld=C + 8)
+    check(rs[:, 8:], x.grad.sum((2, 3)), 3e-5, "groupnorm fused row sums, no residuals")
 
 
 def _attn_ref(qkv, C, scale):

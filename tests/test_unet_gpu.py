@@ -96,6 +96,30 @@ def test_backward_matches_oracle(pair):
     assert float(net.flat_grad.abs().max()) == 0.0
 
 
+def test_fused_groupnorm_backward_side_passes_equal_the_separate_launches(pair):
+    """Bias-gradient row sums and skip-gradient adds inside vd_groupnorm_bwd_fused (default) against the rowsum / add_strided launches
+    they replace: same gradient up to the summation order."""
+    ref, net = pair
+    x = torch.randn(3, 3, 32, 32, generator=torch.Generator().manual_seed(12)).cuda()
+    t = torch.tensor([5, 420, 990]).cuda()
+    grads = {}
+    assert net.fuse_gn_bwd
+    try:
+        for fuse in (True, False):
+            net.fuse_gn_bwd = fuse
+            net.zero_grad()
+            net(x, t)[0].square().sum().backward()
+            grads[fuse] = net.flat_grad.clone()
+    finally:
+        net.fuse_gn_bwd = True
+        net.zero_grad()
+    biases = torch.cat([p.grad.flatten() for n, p in net.named_parameters() if n.endswith(".bias")])
+    assert biases.numel() > 10000
+    e = float((grads[True] - grads[False]).abs().max() / grads[False].abs().max())
+    print(f"[parity] fused GroupNorm-backward side passes vs separate launches ({net.conv_math}): {e:.3e}")
+    assert 0 < float(grads[True].abs().max()) and e < 2e-6, e
+
+
 def test_gradient_buckets_are_final_when_their_hook_fires(pair):
     """The trainer overlaps the all-reduce of bucket i with the rest of backward: at hook(i) the bucket must already hold
     its final value."""

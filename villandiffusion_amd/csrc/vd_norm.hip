@@ -257,9 +257,10 @@ __global__ __launch_bounds__(NTH) void gn_bwd_reg_kernel(const float* __restrict
                                                          const float* __restrict__ extra, float* __restrict__ dx,
                                                          float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws, int C,
                                                          int HW, int G, int apply_silu, int64_t dy_bs, int64_t x_bs,
-                                                         int64_t ex_bs, int64_t dx_bs) {
-    __shared__ float ch_s1[64], ch_s2[64];
-    __shared__ float part1[NV * (NTH / 64)], part2[NV * (NTH / 64)];
+                                                         int64_t ex_bs, int64_t dx_bs, const float* __restrict__ extra2,
+                                                         int64_t ex2_bs, float* __restrict__ rs_out, int64_t rs_ld) {
+    __shared__ float ch_s1[64], ch_s2[64], ch_s3[64];
+    __shared__ float part1[NV * (NTH / 64)], part2[NV * (NTH / 64)], part3[NV * (NTH / 64)];
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int cpg = C / G;
     const int n4 = (cpg * HW) >> 2;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(NTH) void gn_bwd_reg_kernel(const float* __restrict
     const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff);
     const f32x4* __restrict__ d4 = reinterpret_cast<const f32x4*>(dy + (int64_t)b * dy_bs + goff);
     const f32x4* __restrict__ e4 = extra ? reinterpret_cast<const f32x4*>(extra + (int64_t)b * ex_bs + goff) : nullptr;
+    const f32x4* __restrict__ f4 = extra2 ? reinterpret_cast<const f32x4*>(extra2 + (int64_t)b * ex2_bs + goff) : nullptr;
     f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(dx + (int64_t)b * dx_bs + goff);
     const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,13 +346,46 @@ __global__ __launch_bounds__(NTH) void gn_bwd_reg_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * NTH;
-        if (idx < n4) {
+        const bool in = idx < n4;
+        float s3 = 0.f;
+        if (in) {
             const float ga = gamma[g * cpg + idx / L];
             f32x4 ev = {0.f, 0.f, 0.f, 0.f}, o;
             if (e4) ev = e4[idx];
+            if (f4) {
+                const f32x4 fv = f4[idx];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = rstd * (dz[i][j] * ga - m1 - xh[i][j] * m2) + ev[j];
+                for (int j = 0; j < 4; ++j) ev[j] += fv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = rstd * (dz[i][j] * ga - m1 - xh[i][j] * m2) + ev[j];
+                s3 += o[j];
+            }
             o4[idx] = o;
+        }
+        if (rs_out) {                                         // per-channel sums of the dx just written (the consumer's bias gradient rows)
+            if (L >= 64) {
+                s3 = wave_sum(s3);
+                if (lane == 0) part3[i * (NTH / 64) + wave] = s3;
+            } else {
+                for (int off = 1; off < L; off <<= 1) s3 += __shfl_xor(s3, off, 64);
+                if (in && (lane & (L - 1)) == 0) ch_s3[idx / L] = s3;
+            }
+        }
+    }
+    if (rs_out) {
+        __syncthreads();
+        if (tid < cpg) {
+            float a3;
+            if (L >= 64) {
+                const int np = L >> 6;
+                a3 = 0.f;
+                for (int k = 0; k < np; ++k) a3 += part3[tid * np + k];
+            } else {
+                a3 = ch_s3[tid];
+            }
+            rs_out[(int64_t)b * rs_ld + g * cpg + tid] = a3;
         }
     }
 }
@@ -620,44 +655,65 @@ extern "C" int vd_groupnorm_stats(const float* x, const float* gamma, const floa
     return 0;
 }
 
-extern "C" int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws, int B,
-                                int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride,
-                                int64_t extra_bstride, int64_t dx_bstride, float* ws, void* stream) {
+extern "C" int vd_rowsum(const float* x, float* ws, int B, int M, int HW, int64_t x_bstride, int64_t ws_ld, void* stream);
+extern "C" int vd_add_strided(float* dst, const float* src, int B, int64_t inner, int64_t dst_bstride, int64_t src_bstride, int accumulate,
+                              void* stream);
+
+// dx = GroupNorm(+SiLU) backward + extra + extra2 (two residual gradients: the block's own and a skip connection's), and optionally
+// rowsum[b*rowsum_ld + c] = sum_p dx[b][c][p] -- the bias-gradient rows of whichever convolution produced x (its dY IS this dx).  On the
+// register-resident kernels both ride in the pass that writes dx; the other paths fall back to vd_add_strided / vd_rowsum launches.
+extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                      const float* beta, const float* extra, const float* extra2, float* dx, float* dgamma_ws,
+                                      float* dbeta_ws, float* rowsum, int B, int C, int HW, int G, int apply_silu, int64_t dy_bstride,
+                                      int64_t x_bstride, int64_t extra_bstride, int64_t extra2_bstride, int64_t dx_bstride,
+                                      int64_t rowsum_ld, float* ws, void* stream) {
     VD_REQUIRE(dy && x && mean && rstd && gamma && beta && dx && dgamma_ws && dbeta_ws, "vd_groupnorm_bwd: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 64, "vd_groupnorm_bwd: bad dims");
+    VD_REQUIRE(!rowsum || rowsum_ld >= C, "vd_groupnorm_bwd: rowsum_ld < C");
     const int64_t slab = (int64_t)(C / G) * HW;
     const int L = HW / 4;
-    const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)extra)) & 15) == 0 &&
-                    ((x_bstride | dy_bstride | dx_bstride | extra_bstride) & 3) == 0;
+    const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)extra) | ((uintptr_t)extra2)) & 15) == 0 &&
+                    ((x_bstride | dy_bstride | dx_bstride | extra_bstride | extra2_bstride) & 3) == 0;
     const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
+    const bool reg_ok = !S && al && HW % 4 == 0 && slab <= 12 * 1024 &&
+                        ((L >= 64 && L % 64 == 0) || (L < 64 && (L & (L - 1)) == 0 && L > 0)) && getenv("VD_GN_BWD_GENERIC") == nullptr;
+    if (reg_ok) {
+#define VD_GN_BWD(NVV, NT)                                                                                                          \
+    hipLaunchKernelGGL((gn_bwd_reg_kernel<NVV, NT>), dim3(B * G), dim3(NT), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, \
+                       extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride,      \
+                       extra2, extra2_bstride, rowsum, rowsum_ld)
+        if (slab <= 1024) VD_GN_BWD(1, 256);
+        else if (slab <= 2048) VD_GN_BWD(2, 256);
+        else if (slab <= 4096) VD_GN_BWD(4, 256);
+        else if (slab <= 8192) VD_GN_BWD(4, 512);
+        else VD_GN_BWD(6, 512);
+#undef VD_GN_BWD
+        VD_LAUNCH_CHECK("vd_groupnorm_bwd");
+        return 0;
+    }
     if (S) {
         hipLaunchKernelGGL(gn_chunk_bwd_stats_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
                            beta, ws, C, HW, G, S, apply_silu, dy_bstride, x_bstride);
         hipLaunchKernelGGL(gn_chunk_bwd_apply_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
                            beta, extra, dx, dgamma_ws, dbeta_ws, ws, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride,
                            dx_bstride);
-        VD_LAUNCH_CHECK("vd_groupnorm_bwd");
-        return 0;
-    }
-    const bool reg_ok = al && HW % 4 == 0 && slab <= 12 * 1024 &&
-                        ((L >= 64 && L % 64 == 0) || (L < 64 && (L & (L - 1)) == 0 && L > 0)) && getenv("VD_GN_BWD_GENERIC") == nullptr;
-#define VD_GN_BWD(NVV)                                                                                                         \
-    hipLaunchKernelGGL((gn_bwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, \
-                       extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride)
-    if (reg_ok && slab <= 1024) VD_GN_BWD(1);
-    else if (reg_ok && slab <= 2048) VD_GN_BWD(2);
-    else if (reg_ok && slab <= 4096) VD_GN_BWD(4);
-    else if (reg_ok && slab <= 8192)
-        hipLaunchKernelGGL((gn_bwd_reg_kernel<4, 512>), dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta,
-                           extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
-    else if (reg_ok)
-        hipLaunchKernelGGL((gn_bwd_reg_kernel<6, 512>), dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta,
-                           extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
-    else
+    } else {
         hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
                            dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);
-#undef VD_GN_BWD
+    }
     VD_LAUNCH_CHECK("vd_groupnorm_bwd");
+    if (extra2) {
+        const int rc = vd_add_strided(dx, extra2, B, (int64_t)C * HW, dx_bstride, extra2_bstride, 1, stream);
+        if (rc) return rc;
+    }
+    if (rowsum) return vd_rowsum(dx, rowsum, B, C, HW, dx_bstride, rowsum_ld, stream);
     return 0;
+}
+
+extern "C" int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws, int B,
+                                int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride,
+                                int64_t extra_bstride, int64_t dx_bstride, float* ws, void* stream) {
+    return vd_groupnorm_bwd_fused(dy, x, mean, rstd, gamma, beta, extra, nullptr, dx, dgamma_ws, dbeta_ws, nullptr, B, C, HW, G, apply_silu,
+                                  dy_bstride, x_bstride, extra_bstride, 0, dx_bstride, 0, ws, stream);
 }

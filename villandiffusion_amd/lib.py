@@ -71,6 +71,7 @@ PROTOTYPES = {
     "vd_groupnorm_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i64, _vp]),
     "vd_groupnorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i64, _i64, _vp, _vp]),
     "vd_groupnorm_bwd": (_i32, [_vp] * 10 + [_i32] * 5 + [_i64] * 4 + [_vp, _vp]),
+    "vd_groupnorm_bwd_fused": (_i32, [_vp] * 12 + [_i32] * 5 + [_i64] * 6 + [_vp, _vp]),
     "vd_softmax_col_fwd": (_i32, [_vp, _i32, _i32, _vp]),
     "vd_softmax_col_bwd": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "vd_attn_small_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i64, _i64, _vp]),
@@ -136,7 +137,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 5:
+    if lib.vd_abi_version() != 6:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -638,16 +638,24 @@ def gn_fusable(x, cout) -> bool:
     return W in (16, 32) and H == W and Cc % 8 == 0 and Cc <= 1024 and cout >= 64
 
 
-def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma_ws, dbeta_ws, G, silu, extra=None):
+def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma_ws, dbeta_ws, G, silu, extra=None, extra2=None, rowsum=None, rowsum_ld=None):
+    """dx = GN(+SiLU) backward (+ extra + extra2); rowsum (optional, [B, >= C] rows of stride rowsum_ld): sum_p dx[b, c, p], written by the
+    same pass (vd_groupnorm_bwd_fused)."""
     Bn, Cc, H, W, xbs = _img(x)
     dbs, dxbs = _img(dy)[4], _img(dx)[4]
     ebs = _img(extra)[4] if extra is not None else 0
+    e2bs = _img(extra2)[4] if extra2 is not None else 0
     assert dgamma_ws.numel() >= Bn * Cc and dbeta_ws.numel() >= Bn * Cc
-    nbytes = (12.0 + (4.0 if extra is not None else 0.0)) * x.numel()          # dy, x (+ extra) read once, dx written once
+    assert extra2 is None or extra2.shape == x.shape
+    rld = 0
+    if rowsum is not None:
+        rld = Cc if rowsum_ld is None else rowsum_ld
+        assert rld >= Cc
+    nbytes = (12.0 + (4.0 if extra is not None else 0.0) + (4.0 if extra2 is not None else 0.0)) * x.numel()   # dy, x (+ extras) read once, dx written once
     _timed("groupnorm_bwd (gn_bwd_reg_kernel<*> / gn_chunk_*)", nbytes, "hbm", lambda: L.check(
-        _lib().vd_groupnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(extra), _p(dx),
-                                _p(dgamma_ws), _p(dbeta_ws), Bn, Cc, H * W, G, int(silu), dbs, xbs, ebs, dxbs,
-                                _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_bwd"))
+        _lib().vd_groupnorm_bwd_fused(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(extra), _p(extra2), _p(dx),
+                                      _p(dgamma_ws), _p(dbeta_ws), _p(rowsum), Bn, Cc, H * W, G, int(silu), dbs, xbs, ebs, e2bs, dxbs, rld,
+                                      _p(_gn_ws(Bn, Cc, H * W, G, x.device)), _s()), "vd_groupnorm_bwd"))
     return dx
 
 

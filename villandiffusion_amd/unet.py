@@ -228,12 +228,15 @@ class _Norm:
                             self.groups, net.eps)
         return ss
 
-    def bwd(self, dy, x, mean, rstd, dx, extra=None):
+    def bwd(self, dy, x, mean, rstd, dx, extra=None, extra2=None, rowsum=None):
+        """extra / extra2: residual gradients added into dx; rowsum ([B, C] view, row stride free): per-image channel sums of the dx
+        written, i.e. the bias-gradient rows of the layer that produced x, from the same pass."""
         net = self.net
         B = x.shape[0]
         wg, wb = net.scratch_bc(B, self.ch, 1), net.scratch_bc(B, self.ch, 2)
         ops.groupnorm_bwd(dy, x, mean, rstd, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], dx, wg, wb,
-                          self.groups, self.silu, extra=extra)
+                          self.groups, self.silu, extra=extra, extra2=extra2, rowsum=rowsum,
+                          rowsum_ld=(rowsum.stride(0) if rowsum is not None else None))
         net.colsum_later(wg, net.G[self.prefix + ".weight"], B, self.ch)
         net.colsum_later(wb, net.G[self.prefix + ".bias"], B, self.ch)
         return dx
@@ -291,36 +294,44 @@ class _Resnet:
             return (x, a1, m1, r1, h1, a2, m2, r2)
         return None
 
-    def bwd(self, saved, dout, dx, st):
+    def bwd(self, saved, dout, dx, st, dout_rs=None, extra2=None, dx_rs=None):
+        """dout_rs: [B, cout] per-image channel sums of dout when its producer already made them (else a rowsum launch); extra2: a skip
+        connection's gradient to add into dx; dx_rs: [B, cin] view to receive the sums of dx (both ride in the last GroupNorm backward)."""
         net = self.net
         x, a1, m1, r1, h1, a2, m2, r2 = saved
         B, _, H, W = x.shape
         dev = x.device
         # conv2 (+ shortcut bias: both biases receive rowsum(dout))
-        bias_ws = net.scratch_bc(B, self.cout)
-        net.rowsum(dout, bias_ws)
+        if dout_rs is None:
+            bias_ws = net.scratch_bc(B, self.cout).view(B, self.cout)
+            net.rowsum(dout, bias_ws)
+        else:
+            bias_ws = dout_rs
         da2 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
         self.conv2.bwd(dout, a2, da2, bias_ws=bias_ws)
         dh1 = torch.empty_like(da2)
-        self.norm2.bwd(da2, h1, m2, r2, dh1)
         # temb projection gradient rows + conv1 bias share rowsum(dh1)
         dt = st.d_temb_all[:, self.temb_off:self.temb_off + self.cout]
-        net.rowsum(dh1, dt, ws_ld=st.d_temb_all.stride(0))
+        if getattr(net, "fuse_gn_bwd", False):
+            self.norm2.bwd(da2, h1, m2, r2, dh1, rowsum=dt)
+        else:
+            self.norm2.bwd(da2, h1, m2, r2, dh1)
+            net.rowsum(dh1, dt, ws_ld=st.d_temb_all.stride(0))
         da1 = da2 if self.cin == self.cout else torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
         self.conv1.bwd(dh1, a1, da1, bias_ws=dt)
         if self.has_sc:
             wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
             net.wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
                       math_mode=_wgrad1x1_math(net, dout, x))
-            net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout)
+            net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout, ld=bias_ws.stride(0))
             dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
             HW = H * W
             ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
                      ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
                      a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
-            self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc)
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc, extra2=extra2, rowsum=dx_rs)
         else:
-            self.norm1.bwd(da1, x, m1, r1, dx, extra=dout)
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dout, extra2=extra2, rowsum=dx_rs)
         return dx
 
 
@@ -388,7 +399,7 @@ class _Attn:
             return (x, mean, rstd, g, qkv, P, o)
         return None
 
-    def bwd(self, saved, dout, dx, st):
+    def bwd(self, saved, dout, dx, st, dout_rs=None, extra2=None, dx_rs=None):
         net, Cc = self.net, self.ch
         x, mean, rstd, g, qkv, P, o = saved
         B, _, H, W = x.shape
@@ -396,9 +407,12 @@ class _Attn:
         dev = x.device
         wo = net.P[self.prefix + ".to_out.0.weight"]
         net.wgrad(dout, o, net.G[self.prefix + ".to_out.0.weight"], B_PLAIN, math_mode=_wgrad1x1_math(net, dout, o))
-        bias_ws = net.scratch_bc(B, Cc)
-        net.rowsum(dout, bias_ws)
-        net.colsum_later(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc)
+        if dout_rs is None:
+            bias_ws = net.scratch_bc(B, Cc).view(B, Cc)
+            net.rowsum(dout, bias_ws)
+        else:
+            bias_ws = dout_rs
+        net.colsum_later(bias_ws, net.G[self.prefix + ".to_out.0.bias"], B, Cc, ld=bias_ws.stride(0))
         do = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(wo, dout, do, M=Cc, N=B * N, K=Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
                  b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N, B))
@@ -462,7 +476,7 @@ class _Attn:
         dg = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(net.Pq[self.qkv_w], dqkv, dg, M=Cc, N=B * N, K=3 * Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
                  b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", True, Cc, 3 * Cc, N, B))
-        self.norm.bwd(dg, x, mean, rstd, dx, extra=dout)
+        self.norm.bwd(dg, x, mean, rstd, dx, extra=dout, extra2=extra2, rowsum=dx_rs)
         return dx
 
 
@@ -641,7 +655,7 @@ class UNet2DModel(nn.Module):
         self._cs_pool: Optional[torch.Tensor] = None
         self._cs_tables: Dict[tuple, torch.Tensor] = {}
         self._cs_cols_hint = 4 * sum(int(math.prod(sh)) for _, sh, _ in layout if len(sh) == 1) + 4096
-        self._cs_off, self._cs_jobs, self._cs_B = 0, [], 0
+        self._cs_off, self._cs_jobs, self._cs_B, self._cs_retired = 0, [], 0, []
         self._d_temb: Dict[int, torch.Tensor] = {}
         half = self.time_dim0 // 2
         # [UPSTREAM] get_timestep_embedding: exponent = -ln(1e4) * arange(half) / (half - freq_shift), fp32 torch ops
@@ -676,6 +690,9 @@ class UNet2DModel(nn.Module):
         self.wgrad_stream = os.environ.get("VILLAN_WGRAD_STREAM", "1") != "0"
         self.wgrad_flush_jobs = int(os.environ.get("VILLAN_WGRAD_FLUSH_JOBS", "24"))
         self._wg_side, self._wg_keep, self._rs_jobs = None, [], []
+        # bias-gradient row sums and skip-connection gradient adds ride in the GroupNorm backward that writes the tensor they read
+        # (vd_groupnorm_bwd_fused) instead of ~50 rowsum + 12 add_strided launches per step; False: the separate launches
+        self.fuse_gn_bwd = os.environ.get("VILLAN_FUSE_GN_BWD", "1") != "0"
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
@@ -754,11 +771,13 @@ class UNet2DModel(nn.Module):
             self._cs_pool = torch.empty(need, device=self._dev, dtype=torch.float32)
             self._cs_tables = {}
         self._cs_off, self._cs_jobs, self._cs_B = 0, [], B
+        self._cs_retired = []                                     # pools outgrown during this pass: row sums handed from layer to layer may still live there
 
     def scratch_bc(self, B, Cc, slot=0):
         n = (B * Cc + 3) // 4 * 4
         if self._cs_off + n > self._cs_pool.numel():             # first pass with an under-estimated hint: flush and grow
             self._cs_flush()
+            self._cs_retired.append(self._cs_pool)
             self._cs_cols_hint *= 2
             self._cs_pool = torch.empty(B * self._cs_cols_hint, device=self._dev, dtype=torch.float32)
             self._cs_tables, self._cs_off = {}, 0
@@ -1063,7 +1082,10 @@ class UNet2DModel(nn.Module):
         da = torch.empty_like(a)
         self._conv_out.bwd(dout, a, da)
         g = torch.empty(final.shape, device=dev, dtype=torch.float32)
-        self.norm_out.bwd(da, final, mo, ro, g)
+        fuse = self.fuse_gn_bwd
+        # g_rs: per-image channel sums of g ([B, C] view) when the kernel that wrote g also summed it (vd_groupnorm_bwd_fused), else None
+        g_rs = self.scratch_bc(B, final.shape[1]).view(B, final.shape[1]) if fuse else None
+        self.norm_out.bwd(da, final, mo, ro, g, rowsum=g_rs)
         # `g` is the gradient wrt the output of the most recent forward op; walk the tape backwards.
         slot = n_skip
         hook = self.bucket_ready_hook
@@ -1081,29 +1103,33 @@ class UNet2DModel(nn.Module):
                 layer, saved = rec[1], rec[2]
                 x = saved[0]
                 is_cat_input = kind == "res" and any(x.data_ptr() == c.data_ptr() and x.shape == c.shape for c in st.cats)
+                dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
+                rs = self.scratch_bc(B, x.shape[1]).view(B, x.shape[1]) if fuse else None
                 if is_cat_input:
                     slot -= 1
-                    dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
                     dcats[slot] = dx
-                    layer.bwd(saved, g, dx, st)
+                    layer.bwd(saved, g, dx, st, dout_rs=g_rs, dx_rs=rs)
                     g = dx[:, :up_slots[slot][0]]
+                    g_rs = rs[:, :up_slots[slot][0]] if fuse else None
+                elif fuse:                                        # the skip connection's gradient rides in the block's last GroupNorm backward
+                    layer.bwd(saved, g, dx, st, dout_rs=g_rs, extra2=self._skip_grad(x, st, dcats), dx_rs=rs)
+                    g, g_rs = dx, rs
                 else:
-                    dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
                     layer.bwd(saved, g, dx, st)
                     g = dx
                     g = self._add_skip_grad(g, x, st, dcats)
             elif kind == "us":
                 layer, x = rec[1], rec[2]
                 dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
-                layer.bwd(g, x, dx)
-                g = dx
+                layer.bwd(g, x, dx, bias_ws=g_rs)
+                g, g_rs = dx, None
             elif kind == "ds":
                 layer, x = rec[1], rec[2]
                 dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
-                layer.bwd(g, x, dx)
-                g = self._add_skip_grad(dx, x, st, dcats)
+                layer.bwd(g, x, dx, bias_ws=g_rs)
+                g, g_rs = self._add_skip_grad(dx, x, st, dcats), None
             elif kind == "conv_in":
-                self._conv_in.bwd(g, rec[1], None)
+                self._conv_in.bwd(g, rec[1], None, bias_ws=g_rs)
             else:
                 raise RuntimeError(kind)
         self._cs_flush()                                          # d_temb_all's partials may sit on the side stream
@@ -1128,12 +1154,18 @@ class UNet2DModel(nn.Module):
         if hook is not None:
             hook(3)
 
-    def _add_skip_grad(self, g, x, st, dcats):
-        """If `x` (the input whose gradient `g` was just produced) is a skip tensor living in a concat buffer, add the
-        gradient that flowed into it through the up path."""
+    def _skip_grad(self, x, st, dcats):
+        """If `x` is a skip tensor living in a concat buffer: the gradient that flowed into it through the up path (a channel
+        slice of that buffer's gradient), else None."""
         for k, c in enumerate(st.cats):
             h_ch = st.up_slots[k][0]
             if x.shape[1:] == c[:, h_ch:].shape[1:] and x.data_ptr() == c[:, h_ch:].data_ptr():
-                ops.add_strided(g, dcats[k][:, h_ch:], accumulate=True)
-                break
+                return dcats[k][:, h_ch:]
+        return None
+
+    def _add_skip_grad(self, g, x, st, dcats):
+        """g += the up path's gradient of the skip tensor `x` (whose gradient `g` was just produced), if it is one."""
+        sg = self._skip_grad(x, st, dcats)
+        if sg is not None:
+            ops.add_strided(g, sg, accumulate=True)
         return g
