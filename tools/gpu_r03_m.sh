@@ -1,8 +1,8 @@
 #!/bin/bash
-for rep in 1 2 3; do
-  for g in 0 1; do
-    timeout 300 python3 bench.py --mode train --no-cpu --no-exact --no-roofline --graph-step $g 2>/dev/null | python3 -c "
-import sys,json
-l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('graph-step $g', l['ms_per_step'], l['host_submit_ms_per_step'], l['final_loss'])"
-  done
+mkdir -p gpurun_out/r03
+timeout 1200 python -m pytest tests/test_hip_kernels.py tests/test_unet_gpu.py tests/test_cabi.py tests/test_train_sample_gpu.py -q -m gpu -x > gpurun_out/r03/t_m.log 2>&1
+grep -E "Fatal|FAILED|passed|failed|Error" gpurun_out/r03/t_m.log | tail -n 8
+for f in 1 0 1 0; do
+  echo "== VILLAN_FUSED_SPLITK=$f"
+  VILLAN_FUSED_SPLITK=$f timeout 600 python bench.py --steps 30 --warmup 10 --no-exact --no-cpu --no-roofline --no-secondary --sample-images 128 --sample-streams 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d.get('sample_ddpm1000_images_per_sec'))"
 done
