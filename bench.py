@@ -251,6 +251,8 @@ def main():
                       graph_micro_step=None if args.graph_step is None else bool(args.graph_step))
     from villandiffusion_amd.trainer import shard_indices
     ids = shard_indices(len(dsl), 0, rank, world, seed=0)
+    if os.environ.get("VD_BENCH_HOST_POSITIONS", "0") != "1":
+        ids = ids.to(dev)                                    # device positions: a batch then needs no host -> device copy (dataset.make_batch)
     tgen = torch.Generator(device=dev).manual_seed(100 + rank)
 
     def one_step(i):

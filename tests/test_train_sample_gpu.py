@@ -329,6 +329,30 @@ def test_celebahq256_config_train_step_with_image_trigger():
     assert out.images.shape == (2, 256, 256, 3)
 
 
+def test_batches_addressed_by_device_positions_need_no_host_copy_and_equal_the_host_path():
+    """Training batches (full=False) for device-resident positions: indices / poison flags gathered on the GPU (dataset._make_batch_resident);
+    same tensors as the host-position path for the same flip bits; random flips are per-sample mirror images; the loader feeds device positions."""
+    dsl = DatasetLoader("SYNTHETIC-CIFAR10", root=ROOT, batch_size=32, seed=0, images=synthetic_images(n=256, size=32))
+    dsl.set_poison("BOX_14", "HAT", poison_rate=0.25).prepare_dataset(mode="FIXED")
+    ids = torch.randperm(256, generator=torch.Generator().manual_seed(3))[:64]
+    flips = torch.rand(64, generator=torch.Generator().manual_seed(4)) < 0.5
+    host = dsl.make_batch(ids, flip_bits=flips, full=False)
+    resident = dsl.make_batch(ids.cuda(), flip_bits=flips, full=False)
+    assert set(host) == set(resident)
+    for k in host:
+        assert torch.equal(host[k], resident[k]), k
+    assert int((dsl._flags[ids.numpy()] & 1).sum()) > 0                         # poisoned samples in the batch
+    rnd = dsl.make_batch(ids.cuda(), full=False)
+    noflip = dsl.make_batch(ids.cuda(), flip_bits=torch.zeros(64, dtype=torch.bool), full=False)
+    same = (rnd["image"] == noflip["image"]).flatten(1).all(1)
+    mirrored = (rnd["image"] == noflip["image"].flip(-1)).flatten(1).all(1)
+    assert bool((same | mirrored).all()) and 8 < int(mirrored.sum()) < 56
+    loader = dsl.get_dataloader(batch_size=32, full=False)
+    assert loader._ids_dev is not None and loader._ids_dev.is_cuda
+    n = sum(b["pixel_values"].shape[0] for b in loader)
+    assert n == 256
+
+
 def test_cli_resume_continues_from_the_checkpoint(tmp_path):
     """--mode resume (reference :454-461, 1103-1115): model from the run directory, optimiser / LR-schedule / counters from
     ckpt/trainer.pt and data.ckpt.  As in the reference the checkpoint records the 0-based index of the epoch it was written AFTER

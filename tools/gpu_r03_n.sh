@@ -1,15 +1,7 @@
 #!/bin/bash
-O=gpurun_out/r03
-mkdir -p $O
-timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_unet_gpu.py -q -m gpu -k "grouped or batch128_backward" 2>&1 | tail -3
-for rep in 1 2 3; do
-for t in "VD_W1X1_WIDE=0" "VD_NOP=1" "VD_W1X1_WIDE_KCAP=32" "VD_W1X1_WIDE_KCAP=128"; do
-  for sw in "" "--serial-wgrad"; do
-  env $t timeout 300 python3 bench.py --mode train --no-cpu --no-exact $sw 2>$O/q.err | python3 -c "
-import sys,json
-l=json.loads(sys.stdin.read().strip().splitlines()[-1])
-d=json.load(open('gpurun_out/bench_detail.json'))
-print('$t $sw', l['ms_per_step'], [(k['kernel'][:28], k['ms']) for k in d['train_step_kernels'] if 'wgrad1x1' in k['kernel']])"
-  done
-done
+run() { timeout 600 python bench.py --mode train --steps 40 --warmup 10 --no-exact --no-cpu --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+for i in 1 2 3; do
+echo "== resident positions"; run
+echo "== host positions, pinned non-blocking"; VD_BENCH_HOST_POSITIONS=1 run
+echo "== host positions, pageable (round-2 behaviour)"; VD_BENCH_HOST_POSITIONS=1 VILLAN_PAGEABLE_H2D=1 run
 done

@@ -466,6 +466,7 @@ class DatasetLoader:
         else:
             raise NotImplementedError(f"Argument mode: {mode} isn't defined")
         self._index, self._flags = base[idx], flags
+        self._dev_images = None                                # device copies (images, partition, trigger / target) are rebuilt on first use
         return self
 
     def _prepare_latent(self) -> "DatasetLoader":
@@ -491,7 +492,7 @@ class DatasetLoader:
             self._lat_dev = (self._lat_raw.to(self._dev), self._lat_poison.to(self._dev), self._lat_target.to(self._dev),
                              torch.from_numpy(self._flags.astype(bool)).to(self._dev))
         raw, poi, tgt, fl = self._lat_dev
-        idx = sample_ids.to(self._dev).long()
+        idx = self._h2d(sample_ids.long())
         is_p = fl[idx]
         r = raw[idx]
         m = is_p[:, None, None, None]
@@ -566,14 +567,28 @@ class DatasetLoader:
             self._dev_images = torch.from_numpy(self._images).to(self._dev)
             self._dev_trigger = self._trigger.to(self._dev).contiguous()
             self._dev_target = self._target.to(self._dev).contiguous()
+            # the partition itself is resident too: a batch addressed by DEVICE positions needs no host -> device copy at all
+            self._dev_index = torch.from_numpy(np.ascontiguousarray(self._index, dtype=np.int64)).to(self._dev)
+            self._dev_flags = torch.from_numpy(np.ascontiguousarray(self._flags, dtype=np.uint8)).to(self._dev)
+            self._any_rto = bool((self._flags & 4).any())
+            self._flip_gen = torch.Generator(device=self._dev).manual_seed(int(self._seed) + 7919) if self._dev.type == "cuda" else None
+
+    def _h2d(self, t: torch.Tensor) -> torch.Tensor:
+        """Small per-batch host arrays (indices, flags) go up from PINNED memory without blocking: a pageable copy makes the host wait for
+        everything already queued on the stream, i.e. one full drain per training step (measured: 0.5 ms of idle GPU at every step start)."""
+        if self._dev.type == "cuda" and os.environ.get("VILLAN_PAGEABLE_H2D", "0") != "1":      # (1: the blocking copy, for A/B measurements)
+            return t.contiguous().pin_memory().to(self._dev, non_blocking=True)
+        return t.to(self._dev)
 
     def make_batch(self, sample_ids: torch.Tensor, flip_bits: Optional[torch.Tensor] = None, full: bool = True) -> Dict[str, torch.Tensor]:
         """Batch dict for positions `sample_ids` of the prepared (partitioned) dataset."""
         if self._latent is not None:
             return self._make_latent_batch(sample_ids, full)
         self._ensure_device()
+        if sample_ids.device.type == "cuda" and not full and not self._any_rto:
+            return self._make_batch_resident(sample_ids, flip_bits)
         pos = sample_ids.cpu().numpy()
-        ds_idx = torch.from_numpy(self._index[pos]).to(self._dev)
+        ds_idx = self._h2d(torch.from_numpy(self._index[pos]))
         flags = torch.from_numpy(self._flags[pos].copy())
         B = len(pos)
         if flip_bits is None:
@@ -581,21 +596,41 @@ class DatasetLoader:
         rto = bool((flags & 4).any())
         if rto and not bool(((flags & 1) == 0).logical_or((flags & 4) != 0).all()):
             raise NotImplementedError("mixed R_trigger_only flags inside one batch")
-        kflags = ((flags & 1) | (flip_bits.to(torch.uint8) << 1)).to(torch.uint8).to(self._dev)
+        kflags = self._h2d(((flags & 1) | (flip_bits.to(torch.uint8) << 1)).to(torch.uint8))
         C, S = self._channel, self._image_size
         pv, tg, im = (torch.empty((B, C, S, S), device=self._dev, dtype=torch.float32) for _ in range(3))
         ops.poison_batch(self._dev_images, kflags, self._dev_trigger, self._dev_target, pv, tg, im, self._vmin, self._vmax,
                          R_trigger_only=rto, idx=ds_idx.contiguous())
         batch = {self.PIXEL_VALUES: pv, self.TARGET: tg, self.IMAGE: im}
         if full:
-            is_p = (flags & 1).bool().to(self._dev)
+            is_p = self._h2d((flags & 1).bool())
             trig = self._dev_trigger[None].expand(B, C, S, S)
             batch[self.TRIGGER] = trig
             batch[self.PIXEL_VALUES_TRIGGER] = torch.where(is_p[:, None, None, None], trig, torch.zeros((), device=self._dev))
             lab = torch.full((B,), -1.0) if self._labels is None else torch.from_numpy(self._labels[self._index[pos]]).float()
-            batch[self.LABEL] = lab.to(self._dev)
+            batch[self.LABEL] = self._h2d(lab)
             batch[self.IS_CLEAN] = ~is_p
         return batch
+
+    def _make_batch_resident(self, pos: torch.Tensor, flip_bits: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Training batch (full=False) for DEVICE-resident positions: dataset indices, poison flags and flip bits are gathered / drawn on the
+        GPU, so a steady-state step issues no host -> device copy (each one costs ~50-100 us of idle GPU in the runtime's copy path)."""
+        B = len(pos)
+        pos = pos.long()
+        ds_idx = self._dev_index.index_select(0, pos)
+        fl = self._dev_flags.index_select(0, pos)
+        if flip_bits is None:
+            flip = (torch.rand(B, device=self._dev, generator=self._flip_gen) < 0.5) if self.random_flip else None
+        else:
+            flip = flip_bits if flip_bits.device.type == "cuda" else self._h2d(flip_bits)
+        kflags = fl & 1
+        if flip is not None:
+            kflags = kflags | (flip.to(torch.uint8) << 1)
+        C, S = self._channel, self._image_size
+        pv, tg, im = (torch.empty((B, C, S, S), device=self._dev, dtype=torch.float32) for _ in range(3))
+        ops.poison_batch(self._dev_images, kflags.contiguous(), self._dev_trigger, self._dev_target, pv, tg, im, self._vmin, self._vmax,
+                         R_trigger_only=False, idx=ds_idx)
+        return {self.PIXEL_VALUES: pv, self.TARGET: tg, self.IMAGE: im}
 
     def get_dataloader(self, batch_size: int = None, shuffle: bool = None, num_workers: int = None, collate_fn=None,
                        rank: int = 0, world: int = 1, epoch: int = 0, full: bool = True):
@@ -612,13 +647,16 @@ class _Loader:
         from .trainer import shard_indices
         self.dsl, self.bs, self.full = dsl, bs, full
         self.ids = shard_indices(len(dsl), epoch, rank, world, seed=dsl._seed, shuffle=shuffle)
+        # training batches (full=False) of the pixel datasets are addressed by device positions: uploaded once per epoch, not per batch
+        self._ids_dev = self.ids.to(dsl._dev) if (not full and dsl._latent is None and dsl._dev.type == "cuda") else None
 
     def __len__(self):
         return (len(self.ids) + self.bs - 1) // self.bs
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
-        for s in range(0, len(self.ids), self.bs):
-            yield self.dsl.make_batch(self.ids[s:s + self.bs], full=self.full)
+        ids = self.ids if self._ids_dev is None else self._ids_dev
+        for s in range(0, len(ids), self.bs):
+            yield self.dsl.make_batch(ids[s:s + self.bs], full=self.full)
 
 
 class LatentDataset(torch.utils.data.Dataset):
