@@ -611,6 +611,8 @@ BX3_CASES = [
     (128, 256, 256, 4, B_CONV3), (5, 64, 96, 4, B_CONV3), (20, 512, 256, 4, B_CONV3),   # 4x4: eight images per tile (ragged) + split-K
     # images wider than 32 px: two 64-pixel rows / one 128-pixel row segment per tile
     (2, 64, 128, 64, B_CONV3), (1, 80, 64, 128, B_CONV3), (1, 64, 64, 256, B_CONV3), (1, 64, 96, 64, B_CONV3_UP), (1, 64, 64, 32, B_CONV3_UP),
+    # stride 2 (round 3: column-parity patch): 32 -> 16, 16 -> 8 (two images per tile), 8 -> 4 (eight images per tile, ragged), 64 -> 32; split-K at the small ones
+    (6, 128, 128, 32, B_CONV3_S2), (3, 256, 256, 16, B_CONV3_S2), (13, 256, 200, 8, B_CONV3_S2), (2, 64, 64, 64, B_CONV3_S2), (128, 256, 256, 8, B_CONV3_S2),
 ]
 
 
@@ -648,6 +650,21 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
     dx = torch.empty(B, Cin, H, H, device=DEV)
     ops.conv3x3(dy.to(DEV), wt, None, dx, mode=B_CONV3_T, a_packed=pkt)
     check(dx, x.grad, BX3_TOL, f"bf16x3 dgrad {Cin}->{Cout}@{H}")
+
+
+@pytest.mark.parametrize("H,pad", [(32, 1), (16, 1), (8, 1), (8, 0)])
+def test_split_precision_stride2_conv_with_symmetric_padding(H, pad):
+    """Downsample2D(padding=1) (the LDM / VQ-VAE variant) and padding=0 (F.pad (0,1,0,1), the DDPM UNets) on the stride-2 patch."""
+    B, Cin, Cout = 5, 64, 96
+    x = torch.randn(B, Cin, H, H, generator=g(0))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g(2))
+    y_ref = F.conv2d(x, w, b, stride=2, padding=1) if pad else F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    assert ops.bx3_eligible(Cout, Cin, H // 2, H // 2, B_CONV3_S2)
+    wd = w.to(DEV).view(Cout, -1)
+    out = torch.empty(B, Cout, H // 2, H // 2, device=DEV)
+    ops.conv3x3(x.to(DEV), wd, b.to(DEV), out, mode=B_CONV3_S2, pad=pad, a_packed=ops.conv3_pack_weights(wd, Cout, Cin))
+    check(out, y_ref, BX3_TOL, f"bf16x3 stride-2 conv pad={pad} @{H}")
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,mode", [(64, 128, 128, 32, B_CONV3), (40, 192, 200, 32, B_CONV3), (128, 256, 256, 16, B_CONV3), (72, 64, 256, 16, B_CONV3),

@@ -2041,7 +2041,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             bx3_plan(d, splits, c_per);
             static const int big_off = getenv("VD_BX3_BIG_OFF") ? atoi(getenv("VD_BX3_BIG_OFF")) : 0;
             if (bx3_big_split(d)) return 16;                           // 16: 8x8 layers, 128 x 256 tiles with the channel loop split
-            const int big = big_off ? 0 : bx3_big_tile(d, splits);
+            const int big = (big_off || d.b_mode == VD_B_CONV3_S2) ? 0 : bx3_big_tile(d, splits);
             static const int keep_huge = getenv("VD_BX3_K32_KEEP_HUGE") ? atoi(getenv("VD_BX3_K32_KEEP_HUGE")) : 0;
             static const int k32_up32 = getenv("VD_BX3_K32_UP32") ? atoi(getenv("VD_BX3_K32_UP32")) : 0;
             if (big >= 1 && !(big == 2 && (keep_huge || (d.b_mode == VD_B_CONV3_UP && !k32_up32))) && conv3_k32_eligible(d)) return 17;      // 17: conv3_k32_kernel (16x16x32 MFMA, 128 x 256 tile)

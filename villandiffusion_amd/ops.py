@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -168,7 +169,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
         name = f"conv3_k32_kernel<{d.OW}, {md}>"
     elif tl in (8, 12, 15, 16):
-        md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
+        md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
         name = f"conv3_bx3_kernel<{d.OW if d.OW <= 64 else 128}, {md}, {4 if tl == 15 else 2}, {256 if tl == 8 else 512}, 2>"
     elif tl in (4, 6):     # symbol names as rocprofv3 prints them
         tw = d.OW if d.OW <= 64 else 128          # tile width (template W): row segments of wider images
@@ -217,6 +218,8 @@ WEIGHTS_EPOCH = 0
 
 def bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision convolution kernel takes (vd_gemm_desc.a_packed)."""
+    if mode == B_CONV3_S2:                                  # stride 2 (OH, OW: the OUTPUT, half the input): square 4x4 .. 32x32 outputs
+        return Cc % 16 == 0 and M >= 64 and OH == OW and OW in (4, 8, 16, 32) and os.environ.get("VD_BX3_S2_OFF", "0") in ("", "0")
     if mode not in (B_CONV3, B_CONV3_T, B_CONV3_UP) or Cc % 16 != 0 or M < 64 or (OW == 4 and mode == B_CONV3_UP):
         return False
     if OW == 64 or (OW >= 128 and OW % 128 == 0):           # row-segment tiles of wide images
