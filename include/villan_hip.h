@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 6
+#define VD_ABI_VERSION 7
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -110,6 +110,10 @@ typedef struct vd_gemm_desc {
     int32_t pad_h, pad_w;    /* VD_B_CONVG only: zero padding on each side                                              */
     int32_t act;             /* 0: none; 1: D = max(D, 0) after every other epilogue term (BasicConv2d = conv + folded BatchNorm + ReLU).
                                 Honoured by the exact-f32 gather / plain kernels only (a_packed == NULL, math == 0); else VD_EINVAL */
+    float* gn_part;          /* optional OUTPUT of the 16x16x32 split-precision 3x3 convolution (vd_gemm_tile() == 17, else VD_EINVAL):
+                                [B][NP / 256][M][2] = (sum, sum of squares) of the FINAL result (after bias / rowadd / residual) of channel m
+                                over each 256-pixel tile -- the GroupNorm that follows (ResnetBlock2D: conv1 -> norm2) gets its statistics
+                                from vd_groupnorm_stats_from_partials() instead of a read of the whole tensor.  Fixed-order sums.           */
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -214,6 +218,10 @@ int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, floa
  * (one read of x, no y).  Groups of at most 12 K elements. */
 int vd_groupnorm_stats(const float* x, const float* gamma, const float* beta, float* ss, float* mean, float* rstd,
                        int B, int C, int HW, int G, float eps, int64_t x_bstride, void* stream);
+/* vd_groupnorm_stats from the per-tile channel sums a convolution left in vd_gemm_desc.gn_part ([B][tiles][C][2], HW pixels per image in
+ * `tiles` tiles): same outputs, no pass over x.  Sums are combined in double precision in a fixed order. */
+int vd_groupnorm_stats_from_partials(const float* part, int tiles, const float* gamma, const float* beta, float* ss, float* mean,
+                                     float* rstd, int B, int C, int HW, int G, float eps, void* stream);
 /* dx = GN'(dy) (+ extra); dgamma_ws/dbeta_ws are [B][C] partials (reduce with vd_colsum). */
 int vd_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* extra, float* dx, float* dgamma_ws, float* dbeta_ws,

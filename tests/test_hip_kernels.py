@@ -652,6 +652,48 @@ def test_split_precision_conv3x3_forward_and_dgrad(B, Cin, Cout, H, mode):
     check(dx, x.grad, BX3_TOL, f"bf16x3 dgrad {Cin}->{Cout}@{H}")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,fold", [(64, 128, 128, 32, True), (128, 256, 256, 16, True), (128, 256, 200, 16, False)])
+def test_conv_epilogue_channel_sums_give_the_groupnorm_statistics(B, Cin, Cout, H, fold):
+    """vd_gemm_desc.gn_part (16x16x32 kernel): per-tile (sum, sum of squares) of the final output per channel, and
+    vd_groupnorm_stats_from_partials == vd_groupnorm_stats of the tensor (ResnetBlock2D conv1 -> norm2 of the no-grad forward)."""
+    x = torch.randn(B, Cin, H, H, generator=g(0)).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)).to(DEV)
+    b = torch.randn(Cout, generator=g(2)).to(DEV)
+    temb = torch.randn(B, Cout, generator=g(3)).to(DEV)
+    wd = w.view(Cout, -1)
+    pk = ops.conv3_pack_weights(wd, Cout, Cin)
+    out = torch.empty(B, Cout, H, H, device=DEV)
+    tiles = H * H // 256
+    part = torch.full((B, tiles, Cout, 2), float("nan"), device=DEV)
+    ss_in = None
+    if fold:                                                      # the GroupNorm-folding loader (MODE 3), as the sampler runs it
+        G1 = torch.randn(Cin, generator=g(4)).to(DEV) * 0.3 + 1
+        B1 = torch.randn(Cin, generator=g(5)).to(DEV) * 0.3
+        ss_in = torch.empty(B, Cin, 2, device=DEV)
+        m_, r_ = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+        ops.groupnorm_stats(x, G1, B1, ss_in, m_, r_, 32, 1e-6)
+    ops.conv3x3(x, wd, b, out, rowadd=temb, rowadd_bstride=Cout, gn_ss=ss_in, a_packed=pk, gn_part=part)
+    assert ops.GN_PART_WRITTEN
+    o64 = out.double().view(B, Cout, tiles, 256)
+    want = torch.stack([o64.sum(-1), (o64 * o64).sum(-1)], -1).permute(0, 2, 1, 3)          # [B, tiles, Cout, 2]
+    e = float((part.double() - want).abs().max() / want.abs().max())
+    assert e < 1e-6, e
+    G2 = torch.randn(Cout, generator=g(6)).to(DEV) * 0.3 + 1
+    B2 = torch.randn(Cout, generator=g(7)).to(DEV) * 0.3
+    groups = 8 if Cout % 32 else 32
+    ss_a, ss_b = torch.empty(B, Cout, 2, device=DEV), torch.empty(B, Cout, 2, device=DEV)
+    ma, ra, mb, rb = (torch.empty(B * groups, device=DEV) for _ in range(4))
+    ops.groupnorm_stats(out, G2, B2, ss_a, ma, ra, groups, 1e-6)
+    ops.groupnorm_stats_from_partials(part, tiles, G2, B2, ss_b, mb, rb, H * H, groups, 1e-6)
+    check(mb, ma, 1e-5, "mean from conv-epilogue partials")
+    check(rb, ra, 1e-5, "rstd from conv-epilogue partials")
+    check(ss_b, ss_a, 1e-5, "scale / shift from conv-epilogue partials")
+    # a launch that does not go to the 16x16x32 kernel leaves the buffer alone and says so
+    small = torch.empty(2, Cout, H, H, device=DEV)
+    ops.conv3x3(x[:2], wd, b, small, a_packed=pk, gn_part=part)
+    assert not ops.GN_PART_WRITTEN
+
+
 @pytest.mark.parametrize("H,pad", [(32, 1), (16, 1), (8, 1), (8, 0)])
 def test_split_precision_stride2_conv_with_symmetric_padding(H, pad):
     """Downsample2D(padding=1) (the LDM / VQ-VAE variant) and padding=0 (F.pad (0,1,0,1), the DDPM UNets) on the stride-2 patch."""

@@ -2100,6 +2100,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15 || tile == 17,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     VD_REQUIRE(!d.pool2 || tile == 8 || tile == 12 || tile == 17, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
+    VD_REQUIRE(!d.gn_part || (tile == 17 && !d.pool2), "vd_gemm: gn_part is written by the 16x16x32 split-precision 3x3 kernel only (vd_gemm_tile() == 17)");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (tile) {

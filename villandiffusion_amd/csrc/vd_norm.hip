@@ -655,6 +655,50 @@ extern "C" int vd_groupnorm_stats(const float* x, const float* gamma, const floa
     return 0;
 }
 
+// GroupNorm statistics from per-tile channel sums (vd_gemm_desc.gn_part): one 64-thread workgroup per (batch item, group).
+__global__ __launch_bounds__(64) void gn_stats_from_part_kernel(const float* __restrict__ part, int tiles, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ ss,
+                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int HW, int G,
+                                                                 float eps) {
+    __shared__ float mr[2];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G, cpg = C / G;
+    if (threadIdx.x == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = 0; t < tiles; ++t) {
+            const float* __restrict__ p = part + (((int64_t)b * tiles + t) * C + g * cpg) * 2;
+            for (int c = 0; c < cpg; ++c) {
+                s1 += (double)p[2 * c];
+                s2 += (double)p[2 * c + 1];
+            }
+        }
+        const double n = (double)cpg * HW, m = s1 / n;
+        double var = s2 / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mr[0] = (float)m;
+        mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+        mean_out[blockIdx.x] = mr[0];
+        rstd_out[blockIdx.x] = mr[1];
+    }
+    __syncthreads();
+    const float mean = mr[0], rstd = mr[1];
+    for (int c = threadIdx.x; c < cpg; c += 64) {
+        const int ch = g * cpg + c;
+        const float sc = gamma[ch] * rstd;
+        ss[((int64_t)b * C + ch) * 2] = sc;
+        ss[((int64_t)b * C + ch) * 2 + 1] = beta[ch] - mean * sc;
+    }
+}
+
+extern "C" int vd_groupnorm_stats_from_partials(const float* part, int tiles, const float* gamma, const float* beta, float* ss, float* mean,
+                                                float* rstd, int B, int C, int HW, int G, float eps, void* stream) {
+    VD_REQUIRE(part && gamma && beta && ss && mean && rstd, "vd_groupnorm_stats_from_partials: null pointer");
+    VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && tiles > 0, "vd_groupnorm_stats_from_partials: bad dims");
+    hipLaunchKernelGGL(gn_stats_from_part_kernel, dim3(B * G), dim3(64), 0, (hipStream_t)stream, part, tiles, gamma, beta, ss, mean, rstd, C, HW,
+                       G, eps);
+    VD_LAUNCH_CHECK("vd_groupnorm_stats_from_partials");
+    return 0;
+}
+
 extern "C" int vd_rowsum(const float* x, float* ws, int B, int M, int HW, int64_t x_bstride, int64_t ws_ld, void* stream);
 extern "C" int vd_add_strided(float* dst, const float* src, int B, int64_t inner, int64_t dst_bstride, int64_t src_bstride, int accumulate,
                               void* stream);

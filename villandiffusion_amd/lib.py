@@ -30,7 +30,8 @@ class GemmDesc(C.Structure):
                 ("lda", _i64), ("a_bstride", _i64), ("ldb", _i64), ("b_bstride", _i64),
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32), ("nb2", _i32),
                 ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32), ("pool2", _i32),
-                ("kh", _i32), ("kw", _i32), ("conv_stride", _i32), ("pad_h", _i32), ("pad_w", _i32), ("act", _i32)]
+                ("kh", _i32), ("kw", _i32), ("conv_stride", _i32), ("pad_h", _i32), ("pad_w", _i32), ("act", _i32),
+                ("gn_part", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -71,6 +72,7 @@ PROTOTYPES = {
     "vd_groupnorm_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i64, _vp]),
     "vd_groupnorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i64, _i64, _vp, _vp]),
     "vd_groupnorm_bwd": (_i32, [_vp] * 10 + [_i32] * 5 + [_i64] * 4 + [_vp, _vp]),
+    "vd_groupnorm_stats_from_partials": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "vd_groupnorm_bwd_fused": (_i32, [_vp] * 12 + [_i32] * 5 + [_i64] * 6 + [_vp, _vp]),
     "vd_softmax_col_fwd": (_i32, [_vp, _i32, _i32, _vp]),
     "vd_softmax_col_bwd": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp]),
@@ -137,7 +139,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 6:
+    if lib.vd_abi_version() != 7:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

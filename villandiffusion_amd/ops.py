@@ -114,7 +114,10 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False, convg=None, act=0):
+         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False, convg=None, act=0, gn_part=None):
+    """gn_part: optional [B, NP // 256, M, 2] buffer for the per-tile channel sums of the result (vd_gemm_desc.gn_part); it is filled only when the
+    launch goes to the 16x16x32 split-precision convolution -- ops.GN_PART_WRITTEN tells the caller right after the call."""
+    global GN_PART_WRITTEN
     d = GemmDesc()
     d.act = act
     if convg is not None:
@@ -142,6 +145,10 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     need = lib.vd_gemm_ws_floats(C.byref(d))
     if need > 0:
         d.ws = _gemm_ws(need, D.device).data_ptr()
+    GN_PART_WRITTEN = gn_part is not None and not pool2 and lib.vd_gemm_tile(C.byref(d)) == 17
+    if GN_PART_WRITTEN:
+        assert gn_part.is_contiguous() and gn_part.numel() >= (N // 256) * M * 2
+        d.gn_part = gn_part.data_ptr()
     if _PROF is None:
         L.check(lib.vd_gemm(C.byref(d), _s()), "vd_gemm")
         return D
@@ -233,8 +240,11 @@ def bx3_pool2_eligible(M, Cc, OH, OW, nb) -> bool:
     return bx3_eligible(M, Cc, OH, OW, B_CONV3_T) and OH == OW and OW in (16, 32) and ((M + 127) // 128) * ((nb * OH * OW + 127) // 128) >= 256
 
 
+GN_PART_WRITTEN = False
+
+
 def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
-            pad=0, gn_ss=None, a_packed=None, pool2=False):
+            pad=0, gn_ss=None, a_packed=None, pool2=False, gn_part=None):
     """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9].
     pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1).
     pool2 (B_CONV3_T with a_packed only): `out` has HALF the resolution and receives the 2x2 block sums of the result."""
@@ -255,7 +265,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
                 ldd=OHo * OWo, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
-                pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2)
+                pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2, gn_part=gn_part)
 
 
 def conv2d_general(x, w2d, bias, out, kh, kw, stride=1, pad_h=0, pad_w=0, relu=False):
@@ -632,6 +642,15 @@ def groupnorm_stats(x, gamma, beta, ss, mean, rstd, G, eps):
     assert ss.shape == (Bn, Cc, 2) and ss.is_contiguous()
     L.check(_lib().vd_groupnorm_stats(_p(x), _p(gamma), _p(beta), _p(ss), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps, xbs, _s()),
             "vd_groupnorm_stats")
+    return ss
+
+
+def groupnorm_stats_from_partials(part, tiles, gamma, beta, ss, mean, rstd, HW, G, eps):
+    """groupnorm_stats() from the per-tile channel sums a convolution wrote (conv3x3(gn_part=...)): no pass over the tensor."""
+    Bn, Cc = ss.shape[0], ss.shape[1]
+    assert ss.is_contiguous() and part.is_contiguous() and part.numel() >= Bn * tiles * Cc * 2
+    L.check(_lib().vd_groupnorm_stats_from_partials(_p(part), tiles, _p(gamma), _p(beta), _p(ss), _p(mean), _p(rstd), Bn, Cc, HW, G, eps, _s()),
+            "vd_groupnorm_stats_from_partials")
     return ss
 
 

@@ -159,12 +159,13 @@ class _Conv:
     def w2d(self):
         return self.net.P[self.prefix + ".weight"].view(self.cout, self.cin * 9)
 
-    def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None, gn_ss=None):
+    def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None, gn_ss=None, gn_part=None):
+        """gn_part: buffer for the per-tile channel sums of `out` (ops.conv3x3); ops.GN_PART_WRITTEN says whether this launch filled it."""
         pk = _bx3_packed(self.net, self.prefix, False, self.cout, self.cin, out.shape[2], out.shape[3], self.mode)
         if gn_ss is not None and (out.shape[3] not in (16, 32) or self.mode != B_CONV3):
             pk = None                                      # the folded-GroupNorm loader of the split-precision kernel: 16x16 / 32x32 only
         return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
-                           rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk)
+                           rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk, gn_part=gn_part)
 
     def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
         """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
@@ -228,6 +229,15 @@ class _Norm:
                             self.groups, net.eps)
         return ss
 
+    def stats_from_partials(self, part, tiles, B, HW):
+        """stats() of a tensor whose producing convolution left its per-tile channel sums in `part` (vd_gemm_desc.gn_part)."""
+        net = self.net
+        ss = torch.empty((B, self.ch, 2), device=part.device, dtype=torch.float32)
+        mean = torch.empty(B * self.groups, device=part.device, dtype=torch.float32)
+        ops.groupnorm_stats_from_partials(part, tiles, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], ss, mean,
+                                          torch.empty_like(mean), HW, self.groups, net.eps)
+        return ss
+
     def bwd(self, dy, x, mean, rstd, dx, extra=None, extra2=None, rowsum=None):
         """extra / extra2: residual gradients added into dx; rowsum ([B, C] view, row stride free): per-image channel sums of the dx
         written, i.e. the bias-gradient rows of the layer that produced x, from the same pass."""
@@ -267,8 +277,15 @@ class _Resnet:
             # inference: GroupNorm + SiLU folded into the convolutions' patch loaders -- a statistics pass (one read) replaces the
             # normalise pass (read + write) and the normalised activations never reach HBM
             h1 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
-            self.conv1.fwd(x, h1, rowadd=st.temb_all[:, self.temb_off:], rowadd_bstride=st.temb_all.stride(0), gn_ss=self.norm1.stats(x))
-            ss2 = self.norm2.stats(h1)
+            # norm2's statistics come out of conv1's epilogue (per-tile channel sums) when conv1 runs on the 16x16x32 kernel: no read of h1
+            tiles = (H * W) // 256
+            part = torch.empty((B, tiles, self.cout, 2), device=dev, dtype=torch.float32) if (getattr(net, "gn_stats_in_epilogue", False) and tiles > 0) else None
+            self.conv1.fwd(x, h1, rowadd=st.temb_all[:, self.temb_off:], rowadd_bstride=st.temb_all.stride(0), gn_ss=self.norm1.stats(x),
+                           gn_part=part)
+            if part is not None and ops.GN_PART_WRITTEN:
+                ss2 = self.norm2.stats_from_partials(part, tiles, B, H * W)
+            else:
+                ss2 = self.norm2.stats(h1)
             if self.has_sc:
                 ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
                             net.P[self.prefix + ".conv_shortcut.bias"], out,
@@ -693,6 +710,9 @@ class UNet2DModel(nn.Module):
         # bias-gradient row sums and skip-connection gradient adds ride in the GroupNorm backward that writes the tensor they read
         # (vd_groupnorm_bwd_fused) instead of ~50 rowsum + 12 add_strided launches per step; False: the separate launches
         self.fuse_gn_bwd = os.environ.get("VILLAN_FUSE_GN_BWD", "1") != "0"
+        # no-grad forward: the statistics of a ResnetBlock2D's second GroupNorm are summed in the first convolution's epilogue
+        # (vd_gemm_desc.gn_part) instead of a read of its output; False: the statistics pass
+        self.gn_stats_in_epilogue = os.environ.get("VILLAN_GN_STATS_IN_EPILOGUE", "1") != "0"
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
