@@ -74,6 +74,71 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float* __restrict
     }
 }
 
+// Small slabs (<= 1024 elements: the 8x8 / 4x4 stages): ONE WAVE per (batch item, group), four groups per workgroup -- no LDS, no barrier; the
+// 256-thread kernel above leaves 128 .. 224 of its threads without an element there and pays two block reductions (7.4 us per launch for 8 MB).
+template <int NV>
+__global__ __launch_bounds__(256) void gn_fwd_wave_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, int C,
+                                                          int HW, int G, float eps, int apply_silu, int64_t x_bs, int64_t y_bs,
+                                                          float* __restrict__ ss_out, int total) {
+    const int lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= total) return;
+    const int b = gid / G, g = gid - b * G;
+    const int cpg = C / G;
+    const int n4 = (cpg * HW) >> 2;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + (int64_t)g * cpg * HW);
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + i * 64;
+        v[i] = (idx < n4) ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float inv_n = 1.f / (float)(cpg * HW);
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + i * 64 < n4) {
+            const float a0 = v[i][0] - mean, a1 = v[i][1] - mean, a2 = v[i][2] - mean, a3 = v[i][3] - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+    if (lane == 0) {
+        mean_out[gid] = mean;
+        rstd_out[gid] = rstd;
+    }
+    if (ss_out) {
+        for (int cl = lane; cl < cpg; cl += 64) {
+            const int c = g * cpg + cl;
+            const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+            ss_out[((int64_t)b * C + c) * 2] = ga;
+            ss_out[((int64_t)b * C + c) * 2 + 1] = be;
+        }
+        return;
+    }
+    f32x4* __restrict__ y4 = reinterpret_cast<f32x4*>(y + (int64_t)b * y_bs + (int64_t)g * cpg * HW);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < n4) {
+            const int c = g * cpg + (idx * 4) / HW;
+            const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = v[i][j] * ga + be;
+                o[j] = apply_silu ? z * sigmoidf_(z) : z;
+            }
+            y4[idx] = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int HW,
@@ -390,6 +455,101 @@ __global__ __launch_bounds__(NTH) void gn_bwd_reg_kernel(const float* __restrict
     }
 }
 
+// Backward for small slabs (<= 1024 elements, a channel = L = HW/4 < 64 lanes, L a power of two: the 8x8 / 4x4 stages): one WAVE per (batch item,
+// group), four groups per workgroup, no LDS and no barrier (gn_bwd_reg_kernel<1, 256>: 10 us per launch for 8-25 MB).  Channels are L-lane segments:
+// per-channel sums by butterflies inside the segment, the two group sums m1 = sum ga*dz, m2 = sum ga*dz*xhat by one wave reduction each.
+template <int NV>
+__global__ __launch_bounds__(256) void gn_bwd_wave_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ extra, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws, int C,
+                                                          int HW, int G, int apply_silu, int64_t dy_bs, int64_t x_bs,
+                                                          int64_t ex_bs, int64_t dx_bs, const float* __restrict__ extra2,
+                                                          int64_t ex2_bs, float* __restrict__ rs_out, int64_t rs_ld, int total) {
+    const int lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= total) return;
+    const int b = gid / G, g = gid - b * G;
+    const int cpg = C / G;
+    const int n4 = (cpg * HW) >> 2;
+    const int L = HW >> 2;
+    const int64_t goff = (int64_t)g * cpg * HW;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff);
+    const f32x4* __restrict__ d4 = reinterpret_cast<const f32x4*>(dy + (int64_t)b * dy_bs + goff);
+    const f32x4* __restrict__ e4 = extra ? reinterpret_cast<const f32x4*>(extra + (int64_t)b * ex_bs + goff) : nullptr;
+    const f32x4* __restrict__ f4 = extra2 ? reinterpret_cast<const f32x4*>(extra2 + (int64_t)b * ex2_bs + goff) : nullptr;
+    f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(dx + (int64_t)b * dx_bs + goff);
+    const float mean = mean_in[gid], rstd = rstd_in[gid];
+
+    f32x4 xh[NV], dz[NV];
+    float gav[NV];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + i * 64;
+        const bool in = idx < n4;
+        const f32x4 xv = in ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 dv = in ? d4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = g * cpg + (in ? idx / L : 0);
+        const float ga = gamma[c], be = beta[c];
+        gav[i] = ga;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h_ = (xv[j] - mean) * rstd;
+            float z_ = dv[j];
+            if (apply_silu) {
+                const float z = h_ * ga + be, sg = sigmoidf_(z);
+                z_ *= sg * (1.f + z * (1.f - sg));
+            }
+            if (!in) z_ = 0.f;
+            xh[i][j] = h_;
+            dz[i][j] = z_;
+            s1 += z_;
+            s2 += z_ * h_;
+        }
+        for (int off = 1; off < L; off <<= 1) {                   // butterfly inside the L-lane channel segment
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+        }
+        if (in && (lane & (L - 1)) == 0) {
+            dbeta_ws[(int64_t)b * C + c] = s1;
+            dgamma_ws[(int64_t)b * C + c] = s2;
+            m1 += ga * s1;                                        // one lane per channel carries the channel's weighted sums
+            m2 += ga * s2;
+        }
+    }
+    const float inv_n = 1.f / (float)(cpg * HW);
+    m1 = wave_sum(m1) * inv_n;
+    m2 = wave_sum(m2) * inv_n;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + i * 64;
+        const bool in = idx < n4;
+        float s3 = 0.f;
+        if (in) {
+            f32x4 ev = {0.f, 0.f, 0.f, 0.f}, o;
+            if (e4) ev = e4[idx];
+            if (f4) {
+                const f32x4 fv = f4[idx];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ev[j] += fv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = rstd * (dz[i][j] * gav[i] - m1 - xh[i][j] * m2) + ev[j];
+                s3 += o[j];
+            }
+            o4[idx] = o;
+        }
+        if (rs_out) {
+            for (int off = 1; off < L; off <<= 1) s3 += __shfl_xor(s3, off, 64);
+            if (in && (lane & (L - 1)) == 0) rs_out[(int64_t)b * rs_ld + g * cpg + idx / L] = s3;
+        }
+    }
+}
+
 // ---- multi-workgroup GroupNorm for slabs too large for registers (256x256 images at batch 8: B*G = 256 groups of 1 MB) ----
 // One workgroup per group streams a 1 MB slab three times at a fraction of the HBM rate.  Here a group is cut into S
 // chunks of <= 8192 floats, one workgroup each: pass A reduces the chunk (register-resident) to (mean, M2) partials,
@@ -582,6 +742,11 @@ __global__ __launch_bounds__(256) void gn_chunk_bwd_apply_kernel(const float* __
 }
 
 // Chunks per group for the multi-workgroup path (0: not applicable): chunk <= 8192 floats, inside one channel, S <= 256.
+static bool gn_wave_ok() {
+    static const int off = getenv("VD_GN_WAVE_OFF") ? atoi(getenv("VD_GN_WAVE_OFF")) : 0;
+    return !off;
+}
+
 static int gn_chunks(int B, int C, int HW, int G) {
     const int cpg = C / G;
     const int64_t slab = (int64_t)cpg * HW;
@@ -622,7 +787,15 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
 #define VD_GN_FWD(NVV)                                                                                                       \
     hipLaunchKernelGGL((gn_fwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, \
                        C, HW, G, eps, apply_silu, x_bstride, y_bstride, (float*)nullptr)
-    if (reg_ok && slab <= 1024) VD_GN_FWD(1);
+    if (reg_ok && slab <= 1024 && gn_wave_ok()) {
+#define VD_GN_FWDW(NVV)                                                                                                                     \
+    hipLaunchKernelGGL((gn_fwd_wave_kernel<NVV>), dim3(vd_cdiv(B * G, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, \
+                       C, HW, G, eps, apply_silu, x_bstride, y_bstride, (float*)nullptr, B * G)
+        if (slab <= 256) VD_GN_FWDW(1);
+        else if (slab <= 512) VD_GN_FWDW(2);
+        else VD_GN_FWDW(4);
+#undef VD_GN_FWDW
+    } else if (reg_ok && slab <= 1024) VD_GN_FWD(1);
     else if (reg_ok && slab <= 2048) VD_GN_FWD(2);
     else if (reg_ok && slab <= 4096) VD_GN_FWD(4);
     else if (reg_ok && slab <= 8192) VD_GN_FWD(8);
@@ -645,7 +818,15 @@ extern "C" int vd_groupnorm_stats(const float* x, const float* gamma, const floa
 #define VD_GN_ST(NVV)                                                                                                          \
     hipLaunchKernelGGL((gn_fwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)nullptr, \
                        mean, rstd, C, HW, G, eps, 0, x_bstride, (int64_t)0, ss)
-    if (slab <= 1024) VD_GN_ST(1);
+    if (slab <= 1024 && gn_wave_ok()) {                           // (the same kernel as vd_groupnorm_fwd takes for this slab: identical statistics)
+#define VD_GN_STW(NVV)                                                                                                                       \
+    hipLaunchKernelGGL((gn_fwd_wave_kernel<NVV>), dim3(vd_cdiv(B * G, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)nullptr, \
+                       mean, rstd, C, HW, G, eps, 0, x_bstride, (int64_t)0, ss, B * G)
+        if (slab <= 256) VD_GN_STW(1);
+        else if (slab <= 512) VD_GN_STW(2);
+        else VD_GN_STW(4);
+#undef VD_GN_STW
+    } else if (slab <= 1024) VD_GN_ST(1);
     else if (slab <= 2048) VD_GN_ST(2);
     else if (slab <= 4096) VD_GN_ST(4);
     else if (slab <= 8192) VD_GN_ST(8);
@@ -726,7 +907,16 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
     hipLaunchKernelGGL((gn_bwd_reg_kernel<NVV, NT>), dim3(B * G), dim3(NT), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, \
                        extra, dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride,      \
                        extra2, extra2_bstride, rowsum, rowsum_ld)
-        if (slab <= 1024) VD_GN_BWD(1, 256);
+        if (slab <= 1024 && L < 64 && gn_wave_ok()) {
+#define VD_GN_BWDW(NVV)                                                                                                                          \
+    hipLaunchKernelGGL((gn_bwd_wave_kernel<NVV>), dim3(vd_cdiv(B * G, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, \
+                       dx, dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride, extra2, extra2_bstride,   \
+                       rowsum, rowsum_ld, B * G)
+            if (slab <= 256) VD_GN_BWDW(1);
+            else if (slab <= 512) VD_GN_BWDW(2);
+            else VD_GN_BWDW(4);
+#undef VD_GN_BWDW
+        } else if (slab <= 1024) VD_GN_BWD(1, 256);
         else if (slab <= 2048) VD_GN_BWD(2, 256);
         else if (slab <= 4096) VD_GN_BWD(4, 256);
         else if (slab <= 8192) VD_GN_BWD(4, 512);
