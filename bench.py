@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-f32 leg (profiling runs: the summary then covers the default arithmetic only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
+    ap.add_argument("--cpu-true-1000", action="store_true",
+                    help="CPU leg: also one TRUE 1000-step DDPM run of one image on the oracle and on the product with the same noise (about a minute of CPU)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph-step", type=int, default=None, choices=(0, 1),
                     help="1: replay q-sample + forward + loss + backward of the training step as ONE HIP graph (trainer.GraphedMicroStep; single process only); "
@@ -62,7 +64,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=None):
+def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=None, true_1000: bool = False):
     """The oracle (plain torch fp32 = what the reference's diffusers path executes on a CPU) on the host cores:
     fwd + bwd + clip(1.0) + Adam on a bounded sample of the same workload.
 
@@ -137,11 +139,25 @@ def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=N
                               and parity["denoised_max_rel_err"] <= 1e-3 and parity["timestep_indices_bit_exact"])
         parity["what"] = (f"product vs CPU oracle on identical weights and inputs: one fwd+bwd at batch {batch} (loss, gradient norm); "
                           "8 images x the last 20 steps of DDPM-1000 with the same CPU-generator noise (denoised images); DDPM-1000 timestep table")
+    full = None
+    if true_1000:          # SURVEY 8d "one true 1000-step run at n=1 if budget allows": the whole chain, product vs oracle on the same noise (opt-in: ~1 min of CPU)
+        init1 = torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(12))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            x1 = sample_loop(net, sched, init1.clone(), 1000, generator=torch.Generator().manual_seed(6), start_from=0)
+            dt1 = time.perf_counter() - t0
+        full = {"images_per_sec": round(1.0 / dt1, 5), "seconds": round(dt1, 2)}
+        if gpu_side is not None:
+            ref1 = (x1 / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+            img1, _ = gpu_side["sample"](init1, 6, 0, sched.timesteps)
+            full["denoised_max_rel_err_after_1000_steps"] = float(f"{abs(img1 - ref1).max() / abs(ref1).max():.3e}")
     cpu = {"value": round(train_ips, 3), "unit": "train images/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"{n_steps} optimiser steps at batch {batch} (fwd+bwd+clip+Adam, fp32 torch CPU oracle); "
                      f"sampling: 8 images x 20 DDPM steps extrapolated x50",
            "sample_ddpm1000_images_per_sec": round(sample_ips, 5), "host_cpus": os.cpu_count(),
            "affinity": len(os.sched_getaffinity(0))}
+    if full is not None:
+        cpu["true_1000_step_run_n1"] = full
     return cpu, parity
 
 
@@ -518,7 +534,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
         cpu, parity = cpu_baseline(args.cpu_batch, args.cpu_steps, state_dict=sd,
-                                   gpu_side={"train": gpu_train_side, "sample": gpu_sample_side})
+                                   gpu_side={"train": gpu_train_side, "sample": gpu_sample_side}, true_1000=args.cpu_true_1000)
         log(f"cpu baseline: {cpu}")
         log(f"parity: {parity}")
 
