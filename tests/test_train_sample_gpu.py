@@ -351,6 +351,15 @@ def test_batches_addressed_by_device_positions_need_no_host_copy_and_equal_the_h
     assert loader._ids_dev is not None and loader._ids_dev.is_cuda
     n = sum(b["pixel_values"].shape[0] for b in loader)
     assert n == 256
+    # R_trigger_only partitions (the per-batch flag check needs the host flags) and full batches take the host-position path even for device positions
+    rto = DatasetLoader("SYNTHETIC-CIFAR10", root=ROOT, batch_size=32, seed=0, images=synthetic_images(n=256, size=32))
+    rto.set_poison("BOX_14", "HAT", poison_rate=1.0).prepare_dataset(mode="FIXED", R_trigger_only=True)
+    a = rto.make_batch(ids, flip_bits=flips, full=False)
+    b = rto.make_batch(ids.cuda(), flip_bits=flips, full=False)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.equal(b["pixel_values"][0], rto.trigger.to(b["pixel_values"].device))       # R = the trigger alone
+    fa, fb = dsl.make_batch(ids, flip_bits=flips, full=True), dsl.make_batch(ids.cuda(), flip_bits=flips, full=True)
+    assert set(fa) == set(fb) and all(torch.equal(fa[k], fb[k]) for k in fa)
 
 
 def test_cli_resume_continues_from_the_checkpoint(tmp_path):
