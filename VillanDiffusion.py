@@ -347,6 +347,12 @@ def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
     g = torch.Generator().manual_seed(cfg.seed)
     noise = torch.randn((n, pipeline.unet.in_channels, pipeline.unet.sample_size, pipeline.unet.sample_size), generator=g)
     bd_noise = noise + pipeline.encode(dsl.trigger.unsqueeze(0)).to(noise.device)
+    # Throughput mode of the 2 x N-image sampling job: the per-step noise of the stochastic samplers comes from the in-kernel Philox stream seeded with
+    # cfg.seed (not from a CPU generator whose draws would cross PCIe every step), which also lets the chunks of --eval_max_batch run concurrently
+    # (sampling_io.batch_sampling_save -> pipelines.sample_concurrent).  VILLAN_HOST_RNG=1: the reference's CPU-generator noise, one chunk at a time.
+    sch = pipeline.scheduler
+    if os.environ.get("VILLAN_HOST_RNG", "0") != "1" and hasattr(sch, "device_rng_seed") and pipeline.device.type == "cuda":
+        sch.device_rng_seed = int(cfg.seed)
     for path, init in ((clean_path, noise), (bd_path, bd_noise)):
         batch_sampling_save(n, pipeline, path, init=init, max_batch_n=cfg.eval_max_batch, rng=torch.Generator().manual_seed(cfg.seed),
                             num_inference_steps=cfg.infer_steps, eta=cfg.ddim_eta, rank=rank, world=world)

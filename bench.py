@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config #2)")
     ap.add_argument("--sample-steps", type=int, default=1000)
     ap.add_argument("--sample-images", type=int, default=384, help="per-GPU images of the DDPM sampling leg, in chunks of --batch (0 = skip)")
-    ap.add_argument("--sample-streams", type=int, default=3,
+    ap.add_argument("--sample-streams", type=int, default=4,
                     help="chunks denoised concurrently, each on its own stream / HIP graph (pipelines.sample_concurrent); 1: one after the other")
     ap.add_argument("--mode", choices=("all", "train", "sample"), default="all",
                     help="train: training legs only (no sampler) / sample: sampler only -- so that a rocprofv3 summary covers ONE dispatch population")
@@ -558,12 +558,12 @@ def main():
             "vs_baseline": None, "dtype": "bf16x3/f32" if split else "f32", "data": "synthetic",
             "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), per-GPU batch %d; "
                                    "+ %d-step DDPM sampling of %d images/GPU in chunks of %d, %d chunks at a time on their own streams (SURVEY 8d: 1024 = 8 such chunks)"
-                                   % (B, args.sample_steps, args.sample_images, B, args.sample_streams),
+                                   % (B, args.sample_steps, args.sample_images, B, min(args.sample_streams, -(-args.sample_images // B))),
                        "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}", "mode": args.mode},
             "exact_f32_mode": None if exact is None else {k: exact[k] for k in ("train_images_per_sec", "ms_per_step")},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
             "sample_seconds": None if sample_s is None else round(sample_s, 2),
-            "sample_hip_graph": bool(net.sampler_graph), "sample_streams": args.sample_streams if args.sample_images > B else 1,
+            "sample_hip_graph": bool(net.sampler_graph), "sample_streams": min(args.sample_streams, -(-args.sample_images // B)) if args.sample_images > B else 1,
             "sample_secondary_images_per_sec": secondary,
             "train_tflops": None if train_ips is None else round(train_ips * TRAIN_GFLOP_PER_IMG / 1e3, 2),
             "sample_tflops": None if sample_ips is None else round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3, 2),

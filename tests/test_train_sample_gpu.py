@@ -362,6 +362,52 @@ def test_batches_addressed_by_device_positions_need_no_host_copy_and_equal_the_h
     assert set(fa) == set(fb) and all(torch.equal(fa[k], fb[k]) for k in fa)
 
 
+def test_measure_sampling_job_runs_its_chunks_concurrently_with_the_same_images(tmp_path, monkeypatch):
+    """sampling_io.batch_sampling_save (the 2 x N-image job of measure(), reference VillanDiffusion.py:1062-1067 / model.py:504-527): a rank's chunks go
+    through pipelines.sample_concurrent where that gives the same PNGs -- deterministic samplers always, DDPM with the in-kernel noise the driver selects."""
+    from PIL import Image
+    from villandiffusion_amd import sampling_io as SIO
+    from villandiffusion_amd.pipelines import DDIMPipeline, DDPMPipeline
+    net = UNet2DModel(block_out_channels=(32, 64), down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+                      up_block_types=("AttnUpBlock2D", "UpBlock2D"), norm_num_groups=8)
+    net.reset_parameters(0)
+    init = torch.randn(10, 3, 32, 32, generator=torch.Generator().manual_seed(0))              # chunks of 4, 4, 2
+
+    def pngs(d):
+        return np.stack([np.asarray(Image.open(os.path.join(d, f"{i}.png"))) for i in range(10)])
+
+    calls = []
+    orig = DDIMPipeline.sample_concurrent
+
+    def spy(self, inits, **kw):
+        calls.append(len(inits))
+        return orig(self, inits, **kw)
+
+    monkeypatch.setattr(DDIMPipeline, "sample_concurrent", spy)
+    pipe = DDIMPipeline(net, S.DDIMScheduler(clip_sample=False))
+    SIO.batch_sampling_save(10, pipe, str(tmp_path / "conc"), init=init, max_batch_n=4, rng=torch.Generator().manual_seed(1), num_inference_steps=5)
+    assert calls == [3]
+    monkeypatch.setenv("VILLAN_SAMPLER_STREAMS", "1")
+    SIO.batch_sampling_save(10, pipe, str(tmp_path / "seq"), init=init, max_batch_n=4, rng=torch.Generator().manual_seed(1), num_inference_steps=5)
+    assert calls == [3]
+    assert np.array_equal(pngs(tmp_path / "conc"), pngs(tmp_path / "seq"))
+    monkeypatch.delenv("VILLAN_SAMPLER_STREAMS")
+    # two ranks: each takes its own chunks and writes its own index range
+    for r in range(2):
+        SIO.batch_sampling_save(10, pipe, str(tmp_path / "ddp"), init=init, max_batch_n=4, num_inference_steps=5, rank=r, world=2)
+    assert np.array_equal(pngs(tmp_path / "ddp"), pngs(tmp_path / "seq"))
+    # DDPM: host-generator noise keeps the sequential path; with the in-kernel stream (what measure() selects) the chunks run concurrently
+    dd = DDPMPipeline(net, S.DDPMScheduler())
+    assert not SIO._concurrent_ok(dd, [(init[:4], 4), (init[4:8], 4)], None)
+    dd.scheduler.device_rng_seed = 7
+    assert SIO._concurrent_ok(dd, [(init[:4], 4), (init[4:8], 4)], None)
+    SIO.batch_sampling_save(10, dd, str(tmp_path / "ddpm_a"), init=init, max_batch_n=4, num_inference_steps=6)
+    dd.scheduler._rng_offset = 0
+    SIO.batch_sampling_save(10, dd, str(tmp_path / "ddpm_b"), init=init, max_batch_n=4, num_inference_steps=6)
+    a = pngs(tmp_path / "ddpm_a")
+    assert np.array_equal(a, pngs(tmp_path / "ddpm_b")) and a.std() > 0                           # seeded: reproducible
+
+
 def test_cli_resume_continues_from_the_checkpoint(tmp_path):
     """--mode resume (reference :454-461, 1103-1115): model from the run directory, optimiser / LR-schedule / counters from
     ckpt/trainer.pt and data.ckpt.  As in the reference the checkpoint records the 0-based index of the epoch it was written AFTER

@@ -29,15 +29,46 @@ def batch_sampling(sample_n: int, pipeline, init: torch.Tensor = None, max_batch
     return np.concatenate(outs)
 
 
+def sampler_streams() -> int:
+    """Chunks the measure / sampling loops denoise at a time (pipelines.sample_concurrent); VILLAN_SAMPLER_STREAMS=1: one after the other like the reference."""
+    return max(1, int(os.environ.get("VILLAN_SAMPLER_STREAMS", "4")))
+
+
+def _concurrent_ok(pipeline, chunks, eta) -> bool:
+    """The chunk list can go through pipelines.sample_concurrent with the SAME images as one pipeline call per chunk: a plain pipeline on the
+    HIP-graph forward, explicit inits, and either a deterministic sampler or in-kernel noise (scheduler.device_rng_seed: the drivers set it)."""
+    from .pipelines import DiffusionPipeline
+    from .unet import UNet2DModel
+    if sampler_streams() < 2 or len(chunks) < 2 or any(c is None for c, _ in chunks):
+        return False
+    if type(pipeline).__call__ is not DiffusionPipeline.__call__ or not hasattr(pipeline, "sample_concurrent"):
+        return False                                           # LDM / ScoreSDE-VE / Karras-VE pipelines have their own loops
+    unet, sch = pipeline.unet, pipeline.scheduler
+    if not (isinstance(unet, UNet2DModel) and getattr(unet, "sampler_graph", False) and unet.device.type == "cuda"):
+        return False
+    seeded = getattr(sch, "device_rng_seed", None) is not None
+    stochastic = type(sch).__name__ in ("DDPMScheduler", "ScoreSdeVeScheduler") or (eta is not None and float(eta) != 0.0)
+    return seeded or not stochastic
+
+
 def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], init: torch.Tensor = None, max_batch_n: int = 256,
                         rng: torch.Generator = None, num_inference_steps: Optional[int] = None, eta: Optional[float] = None,
                         rank: int = 0, world: int = 1):
-    """model.py:504-527; with `world` > 1 each rank samples its own contiguous slice of the chunk list (replicas only)."""
-    cnt = 0
+    """model.py:504-527; with `world` > 1 each rank samples its own slice of the chunk list (replicas only).  A rank's chunks are denoised
+    sampler_streams() at a time on their own streams where that gives the same images (see _concurrent_ok), else one after the other."""
+    cnt, mine = 0, []
     for k, (c, n) in enumerate(_chunks(sample_n, init, max_batch_n)):
         if k % world == rank:
-            kw = {} if eta is None else {"eta": eta}
-            res = pipeline(batch_size=n, generator=rng, init=c, output_type=None, num_inference_steps=num_inference_steps, **kw)
-            save_imgs(res.images, path, start_cnt=cnt)
+            mine.append((c, n, cnt))
         cnt += n
+    if _concurrent_ok(pipeline, [(c, n) for c, n, _ in mine], eta):
+        from .pipelines import _post
+        xs = pipeline.sample_concurrent([c for c, _, _ in mine], num_inference_steps=num_inference_steps, n_streams=sampler_streams(), eta=eta)
+        for (c, n, start), x in zip(mine, xs):
+            save_imgs(_post(x), path, start_cnt=start)
+        return None
+    for c, n, start in mine:
+        kw = {} if eta is None else {"eta": eta}
+        res = pipeline(batch_size=n, generator=rng, init=c, output_type=None, num_inference_steps=num_inference_steps, **kw)
+        save_imgs(res.images, path, start_cnt=start)
     return None
