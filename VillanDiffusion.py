@@ -2,7 +2,8 @@
 """MI355X-native driver with the reference's command line (VillanDiffusion.py:74-116), modes, config overlay rules,
 result-directory naming and JSON side files (args.json / config.json / sampling.json), so existing recipes
 (`--mode train --dataset CIFAR10 --batch 128 --epoch 50 --poison_rate 0.1 --trigger BOX_14 --target HAT
---ckpt DDPM-CIFAR10-32 --fclip o -o --gpu 0`) run unchanged.  One process per GPU: multi-GPU = `torchrun --nproc-per-node N`.
+--ckpt DDPM-CIFAR10-32 --fclip o -o --gpu 0`) run unchanged.  `--gpu K` runs on device K; `--gpu "0,1,2,3"` starts one rank process per listed
+GPU (gpu_plan below; the reference drives nn.DataParallel over them, :240-245, 440); `torchrun --nproc-per-node N VillanDiffusion.py ...` works too.
 
 Not reproduced on purpose: module-level side effects at import (the reference parses argv and calls wandb.init on import,
 :323), swallowed training exceptions (:1189-1191), nn.DataParallel (:440).  `measure` writes the clean / backdoor PNG
@@ -127,7 +128,7 @@ def setup(args: argparse.Namespace, preflight: bool = False) -> TrainingConfig:
     cfg.mode = mode
     cfg.clip = cfg.fclip == "w"                                        # :252-258
     cfg.mixed_precision = "no"                                         # fp32 everywhere (reference: fp16 autocast for VP/LDM)
-    cfg.device_ids = [int(i) for i in range(len(cfg.gpu.split(",")))]  # :245
+    cfg.device_ids = [int(i) for i in range(len(cfg.gpu.split(",")))]  # :245 (indices into the visible set main() exported from --gpu)
     if isinstance(cfg.sample_ep, int) and cfg.sample_ep < 0:           # :248-251
         cfg.sample_ep = None
     small = cfg.dataset in ("CIFAR10", "MNIST", "SYNTHETIC-CIFAR10", "CELEBA-HQ-LATENT_PR05", "CELEBA-HQ-LATENT")
@@ -176,8 +177,10 @@ def _dist():
     import torch.distributed as dist
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if world > 1 and not dist.is_initialized():
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        backend = os.environ.get("VILLAN_DIST_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm; gloo only for launcher tests on a box without GPUs
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -301,7 +304,7 @@ def measure_inpaints(cfg, pipeline, dsl):
         rec.append(out.images)
     recover = torch.from_numpy(np.vstack(rec)).permute(0, 3, 1, 2).float()
     return {"LPIPS": measure_lpips(recover, target_imgs.float(), cfg.eval_max_batch), "MSE": mse_batch(recover, target_imgs.float()),
-            "SSIM": ssim_batch(recover, target_imgs.float())}
+            "SSIM": ssim_batch(recover, target_imgs.float(), device=pipeline.device)}
 
 
 def measure_lpips(recover, target, max_batch: int = 256):
@@ -366,7 +369,7 @@ def measure(cfg, pipeline, dsl, rank: int = 0, world: int = 1):
     tgt01 = dsl.target.clamp(0, 1) if cfg.sde_type == "SDE-VE" else (dsl.target / 2 + 0.5).clamp(0, 1)
     tgt = tgt01[None].expand(n, -1, -1, -1)
     fid_sc = measure_fid(cfg, dsl, clean_path, n)
-    sc = {"FID": fid_sc, "MSE": mse_batch(gen, tgt), "SSIM": ssim_batch(gen, tgt)}
+    sc = {"FID": fid_sc, "MSE": mse_batch(gen, tgt), "SSIM": ssim_batch(gen, tgt, device=pipeline.device)}
     path = os.path.join(cfg.output_dir, "score.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     for k, v in sc.items():
@@ -403,11 +406,14 @@ def measure_fid(cfg, dsl, clean_path: str, n: int, folder_name: str = "measure")
     return float(fid(path=[dataset_img_dir, clean_path], num_workers=4, batch_size=cfg.eval_max_batch))
 
 
-def checkpoint(cfg, trainer, pipeline, epoch, step):
+def checkpoint(cfg, trainer, pipeline, epoch, step, dsl=None):
     import torch
     os.makedirs(cfg.ckpt_path, exist_ok=True)
     torch.save(trainer.state_dict(), os.path.join(cfg.ckpt_path, "trainer.pt"))
-    torch.save({"epoch": epoch, "step": step}, cfg.data_ckpt_path)
+    data = {"epoch": epoch, "step": step}
+    if dsl is not None and hasattr(dsl, "loader_state"):
+        data["loader"] = dsl.loader_state()                           # device flip generator: a resumed run draws the same flips
+    torch.save(data, cfg.data_ckpt_path)
     pipeline.save_pretrained(cfg.output_dir)
     if cfg.is_save_all_model_epochs:                                   # reference :1110-1114: a copy per checkpointed epoch
         pipeline.save_pretrained(get_ep_model_path(cfg, cfg.output_dir, epoch))
@@ -450,6 +456,8 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
         trainer.load_state_dict(torch.load(os.path.join(cfg.ckpt_path, "trainer.pt"), map_location=model.device))
         d = torch.load(cfg.data_ckpt_path)
         start_epoch, step = int(d["epoch"]), int(d["step"])
+        if hasattr(dsl, "load_loader_state"):
+            dsl.load_loader_state(d.get("loader"))
     pipeline = get_pipeline(None, model, vae, noise_sched)
     if rank == 0:
         sampling(cfg, 0, pipeline, dsl)
@@ -472,16 +480,107 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
                     from villandiffusion_amd.pipelines import drop_sampler_graphs
                     drop_sampler_graphs(model)
             if (epoch + 1) % cfg.save_model_epochs == 0 or epoch == cfg.epoch - 1:
-                checkpoint(cfg, trainer, pipeline, epoch, step)
+                checkpoint(cfg, trainer, pipeline, epoch, step, dsl)
     if rank == 0:                                                      # reference :1192-1195
-        checkpoint(cfg, trainer, pipeline, epoch, step)
+        checkpoint(cfg, trainer, pipeline, epoch, step, dsl)
         sampling(cfg, "final", pipeline, dsl)
     return pipeline
 
 
+def effective_gpu(args: argparse.Namespace) -> str:
+    """The --gpu string that applies to this run BEFORE the config overlay runs (it must be known before anything touches the GPU):
+    the command line, else (resume / sampling / measure) the value the run directory's args.json recorded, else the default "0"."""
+    if getattr(args, "gpu", None):
+        return str(args.gpu)
+    if args.mode in (MODE_RESUME, MODE_SAMPLING, MODE_MEASURE) and getattr(args, "ckpt", None):
+        base = args.ckpt if os.path.isdir(args.ckpt) else os.path.join(args.result or DEFAULT["result"], args.ckpt)
+        try:
+            with open(os.path.join(base, "args.json")) as f:
+                g = json.load(f).get("gpu")
+            if g:
+                return str(g)
+        except OSError:
+            pass
+    return DEFAULT["gpu"]
+
+
+def gpu_plan(gpu: str, env: dict) -> dict:
+    """What `--gpu` means here (reference VillanDiffusion.py:240-245, 440: CUDA_VISIBLE_DEVICES = config.gpu, then nn.DataParallel over
+    device_ids 0..n-1 of the visible set).  Pure function of the flag and the environment, so that it can be tested without a GPU.
+
+    * the listed indices select from the devices visible NOW (an already-set HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES is composed with,
+      not overridden: `--gpu 1` inside HIP_VISIBLE_DEVICES=4,5 is physical device 5);
+    * one index  -> this process runs on that device (`visible` is exported before the HIP runtime starts);
+    * n indices, no WORLD_SIZE -> the parent starts n rank processes, one per listed GPU, through torch.distributed.run BEFORE making any GPU
+      call (it never makes one) and exits with the launcher's code -- the one-process-per-GPU form of the reference's DataParallel;
+    * under a launcher (WORLD_SIZE set) the launcher's device assignment stands: LOCAL_RANK picks the device, nothing is changed."""
+    ids = [i.strip() for i in str(gpu).split(",") if i.strip() != ""]
+    if not ids or not all(i.isdigit() for i in ids):
+        raise ValueError(f"--gpu {gpu!r}: expected a device index or a comma-separated list of indices")
+    if len(set(ids)) != len(ids):
+        raise ValueError(f"--gpu {gpu!r}: a device is listed twice")
+    if "WORLD_SIZE" in env:
+        return {"action": "rank", "visible": None, "n": int(env["WORLD_SIZE"])}
+    cur = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES")
+    if cur:
+        pool = [c.strip() for c in cur.split(",") if c.strip() != ""]
+        for i in ids:
+            if int(i) >= len(pool):
+                raise ValueError(f"--gpu {gpu!r}: index {i} is outside the {len(pool)} visible device(s) ({cur})")
+        vis = [pool[int(i)] for i in ids]
+    else:
+        vis = ids
+    return {"action": "single" if len(ids) == 1 else "spawn", "visible": ",".join(vis), "n": len(ids)}
+
+
+_VISIBLE0: Optional[str] = None
+
+
+def apply_gpu_flag(args: argparse.Namespace, argv: Optional[List[str]]):
+    """Honour --gpu (see gpu_plan).  Called first thing in main(): no torch import, no HIP call has happened yet."""
+    global _VISIBLE0
+    if _VISIBLE0 is None:                                              # main() called again in this process: --gpu indexes the ORIGINAL set
+        _VISIBLE0 = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or ""
+    env = {k: v for k, v in os.environ.items() if k not in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    if _VISIBLE0:
+        env["HIP_VISIBLE_DEVICES"] = _VISIBLE0
+    plan = gpu_plan(effective_gpu(args), env)
+    if plan["action"] == "rank":
+        return plan
+    os.environ["HIP_VISIBLE_DEVICES"] = plan["visible"]
+    os.environ["CUDA_VISIBLE_DEVICES"] = plan["visible"]              # the name the reference sets (:240); HIP honours both
+    if plan["action"] == "single":
+        return plan
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={plan['n']}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    print(f"[VillanDiffusion] --gpu {effective_gpu(args)}: one rank per GPU ({plan['visible']}): {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main(argv: Optional[List[str]] = None):
     args = parse_args(argv)
+    apply_gpu_flag(args, argv)
     rank, world, _ = _dist()
+    if os.environ.get("VILLAN_RENDEZVOUS_ONLY") == "1":               # launcher test on a box without GPUs: process-group proof, no compute
+        import torch
+        import torch.distributed as dist
+        n = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(n)
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "world_size": world, "ranks_counted": int(n),
+                              "visible": os.environ.get("HIP_VISIBLE_DEVICES")}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     err = None
     try:
         cfg = setup(args, preflight=True)

@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config #2)")
     ap.add_argument("--sample-steps", type=int, default=1000)
-    ap.add_argument("--sample-images", type=int, default=384, help="per-GPU images of the DDPM sampling leg, in chunks of --batch (0 = skip)")
+    ap.add_argument("--sample-images", type=int, default=1024,
+                    help="per-GPU images of the DDPM sampling leg, in chunks of --batch (SURVEY 8d: 1024 = 8 chunks of 128; 0 = skip)")
     ap.add_argument("--sample-streams", type=int, default=4,
                     help="chunks denoised concurrently, each on its own stream / HIP graph (pipelines.sample_concurrent); 1: one after the other")
     ap.add_argument("--mode", choices=("all", "train", "sample"), default="all",
@@ -556,9 +557,13 @@ def main():
             "value": None if train_ips is None else round(train_ips, 2), "unit": "train images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": None if ms is None else round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3/f32" if split else "f32", "data": "synthetic",
-            "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune step (BOX_14->HAT, poison_rate 0.1, SDE-VP, psi=1), per-GPU batch %d; "
-                                   "+ %d-step DDPM sampling of %d images/GPU in chunks of %d, %d chunks at a time on their own streams (SURVEY 8d: 1024 = 8 such chunks)"
-                                   % (B, args.sample_steps, args.sample_images, B, min(args.sample_streams, -(-args.sample_images // B))),
+            # `workload` stays under 128 characters (the driver's record truncates there); the details live in the keys beside it
+            "config": {"workload": "DDPM-CIFAR10-32 poisoned fine-tune B=%d (BOX_14->HAT pr0.1 SDE-VP) + DDPM-%d sampling %d img/GPU (%dx%d, %d streams)"
+                                   % (B, args.sample_steps, args.sample_images, -(-args.sample_images // B) if B else 0, B,
+                                      min(args.sample_streams, max(1, -(-args.sample_images // B)))),
+                       "train": "BASELINE config #2: poison_rate 0.1, trigger BOX_14, target HAT, SDE-VP psi=1 sde, per-GPU batch %d, Adam + clip 1.0" % B,
+                       "sampling": "%d-step DDPM, %d images/GPU in chunks of %d, %d chunks at a time on their own streams / HIP graphs"
+                                   % (args.sample_steps, args.sample_images, B, min(args.sample_streams, max(1, -(-args.sample_images // B)))),
                        "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}", "mode": args.mode},
             "exact_f32_mode": None if exact is None else {k: exact[k] for k in ("train_images_per_sec", "ms_per_step")},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),

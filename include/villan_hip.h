@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 7
+#define VD_ABI_VERSION 8
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -322,6 +322,11 @@ int vd_batch_l2norm(const float* x, float* out, int B, int64_t inner, void* stre
 /* out = clamp(x*mul + add, lo, hi), optionally NCHW -> NHWC (pipeline post-processing). */
 int vd_postprocess(const float* x, float* out, int B, int C, int HW, float mul, float add, float lo, float hi,
                    int to_nhwc, void* stream);
+/* out[n] = mean over the SSIM map of image pair n (a, b: [N, C, H, W]; win: the K x K gaussian window, K odd <= 32): torchmetrics'
+ * StructuralSimilarityIndexMeasure(data_range) as measure() uses it (reference VillanDiffusion.py:1001-1007): reflect padding whose border is
+ * cropped from the map; c1 = (0.01 data_range)^2, c2 = (0.03 data_range)^2. */
+int vd_ssim(const float* a, const float* b, const float* win, float* out, int N, int C, int H, int W, int K, float c1, float c2,
+            void* stream);
 /* VQ-VAE quantiser (diffusers VectorQuantizer.forward, reached through VQModel.decode: reference loss.py:951-962,
  * model.py:713): zq[b][:, p] = codebook[argmin_e |z[b][:, p] - e|^2], idx[b*HW + p] = that e (may be NULL).
  * z / zq: [B, D, HW] with batch strides, codebook [n_e, D], D <= 16. */

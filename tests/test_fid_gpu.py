@@ -187,3 +187,18 @@ def test_measure_wiring_fills_fid_and_lpips_when_local_weights_exist(tmp_path, m
     got = V.measure_lpips(a, b, 4)
     want = float(lp(a, b).mean())
     assert abs(got - want) <= 1e-4 * abs(want)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(5, 3, 32, 32), (3, 1, 28, 28), (2, 3, 64, 48), (4, 3, 8, 8)])
+def test_ssim_kernel_matches_oracle(N, C, H, W):
+    """vd_ssim (measure(): VillanDiffusion.py:1001-1007, torchmetrics SSIM) against oracle/metrics_ref.py; 8 x 8 images are smaller than the
+    cropped border, so the reflect-indexed window is exercised too; a CUDA input never takes the host expression."""
+    from oracle.metrics_ref import ssim_ref
+    from villandiffusion_amd.metrics import ssim_batch
+    a = torch.rand((N, C, H, W), generator=g(1))
+    b = (a + 0.2 * torch.randn((N, C, H, W), generator=g(2))).clamp(0, 1)
+    want = ssim_ref(a.numpy(), b.numpy())
+    got = ssim_batch(a.to(DEV), b.to(DEV))
+    got_dev_arg = ssim_batch(a, b[:1].expand(N, -1, -1, -1) if False else b, device=DEV, chunk=2)
+    assert abs(got - want) < 2e-5 and abs(got_dev_arg - want) < 2e-5, (got, got_dev_arg, want)
+    assert abs(ssim_batch(a.to(DEV), a.to(DEV)) - 1.0) < 1e-6

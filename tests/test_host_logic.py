@@ -439,3 +439,55 @@ def test_metrics_agree_with_the_oracle_restatement():
         assert abs(mse_batch(torch.from_numpy(a), torch.from_numpy(b)) - mse_ref(a, b)) < 1e-7
         assert abs(ssim_batch(torch.from_numpy(a), torch.from_numpy(b)) - ssim_ref(a, b)) < 1e-5
     assert abs(ssim_ref(a, a) - 1.0) < 1e-12
+
+
+def test_gpu_flag_plan():
+    """--gpu (reference VillanDiffusion.py:240-245, 440): one index selects the device, a list starts one rank per listed GPU, an already
+    restricted visible set is indexed into, a launcher's assignment is left alone."""
+    import VillanDiffusion as V
+    assert V.gpu_plan("5", {}) == {"action": "single", "visible": "5", "n": 1}
+    assert V.gpu_plan("0,1,2,3", {}) == {"action": "spawn", "visible": "0,1,2,3", "n": 4}
+    assert V.gpu_plan("1", {"HIP_VISIBLE_DEVICES": "4,5"}) == {"action": "single", "visible": "5", "n": 1}
+    assert V.gpu_plan("1,0", {"CUDA_VISIBLE_DEVICES": "6,7"}) == {"action": "spawn", "visible": "7,6", "n": 2}
+    assert V.gpu_plan("0,1", {"WORLD_SIZE": "2", "HIP_VISIBLE_DEVICES": "0,1"})["action"] == "rank"
+    for bad in ("", "a", "0,0", "1,x"):
+        with pytest.raises(ValueError):
+            V.gpu_plan(bad, {})
+    with pytest.raises(ValueError):
+        V.gpu_plan("2", {"HIP_VISIBLE_DEVICES": "0,1"})
+    # the flag of a resumed / sampled run comes from the run directory when the command line omits it
+    a = V.parse_args(["--mode", "train", "--gpu", "3"])
+    assert V.effective_gpu(a) == "3"
+    assert V.effective_gpu(V.parse_args(["--mode", "train"])) == "0"
+
+
+def test_gpu_flag_from_run_directory(tmp_path):
+    import VillanDiffusion as V
+    (tmp_path / "run").mkdir()
+    with open(tmp_path / "run" / "args.json", "w") as f:
+        json.dump({"gpu": "2,3", "trigger": "BOX_14"}, f)
+    assert V.effective_gpu(V.parse_args(["--mode", "sampling", "--ckpt", str(tmp_path / "run")])) == "2,3"
+    assert V.effective_gpu(V.parse_args(["--mode", "sampling", "--ckpt", str(tmp_path / "run"), "--gpu", "1"])) == "1"
+
+
+def test_gpu_list_spawns_one_rank_per_gpu():
+    """`--gpu "0,1"` without a launcher: the parent (which never touches a GPU) starts two rank processes through torch.distributed.run and
+    exits with its code; here on gloo with VILLAN_RENDEZVOUS_ONLY=1 (no compute).  The ranks see the composed visible set."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VILLAN_RENDEZVOUS_ONLY="1", VILLAN_DIST_BACKEND="gloo", HIP_VISIBLE_DEVICES="3,4,5", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("CUDA_VISIBLE_DEVICES", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "VillanDiffusion.py"), "--mode", "train", "--gpu", "2,0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"rendezvous_only": True, "world_size": 2, "ranks_counted": 2, "visible": "5,3"}
+    # one index: same process, device selected through the environment before torch starts
+    r1 = subprocess.run([sys.executable, os.path.join(root, "VillanDiffusion.py"), "--mode", "train", "--gpu", "1"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1]) == \
+        {"rendezvous_only": True, "world_size": 1, "ranks_counted": 1, "visible": "4"}

@@ -464,6 +464,61 @@ extern "C" int vd_postprocess(const float* x, float* out, int B, int C, int HW, 
     return 0;
 }
 
+// ---- SSIM of image pairs (measure glue: torchmetrics StructuralSimilarityIndexMeasure(data_range), VillanDiffusion.py:1001-1007) ----
+// One workgroup per image; a thread walks map positions (c, y, x), accumulates the five 11 x 11 gaussian-window sums with reflect indexing
+// (the window of a kept position lies inside the image whenever H, W > 2 * 5: the reflect-padded border is cropped from the map), evaluates the
+// SSIM expression and the workgroup averages its map in a fixed order.  win: the K x K window (outer product of the normalised 1-D gaussian).
+__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ win,
+                                                    float* __restrict__ out, int C, int H, int W, int K, float c1, float c2) {
+    __shared__ float wsh[32 * 32];
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < K * K; i += 256) wsh[i] = win[i];
+    __syncthreads();
+    const int p = (K - 1) / 2;
+    const bool crop = W > 2 * p && H > 2 * p;            // torchmetrics crops [p:-p] of both map dimensions when the map is larger than the border
+    const int y0 = crop ? p : 0, x0 = crop ? p : 0, mh = crop ? H - 2 * p : H, mw = crop ? W - 2 * p : W;
+    const int total = C * mh * mw;
+    const float* __restrict__ an = a + (int64_t)n * C * H * W;
+    const float* __restrict__ bn = b + (int64_t)n * C * H * W;
+    float acc = 0.f;
+    for (int i = tid; i < total; i += 256) {
+        const int c = i / (mh * mw), r = i - c * mh * mw, y = y0 + r / mw, x = x0 + r % mw;
+        const float* __restrict__ ac = an + (int64_t)c * H * W;
+        const float* __restrict__ bc = bn + (int64_t)c * H * W;
+        float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+        for (int dy = 0; dy < K; ++dy) {
+            int yy = y + dy - p;
+            yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+            for (int dx = 0; dx < K; ++dx) {
+                int xx = x + dx - p;
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+                const float w = wsh[dy * K + dx], va = ac[yy * W + xx], vb = bc[yy * W + xx];
+                sa += w * va;
+                sb += w * vb;
+                saa += w * (va * va);
+                sbb += w * (vb * vb);
+                sab += w * (va * vb);
+            }
+        }
+        const float va_ = saa - sa * sa, vb_ = sbb - sb * sb, cab = sab - sa * sb;
+        acc += ((2.f * sa * sb + c1) * (2.f * cab + c2)) / ((sa * sa + sb * sb + c1) * (va_ + vb_ + c2));
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) out[n] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)total;
+}
+
+extern "C" int vd_ssim(const float* a, const float* b, const float* win, float* out, int N, int C, int H, int W, int K, float c1, float c2,
+                       void* stream) {
+    VD_REQUIRE(a && b && win && out && N > 0 && C > 0 && H > 0 && W > 0 && K > 0 && K <= 32 && (K & 1) && H > (K - 1) / 2 && W > (K - 1) / 2,
+               "vd_ssim: bad args (odd window <= 32, image larger than the window radius)");
+    hipLaunchKernelGGL(ssim_kernel, dim3(N), dim3(256), 0, ST, a, b, win, out, C, H, W, K, c1, c2);
+    VD_LAUNCH_CHECK("vd_ssim");
+    return 0;
+}
+
 extern "C" int vd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
     VD_REQUIRE(out && n > 0, "vd_randn: bad args");
     hipLaunchKernelGGL(randn_kernel, dim3(egrid((n + 3) / 4)), dim3(EB), 0, ST, out, n, seed, offset);

@@ -573,6 +573,18 @@ class DatasetLoader:
             self._any_rto = bool((self._flags & 4).any())
             self._flip_gen = torch.Generator(device=self._dev).manual_seed(int(self._seed) + 7919) if self._dev.type == "cuda" else None
 
+    def loader_state(self) -> Dict:
+        """What a resumed run needs to draw the same random flips: the device flip generator's state (None before the first device batch)."""
+        g = getattr(self, "_flip_gen", None)
+        return {"flip_gen": None if g is None else g.get_state().cpu()}
+
+    def load_loader_state(self, st: Optional[Dict]):
+        if not st or st.get("flip_gen") is None or self._latent is not None:
+            return
+        self._ensure_device()
+        if self._flip_gen is not None:
+            self._flip_gen.set_state(st["flip_gen"].cpu())
+
     def _h2d(self, t: torch.Tensor) -> torch.Tensor:
         """Small per-batch host arrays (indices, flags) go up from PINNED memory without blocking: a pageable copy makes the host wait for
         everything already queued on the stream, i.e. one full drain per training step (measured: 0.5 ms of idle GPU at every step start)."""

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "vd_sched_step": (_i32, [_vp] * 5 + [_i64] + [_f32] * 7 + [C.c_uint64, C.c_uint64, _vp]),
     "vd_batch_l2norm": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "vd_postprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "vd_ssim": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
     "vd_randn": (_i32, [_vp, _i64, C.c_uint64, C.c_uint64, _vp]),
     "vd_fir_resample2": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "vd_fourier_embedding": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
@@ -139,7 +140,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 7:
+    if lib.vd_abi_version() != 8:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

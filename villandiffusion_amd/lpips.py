@@ -68,6 +68,8 @@ class LPIPS:
         return out
 
     def features(self, x):
+        if x.shape[1] == 1:               # the reference ScalingLayer broadcasts a 1-channel input (MNIST tasks) against its [1,3,1,1] shift / scale
+            x = x.expand(-1, 3, -1, -1).contiguous()
         x = ops.channel_affine(x, self.mul, self.add, torch.empty_like(x))
         t1 = self._conv(x, 0)
         t2 = self._conv(self._pool(t1), 1)

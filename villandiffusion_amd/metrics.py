@@ -1,7 +1,9 @@
 """Attack-success metrics of the reference's measure() (VillanDiffusion.py:951-1015, 1078-1091): MSE and SSIM of the
-backdoor samples against the backdoor target.  Host-side glue, not on the hot path.  SSIM restates torchmetrics'
-StructuralSimilarityIndexMeasure(data_range=1.0) defaults: 11x11 gaussian window (sigma 1.5), k1=0.01, k2=0.03, reflect
-padding with the padded border cropped, mean over the map per image.  FID needs InceptionV3 weights (no network)."""
+backdoor samples against the backdoor target.  SSIM restates torchmetrics' StructuralSimilarityIndexMeasure(data_range=1.0)
+defaults: 11x11 gaussian window (sigma 1.5), k1=0.01, k2=0.03, reflect padding with the padded border cropped, mean over the
+map per image.  With `device` (what measure() passes: the model's GPU) or CUDA inputs the map is one HIP kernel (`vd_ssim`), so the
+whole measure pipeline -- sampling, MSE/SSIM, FID (inception.py), LPIPS (lpips.py) -- runs on the HIP library; CPU tensors without
+a device take the torch expression below (host logic, what the CPU tests pin against oracle/metrics_ref.py)."""
 from __future__ import annotations
 
 import torch
@@ -22,7 +24,21 @@ def _gauss(k: int, sigma: float) -> torch.Tensor:
     return (g / g.sum())[None]
 
 
-def ssim_batch(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0, k: int = 11, sigma: float = 1.5) -> float:
+def ssim_batch(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0, k: int = 11, sigma: float = 1.5, device=None,
+               chunk: int = 4096) -> float:
+    dev = torch.device(device) if device is not None else (a.device if a.device.type == "cuda" else b.device)
+    if dev.type == "cuda":
+        from . import ops                 # raises when the HIP library is missing: no silent fallback on a GPU box
+        g1 = _gauss(k, sigma)
+        win = (g1.t() @ g1).contiguous().to(dev)
+        c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+        tot, n = 0.0, a.shape[0]
+        for s0 in range(0, n, chunk):     # `b` is often an expand()ed target: materialise one chunk at a time
+            ac = a[s0:s0 + chunk].to(dev).float().contiguous()
+            bc = b[s0:s0 + chunk].to(dev).float().contiguous()
+            out = torch.empty(ac.shape[0], device=dev, dtype=torch.float32)
+            tot += float(ops.ssim(ac, bc, win, out, c1, c2).double().sum())
+        return tot / n
     a, b = a.float().cpu(), b.float().cpu()
     C = a.shape[1]
     c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2

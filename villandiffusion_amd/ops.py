@@ -836,6 +836,14 @@ def batch_l2norm(x, out):
     return out
 
 
+def ssim(a, b, win, out, c1, c2):
+    """out[n] = mean SSIM map of (a[n], b[n]); win: [K, K] window (vd_ssim)."""
+    Bn, Cc, H, W = a.shape
+    assert a.is_contiguous() and b.is_contiguous() and win.is_contiguous() and a.shape == b.shape and win.shape[0] == win.shape[1]
+    L.check(_lib().vd_ssim(_p(a), _p(b), _p(win), _p(out), Bn, Cc, H, W, win.shape[0], c1, c2, _s()), "vd_ssim")
+    return out
+
+
 def postprocess(x, out, mul, add, lo, hi, to_nhwc):
     Bn, Cc, H, W = x.shape
     assert x.is_contiguous() and out.is_contiguous()

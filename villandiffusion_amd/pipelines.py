@@ -168,14 +168,17 @@ class DiffusionPipeline:
         return SimpleNamespace(images=images, movie=movie)
 
     @torch.no_grad()
-    def sample_concurrent(self, inits, num_inference_steps: Optional[int] = None, n_streams: int = 2, eta: Optional[float] = None):
+    def sample_concurrent(self, inits, num_inference_steps: Optional[int] = None, n_streams: int = 2, eta: Optional[float] = None,
+                          chunk_ids=None):
         """Throughput mode of the measure / sampling loops (reference VillanDiffusion.py:1062-1067 walks its chunks of `eval_max_batch` one after
         the other): the chunks of `inits` are denoised `n_streams` at a time, each on its own HIP stream with its own captured forward, its own
         split-K workspace and its own copy of the scheduler state, stepping in lock-step on the host.  A denoising step is ~250 kernels, a fifth
         of them grids that cannot fill the chip (the 8x8 / 4x4 stages, GroupNorm of small maps, the time-embedding linears) plus a dependency gap
         after every kernel: a second chunk's launches fill those holes.  Noise comes from the in-kernel Philox stream (`scheduler.device_rng_seed`
         must be set); chunk c owns the offset range starting at `chunk_rng_offset(c, ...)`, so a chunk's result does not depend on what runs beside
-        it: it is bit-identical to a sequential `__call__` started at the same offset.  Returns the list of final states (device tensors)."""
+        it: it is bit-identical to a sequential `__call__` started at the same offset (`sample_sequential` does exactly that).  `chunk_ids`:
+        GLOBAL index of every chunk in the caller's chunk list (rank-sharded measure jobs; default 0, 1, ...), so that two ranks never draw the
+        same noise and a chunk's images do not depend on the world size.  Returns the list of final states (device tensors)."""
         import copy
         unet, dev = self.unet, self.device
         n = num_inference_steps if num_inference_steps is not None else self.default_steps
@@ -189,16 +192,27 @@ class DiffusionPipeline:
         off0 = getattr(base, "_rng_offset", 0)
         main = torch.cuda.current_stream(dev)
         streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        if getattr(unet, "_packed", None) is not None:
+            # ONE rebuild of the packed split-precision weights, on `main`, before any chunk stream branches off it: GraphedForward.__call__
+            # refreshes on whichever stream is current and marks the version fresh, so a refresh left to chunk 0's stream would race with the
+            # replays of chunks 1.. on their own streams (they would skip it and read the buffer while it is being rewritten).
+            unet._packed.refresh(False)
+        numel = max(c.numel() for c in inits)
+        chunk_ids = list(range(len(inits))) if chunk_ids is None else [int(c) for c in chunk_ids]
         for first in range(0, len(inits), n_streams):
             group = list(range(first, min(first + n_streams, len(inits))))
             states = []
             for k, ci in enumerate(group):
                 sch = copy.deepcopy(base)
                 if hasattr(sch, "_rng_offset"):
-                    sch._rng_offset = off0 + self.chunk_rng_offset(ci, len(ts), max(c.numel() for c in inits))
-                x = inits[ci].to(dev).float().contiguous()
+                    sch._rng_offset = off0 + self.chunk_rng_offset(chunk_ids[ci], len(ts), numel)
                 streams[k].wait_stream(main)
                 with torch.cuda.stream(streams[k]), ops.ws_slot(k):
+                    # upload on the chunk's OWN stream: the block is then owned by the stream that reads it (a block allocated on `main` and
+                    # dropped below could be handed to the next chunk's host -> device copy while this stream still reads it)
+                    x = inits[ci].to(dev).float().contiguous()
+                    if x.data_ptr() == inits[ci].data_ptr():
+                        x.record_stream(streams[k])       # a caller-owned device tensor: keep its block alive for this stream's reads
                     if sigma_space:
                         x = ops.lincomb(torch.empty_like(x), [x], [float(sch.init_noise_sigma)])
                     fwd = sampler_forward(unet, x.shape[0], slot=k)
@@ -216,7 +230,27 @@ class DiffusionPipeline:
                 main.wait_stream(streams[k])
                 outs[ci] = states[k][1]
         if hasattr(base, "_rng_offset"):
-            base._rng_offset = off0 + self.chunk_rng_offset(len(inits), len(ts), max(c.numel() for c in inits))
+            base._rng_offset = off0 + self.chunk_rng_offset(max(chunk_ids) + 1, len(ts), numel)
+        return outs
+
+    @torch.no_grad()
+    def sample_sequential(self, inits, num_inference_steps: Optional[int] = None, eta: Optional[float] = None, chunk_ids=None):
+        """The chunks of `inits` one after the other with the SAME per-chunk Philox offsets as `sample_concurrent`: seeded stochastic samplers
+        then give identical images whatever VILLAN_SAMPLER_STREAMS / the world size is.  Returns the list of final states (device tensors)."""
+        base = self.scheduler
+        n = num_inference_steps if num_inference_steps is not None else self.default_steps
+        base.set_timesteps(n)
+        off0 = getattr(base, "_rng_offset", 0)
+        numel = max(c.numel() for c in inits)
+        outs = []
+        kw = {} if eta is None else {"eta": eta}
+        chunk_ids = list(range(len(inits))) if chunk_ids is None else [int(c) for c in chunk_ids]
+        for ci, c in enumerate(inits):
+            if hasattr(base, "_rng_offset"):
+                base._rng_offset = off0 + self.chunk_rng_offset(chunk_ids[ci], n, numel)
+            outs.append(self(batch_size=len(c), init=c, num_inference_steps=n, return_tensor=True, **kw))
+        if hasattr(base, "_rng_offset"):
+            base._rng_offset = off0 + self.chunk_rng_offset(max(chunk_ids) + 1, n, numel)
         return outs
 
     @staticmethod

@@ -51,6 +51,14 @@ def _concurrent_ok(pipeline, chunks, eta) -> bool:
     return seeded or not stochastic
 
 
+def _seeded_chunks(pipeline, chunks) -> bool:
+    """Explicit inits + in-kernel noise on a plain pipeline: the per-chunk Philox offsets of pipelines.chunk_rng_offset apply."""
+    from .pipelines import DiffusionPipeline
+    if not chunks or any(c is None for c, _ in chunks) or type(pipeline).__call__ is not DiffusionPipeline.__call__:
+        return False
+    return getattr(pipeline.scheduler, "device_rng_seed", None) is not None and hasattr(pipeline, "sample_sequential")
+
+
 def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], init: torch.Tensor = None, max_batch_n: int = 256,
                         rng: torch.Generator = None, num_inference_steps: Optional[int] = None, eta: Optional[float] = None,
                         rank: int = 0, world: int = 1):
@@ -59,15 +67,24 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
     cnt, mine = 0, []
     for k, (c, n) in enumerate(_chunks(sample_n, init, max_batch_n)):
         if k % world == rank:
-            mine.append((c, n, cnt))
+            mine.append((c, n, cnt, k))
         cnt += n
-    if _concurrent_ok(pipeline, [(c, n) for c, n, _ in mine], eta):
-        from .pipelines import _post
-        xs = pipeline.sample_concurrent([c for c, _, _ in mine], num_inference_steps=num_inference_steps, n_streams=sampler_streams(), eta=eta)
-        for (c, n, start), x in zip(mine, xs):
+    from .pipelines import _post
+    if _concurrent_ok(pipeline, [(c, n) for c, n, _, _ in mine], eta):
+        xs = pipeline.sample_concurrent([c for c, _, _, _ in mine], num_inference_steps=num_inference_steps, n_streams=sampler_streams(), eta=eta,
+                                        chunk_ids=[k for _, _, _, k in mine])
+        for (c, n, start, _), x in zip(mine, xs):
             save_imgs(_post(x), path, start_cnt=start)
         return None
-    for c, n, start in mine:
+    if _seeded_chunks(pipeline, [(c, n) for c, n, _, _ in mine]):
+        # in-kernel noise, one chunk at a time: the same per-chunk Philox ranges as the concurrent walk, so the images (and every score computed
+        # from them) do not depend on VILLAN_SAMPLER_STREAMS or on the number of ranks
+        xs = pipeline.sample_sequential([c for c, _, _, _ in mine], num_inference_steps=num_inference_steps, eta=eta,
+                                        chunk_ids=[k for _, _, _, k in mine])
+        for (c, n, start, _), x in zip(mine, xs):
+            save_imgs(_post(x), path, start_cnt=start)
+        return None
+    for c, n, start, _ in mine:
         kw = {} if eta is None else {"eta": eta}
         res = pipeline(batch_size=n, generator=rng, init=c, output_type=None, num_inference_steps=num_inference_steps, **kw)
         save_imgs(res.images, path, start_cnt=start)

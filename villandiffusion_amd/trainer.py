@@ -166,7 +166,7 @@ class GraphedMicroStep:
         if _DEBUG:
             torch.cuda.synchronize(net.device)
             print("[graph] replayed", flush=True)
-        return self.loss[0]
+        return self.loss[0].clone()       # the static buffer is overwritten by the next replay: callers keep losses across micro-steps
 
 
 class Trainer:
