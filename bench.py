@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="keep the weight gradients on the launch stream for the WHOLE run (profiling: every kernel's duration is then its own; "
                          "the default overlaps them with the backward pass on a side stream)")
+    ap.add_argument("--config", choices=("cifar10", "celebahq256", "ldm64"), default="cifar10",
+                    help="cifar10 (default, the driver's line): BASELINE config #2 + DDPM-1000 sampling.  celebahq256 / ldm64: SECONDARY lines for BASELINE "
+                         "configs #4 / #5 (DDPM-CELEBA-HQ-256 UNet at 3x256x256, LDM-CELEBA-HQ UNet on 3x64x64 latents; per-GPU batch 8 = 64 over 8 GPUs): "
+                         "training step + one denoising step, analytic FLOPs from the architecture, dominant kernel and its roofline fraction")
     ap.add_argument("--conv-math", choices=("bf16x3", "f32"), default=None,
                     help="arithmetic of the eligible 3x3 convolutions (default: the library default, bf16x3 split products)")
     return ap.parse_args()
@@ -162,6 +166,44 @@ def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=N
     return cpu, parity
 
 
+# ---- roofline: per-launch HIP-event timing (on the launch stream) of one extra training step and of one denoising step ----
+def is_split(kname):     # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
+    return "bx3" in kname or "attn_core" in kname or "k32" in kname or "wgrad9" in kname or "wgrad1x1_wide" in kname
+
+
+def peak_of(kname):
+    return PEAK_BF16_MFMA_TFLOPS if is_split(kname) else PEAK_F32_MFMA_TFLOPS
+
+
+def summarise(rec):
+    """Per kernel symbol: launches, summed event time, algorithmic TFLOP/s and GB/s, and the fraction of the BINDING roofline.  Which
+    resource binds is decided on what the hardware does: the matrix pipe's occupancy is the EXECUTED MFMA work (three instructions per
+    split-precision product term) over the dtype's dense peak, HBM's is algorithmic bytes over 8 TB/s; `frac` is then quoted on
+    ALGORITHMIC work against that resource's peak (frac_mfma = algorithmic TFLOP/s / peak, frac_hbm = GB/s / 8000)."""
+    agg = {}
+    for r_ in rec:
+        a = agg.setdefault(r_["name"], {"n": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "kind": r_["kind"]})
+        a["n"] += 1
+        a["flops"] += r_["flops"]
+        a["bytes"] += r_["bytes"]
+        a["ms"] += r_["e0"].elapsed_time(r_["e1"])
+    rows = []
+    for k, v in agg.items():
+        tf = v["flops"] / v["ms"] / 1e9 if v["ms"] > 0 else 0.0
+        gbs = v["bytes"] / v["ms"] / 1e6 if v["ms"] > 0 else 0.0
+        split = is_split(k)
+        f_mfma = tf / peak_of(k) if v["kind"] == "mfma" else 0.0
+        f_hbm = gbs / PEAK_HBM_GBS
+        rows.append({"kernel": k, "launches": v["n"], "ms": round(v["ms"], 3), "avg_us": round(1e3 * v["ms"] / v["n"], 1),
+                     "tflops": round(tf, 2), "gbs": round(gbs, 1), "gflop": round(v["flops"] / 1e9, 1), "mbytes": round(v["bytes"] / 1e6, 1),
+                     "frac_mfma": round(f_mfma, 4), "frac_mfma_executed": round((3 if split else 1) * f_mfma, 4), "frac_hbm": round(f_hbm, 4),
+                     "bound": "hbm" if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else "mfma",
+                     "frac": round(f_hbm if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else f_mfma, 4),
+                     "mfma_peak": peak_of(k) if v["kind"] == "mfma" else None})
+    return sorted(rows, key=lambda r: -r["ms"])
+
+
+
 def log(msg):
     if int(os.environ.get("RANK", 0)) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -185,10 +227,139 @@ def spawn_ranks(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+
+def bench_secondary_config(args):
+    """BASELINE configs #4 / #5 as secondary bench lines (never the driver's default): the fine-tune step of the 256x256 pixel UNet
+    (reference model.py:706-776 `DDPM-CELEBA-HQ-256`, run_celeba_hq_script.py) or of the latent UNet (`LDM-CELEBA-HQ-256`,
+    run_ldm_celeba_hq_script.py:10,68-70) at per-GPU batch 8 (global 64 over 8 GPUs), plus one no-grad denoising forward (UniPC-20 is 20 of
+    them).  FLOPs are computed from the architecture (villandiffusion_amd.flops)."""
+    from villandiffusion_amd import ops
+    from villandiffusion_amd.flops import unet_forward_flops
+    from villandiffusion_amd.loss import LossFn
+    from villandiffusion_amd.model import DDPM_256_ARCH, LDM_CELEBA_UNET_ARCH
+    from villandiffusion_amd.schedulers import DDPMScheduler
+    from villandiffusion_amd.trainer import Trainer
+    from villandiffusion_amd.unet import UNet2DModel
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        dist.init_process_group(os.environ.get("VD_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    B = 8 if args.batch == 128 else args.batch
+    if args.config == "celebahq256":
+        arch, S, sde, tag = dict(DDPM_256_ARCH), 256, "SDE-VP", "DDPM-CELEBA-HQ-256 UNet (113.7 M), 3x256x256, STOP_SIGN_14->CAT recipe"
+        sched = DDPMScheduler(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, clip_sample=False)
+    else:
+        arch, S, sde, tag = dict(LDM_CELEBA_UNET_ARCH), 64, "SDE-LDM", "LDM-CELEBA-HQ-256 UNet (274 M), 3x64x64 latents, GLASSES->CAT recipe"
+        sched = DDPMScheduler(num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear", clip_sample=False)
+    arch.pop("in_channels", None), arch.pop("out_channels", None), arch.pop("sample_size", None)
+    net = UNet2DModel(in_channels=3, out_channels=3, sample_size=S, **arch)
+    net.reset_parameters(seed=0)
+    if args.conv_math:
+        net.conv_math = args.conv_math
+    if args.serial_wgrad:
+        net.wgrad_stream = False
+    fwd_flop = unet_forward_flops(net)
+    n_par = sum(p.numel() for p in net.parameters())
+    lf = LossFn(sched, sde, psi=1, solver_type="sde")
+    lf.noise_seed = 1234 + rank
+    trainer = Trainer(net, lf, lr=6e-5, total_steps=10000, warmup_steps=500, grad_accum=1)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    x0 = torch.rand((B, 3, S, S), device=dev, generator=g) * 2 - 1
+    R = torch.zeros_like(x0)
+    R[: max(1, B // 8)] = torch.rand((max(1, B // 8), 3, S, S), device=dev, generator=g) * 2 - 1
+    tgen = torch.Generator(device=dev).manual_seed(100 + rank)
+
+    def one_step():
+        t = torch.randint(0, 1000, (B,), device=dev, generator=tgen)
+        return trainer.train_step({"target": x0, "pixel_values": R}, t)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(2, args.warmup)):
+        one_step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    ips = world * B * args.steps / dt
+    log(f"{args.config}: {ips:.2f} img/s ({1e3 * dt / args.steps:.2f} ms/step at per-GPU batch {B}), loss {float(loss):.4f}")
+    # one no-grad denoising forward (graph replay as the samplers run it)
+    from villandiffusion_amd.pipelines import sampler_forward
+    fwd_ms = None
+    with torch.no_grad():
+        fwd = sampler_forward(net, B)
+        tq = torch.full((B,), 500.0, device=dev)
+        for _ in range(2):
+            fwd(x0, tq)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fwd(x0, tq)
+        torch.cuda.synchronize()
+        fwd_ms = 1e3 * (time.perf_counter() - t0) / 5
+    from villandiffusion_amd.pipelines import drop_sampler_graphs
+    drop_sampler_graphs(net)
+    kernels = None
+    if not args.no_roofline:
+        ws0, net.wgrad_stream = net.wgrad_stream, False
+        for _ in range(2):
+            ops.profile_start()
+            one_step()
+            torch.cuda.synchronize()
+            rec = ops.profile_stop()
+        net.wgrad_stream = ws0
+        kernels = summarise(rec)
+    if rank == 0:
+        split = net.conv_math == "bf16x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        ms = 1e3 * dt / args.steps
+        out = {"metric": "train imgs/sec (secondary line: BASELINE config #%d)" % (4 if args.config == "celebahq256" else 5),
+               "value": round(ips, 3), "unit": "train images/s", "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup),
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16x3/f32" if split else "f32", "data": "synthetic",
+               "config": {"workload": f"{tag}; fine-tune step at per-GPU batch {B} ({sde}, Adam + clip 1.0)", "global_batch": B * world,
+                          "image": f"3x{S}x{S}", "parallelism": f"dp{world}", "parameters": n_par},
+               "forward_gflop_per_image": round(fwd_flop / 1e9, 2), "train_gflop_per_image": round(3 * fwd_flop / 1e9, 2),
+               "train_tflops": round(ips * 3 * fwd_flop / 1e12, 2), f"train_frac_of_{'bf16' if split else 'f32'}_peak": round(ips * 3 * fwd_flop / 1e12 / (peak * world), 4),
+               "denoise_forward_ms": None if fwd_ms is None else round(fwd_ms, 3),
+               "denoise_forward_tflops": None if fwd_ms is None else round(B * fwd_flop / fwd_ms / 1e9, 2),
+               "final_loss": round(float(loss), 5)}
+        if kernels:
+            mf = [k for k in kernels if k["mfma_peak"]]
+            k0 = mf[0]
+            sp = is_split(k0["kernel"])
+            out["roofline"] = {"bound": k0["bound"], "kernel": k0["kernel"], "achieved": k0["tflops"] if k0["bound"] == "mfma" else k0["gbs"],
+                               "peak": k0["mfma_peak"] if k0["bound"] == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if k0["bound"] == "mfma" else "GB/s",
+                               "frac": k0["frac"], "frac_executed": k0["frac_mfma_executed"], "executed_tflops": round((3 if sp else 1) * k0["tflops"], 2),
+                               "traffic": None, "launches_per_step": k0["launches"], "avg_launch_us": k0["avg_us"], "ms_per_step": k0["ms"],
+                               "algorithmic_gflop_per_launch": round(k0["gflop"] / k0["launches"], 2)}
+            out["top_kernels"] = [{"kernel": k["kernel"], "launches": k["launches"], "ms": k["ms"], "tflops": k["tflops"], "bound": k["bound"], "frac": k["frac"]}
+                                  for k in kernels[:10]]
+            out["profiled_kernels_ms"] = round(sum(k["ms"] for k in kernels), 2)
+            for k in kernels[:14]:
+                log(f"{k['ms']:8.3f} ms {k['launches']:4d}x {k['avg_us']:8.1f} us  {k['tflops']:7.1f} TF {k['bound']:4s} frac {k['frac']:.3f}  {k['kernel']}")
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)
+    if args.config != "cifar10":
+        return bench_secondary_config(args)
     if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', 1)}: launch with "
                  f"`python bench.py --gpus N` or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
@@ -419,40 +590,6 @@ def main():
                 dist.all_reduce(tsec, op=dist.ReduceOp.MAX)
             secondary[tag] = round(world * len(c0) / float(tsec), 2)
         log(f"secondary samplers (img/s): {secondary}")
-
-    # ---- roofline: per-launch HIP-event timing (on the launch stream) of one extra training step and of one denoising step ----
-    def is_split(kname):     # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
-        return "bx3" in kname or "attn_core" in kname or "k32" in kname or "wgrad9" in kname or "wgrad1x1_wide" in kname
-
-    def peak_of(kname):
-        return PEAK_BF16_MFMA_TFLOPS if is_split(kname) else PEAK_F32_MFMA_TFLOPS
-
-    def summarise(rec):
-        """Per kernel symbol: launches, summed event time, algorithmic TFLOP/s and GB/s, and the fraction of the BINDING roofline.  Which
-        resource binds is decided on what the hardware does: the matrix pipe's occupancy is the EXECUTED MFMA work (three instructions per
-        split-precision product term) over the dtype's dense peak, HBM's is algorithmic bytes over 8 TB/s; `frac` is then quoted on
-        ALGORITHMIC work against that resource's peak (frac_mfma = algorithmic TFLOP/s / peak, frac_hbm = GB/s / 8000)."""
-        agg = {}
-        for r_ in rec:
-            a = agg.setdefault(r_["name"], {"n": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "kind": r_["kind"]})
-            a["n"] += 1
-            a["flops"] += r_["flops"]
-            a["bytes"] += r_["bytes"]
-            a["ms"] += r_["e0"].elapsed_time(r_["e1"])
-        rows = []
-        for k, v in agg.items():
-            tf = v["flops"] / v["ms"] / 1e9 if v["ms"] > 0 else 0.0
-            gbs = v["bytes"] / v["ms"] / 1e6 if v["ms"] > 0 else 0.0
-            split = is_split(k)
-            f_mfma = tf / peak_of(k) if v["kind"] == "mfma" else 0.0
-            f_hbm = gbs / PEAK_HBM_GBS
-            rows.append({"kernel": k, "launches": v["n"], "ms": round(v["ms"], 3), "avg_us": round(1e3 * v["ms"] / v["n"], 1),
-                         "tflops": round(tf, 2), "gbs": round(gbs, 1), "gflop": round(v["flops"] / 1e9, 1), "mbytes": round(v["bytes"] / 1e6, 1),
-                         "frac_mfma": round(f_mfma, 4), "frac_mfma_executed": round((3 if split else 1) * f_mfma, 4), "frac_hbm": round(f_hbm, 4),
-                         "bound": "hbm" if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else "mfma",
-                         "frac": round(f_hbm if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else f_mfma, 4),
-                         "mfma_peak": peak_of(k) if v["kind"] == "mfma" else None})
-        return sorted(rows, key=lambda r: -r["ms"])
 
     roofline, kernels, sample_kernels = None, None, None
     if not args.no_roofline and do_train:

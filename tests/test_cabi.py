@@ -87,9 +87,9 @@ def test_split_precision_planner_agrees_with_the_python_side_eligibility():
                     d.lda, d.b_bstride, d.ldd, d.d_bstride, d.alpha = Cc * 9, Cc * H * H, OH * OW, M * OH * OW, 1.0
                     want = ops.bx3_eligible(M, Cc, OH, OW, mode)
                     got = h.vd_gemm_tile(C.byref(d))
-                    assert (got in (8, 12, 15, 16, 17)) == want and got in (8, 12, 15, 16, 17, -1), (mode, OW, M, Cc, nb, got, want)      # 17: the 16x16x32-MFMA kernel
+                    assert (got in (8, 12, 15, 16, 17, 18)) == want and got in (8, 12, 15, 16, 17, 18, -1), (mode, OW, M, Cc, nb, got, want)      # 17 / 18: the 16x16x32-MFMA kernels
                     if mode == B_CONV3_T and ops.bx3_pool2_eligible(M, Cc, OH, OW, nb):      # pool2 needs the unsplit grid
-                        assert got in (8, 12, 15, 17) and h.vd_gemm_ws_floats(C.byref(d)) == 0, (OW, M, Cc, nb)
+                        assert got in (8, 12, 15, 17, 18) and h.vd_gemm_ws_floats(C.byref(d)) == 0, (OW, M, Cc, nb)
                     if mode in (B_CONV3, B_CONV3_UP):
                         w = WgradDesc()
                         w.dY, w.X, w.dW = FAKE, FAKE, FAKE
@@ -107,7 +107,7 @@ def test_split_precision_planner_agrees_with_the_python_side_eligibility():
             d.M, d.N, d.K, d.NP, d.a_mode, d.b_mode = 128, 2 * OH * OW, 64 * 9, OH * OW, A_ROW, mode
             d.C, d.H, d.W, d.OH, d.OW = 64, OH, OW, OH, OW
             d.lda, d.b_bstride, d.ldd, d.d_bstride, d.alpha = 64 * 9, 64 * OH * OW, OH * OW, 128 * OH * OW, 1.0
-            assert (h.vd_gemm_tile(C.byref(d)) in (8, 12, 15, 16, 17)) == ops.bx3_eligible(128, 64, OH, OW, mode), (OH, OW, mode)
+            assert (h.vd_gemm_tile(C.byref(d)) in (8, 12, 15, 16, 17, 18)) == ops.bx3_eligible(128, 64, OH, OW, mode), (OH, OW, mode)
         w = WgradDesc()
         w.dY, w.X, w.dW = FAKE, FAKE, FAKE
         w.M, w.C, w.T, w.nb, w.NP, w.H, w.W, w.OH, w.OW, w.mode, w.math = 128, 64, 9, 2, OH * OW, OH, OW, OH, OW, B_CONV3, 1

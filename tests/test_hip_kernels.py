@@ -986,16 +986,16 @@ def test_tile_choice_does_not_change_a_single_bit():
     """The 128x128, 128x256 and 128x512 tiles of the 32x32x16-MFMA kernel (and its split 128x256 tiles at 8x8) only regroup output elements over
     workgroups: every element is still accumulated chunk by chunk, tap by tap, in the same MFMA order, so the results are bit-identical whichever
     tile the planner picks (the planner is steered through its environment switches, which are read once per process: one subprocess per setting).
-    The 16x16x32-MFMA kernel (vd_conv_k32.inc, the default where it applies) contracts 32 channels per instruction -- another summation grouping,
+    The 16x16x32-MFMA kernels (vd_conv_k32.inc, and round 4's persistent vd_conv_k32p.hip, the default where it applies) contract 32 channels per instruction -- another summation grouping,
     so other bits, held to the same bounds against torch by the parity tests above; what is asserted for it here is run-to-run determinism."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hashes = {}
-    off = {"VD_BX3_K32_OFF": "1"}
+    off = {"VD_BX3_K32_OFF": "1", "VD_K32P_OFF": "1"}
     for name, env in (("default", off), ("small", dict(off, VD_BX3_BIG_OFF="1", VD_BX3_BIGSPLIT_OFF="1")), ("no128x512", dict(off, VD_BX3_HUGE_OFF="1")),
-                      ("k32", {}), ("k32_again", {})):
+                      ("k32", {"VD_K32P_OFF": "1"}), ("k32_again", {"VD_K32P_OFF": "1"}), ("k32p", {}), ("k32p_again", {})):
         e = dict(os.environ, PYTHONPATH=root, **env)
         r = subprocess.run([sys.executable, "-c", _TILE_PROBE], capture_output=True, text=True, env=e, cwd=root, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -1003,6 +1003,9 @@ def test_tile_choice_does_not_change_a_single_bit():
     print("[parity] output hashes per tile setting:", hashes)
     assert hashes["default"] == hashes["small"] == hashes["no128x512"]
     assert hashes["k32"] == hashes["k32_again"]
+    # round 4: the persistent walk (vd_conv_k32p.hip: LDS-DMA weight stages, hand-pipelined fragment reads) keeps the 16x16x32 kernel's MFMA
+    # order per output element (chunk pair by chunk pair, tap by tap): the same bits as round 3's kernel
+    assert hashes["k32p"] == hashes["k32"] == hashes["k32p_again"]
 
 
 _WK32_PROBE = r"""
@@ -1051,3 +1054,76 @@ def test_opt_in_16x16x32_weight_gradient_kernel_stays_correct():
     worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WK32")][0].split()[1])
     print(f"[parity] opt-in k32 weight gradient: worst rel_err {worst:.2e}")
     assert worst < BX3_TOL
+
+
+_K32P_PROBE = r"""
+import math, sys, torch
+import torch.nn.functional as F
+from villandiffusion_amd import ops
+from villandiffusion_amd.lib import B_CONV3, B_CONV3_T, B_CONV3_UP
+worst = 0.0
+def rel(a, b):
+    return float((a.double().cpu() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+# (B, Cin, Cout, H, W, mode): 256-pixel tiles = 8 rows x 32 columns anywhere in the image (64 .. 256 wide, non-square, ragged channel tiles)
+for (B, Cin, Cout, H, W, mode) in [(16, 64, 128, 64, 64, B_CONV3), (4, 64, 96, 128, 128, B_CONV3), (1, 32, 200, 256, 256, B_CONV3), (24, 64, 128, 40, 64, B_CONV3),
+                                   (4, 64, 128, 64, 64, B_CONV3_UP), (2, 64, 64, 64, 128, B_CONV3_UP), (64, 128, 128, 32, 32, B_CONV3)]:
+    g = torch.Generator().manual_seed(B * 7 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    b = torch.randn(Cout, generator=g)
+    temb = torch.randn(B, Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if mode == B_CONV3_UP else x
+    y0 = F.conv2d(xin, w, b, padding=1)
+    res = torch.randn(y0.shape, generator=g)
+    y_ref = (y0 + temb[:, :, None, None] + res).detach()
+    OH, OW = y0.shape[-2:]
+    wd = w.cuda().view(Cout, -1)
+    pk = ops.conv3_pack_weights(wd, Cout, Cin)
+    xd = x.detach().cuda()
+    out = torch.empty(B, Cout, OH, OW, device="cuda")
+    part = torch.zeros(B, OH * OW // 256, Cout, 2, device="cuda")
+    ops.conv3x3(xd, wd, b.cuda(), out, mode=mode, rowadd=temb.cuda(), rowadd_bstride=Cout, residual=res.cuda(), a_packed=pk, gn_part=part)
+    assert ops.LAST_GEMM_TILE == 18, (ops.LAST_GEMM_TILE, B, Cin, Cout, H, W, mode)
+    worst = max(worst, rel(out, y_ref))
+    assert ops.GN_PART_WRITTEN                                  # per-tile channel sums of the FINAL result, fixed order
+    s1 = part[..., 0].sum(1).cpu().double()
+    worst = max(worst, float((s1 - y_ref.double().sum((2, 3))).abs().max() / y_ref.double().abs().sum((2, 3)).max()))
+    s2 = part[..., 1].sum(1).cpu().double()
+    worst = max(worst, float((s2 - (y_ref.double() ** 2).sum((2, 3))).abs().max() / (y_ref.double() ** 2).sum((2, 3)).max()))
+    if mode == B_CONV3 and Cout % 32 == 0:
+        dy = torch.randn(y0.shape, generator=g)
+        y0.backward(dy)
+        pkt = ops.conv3_pack_weights(wd, Cin, Cout, transposed=True)
+        wt = torch.empty(Cin, Cout * 9, device="cuda")
+        dx = torch.full((B, Cin, H, W), 3.0, device="cuda")
+        ops.conv3x3(dy.cuda(), wt, None, dx, mode=B_CONV3_T, a_packed=pkt, accumulate=True)      # dx += ... (skip-gradient form)
+        if ops.LAST_GEMM_TILE == 18:
+            worst = max(worst, rel(dx - 3.0, x.grad))
+    if mode == B_CONV3_UP and Cout % 32 == 0:                     # the upsample convolution's input gradient with the 2x2 sums in the epilogue
+        dy = torch.randn(y0.shape, generator=g)
+        y0.backward(dy)
+        pkt = ops.conv3_pack_weights(wd, Cin, Cout, transposed=True)
+        wt = torch.empty(Cin, Cout * 9, device="cuda")
+        dxb = torch.full((B, Cin + 2, H, W), 7.0, device="cuda")
+        ops.conv3x3(dy.cuda(), wt, None, dxb[:, 1:1 + Cin], mode=B_CONV3_T, a_packed=pkt, pool2=True)
+        assert ops.LAST_GEMM_TILE == 18
+        worst = max(worst, rel(dxb[:, 1:1 + Cin], x.grad))
+        assert float((dxb[:, 0] - 7).abs().max()) == 0 and float((dxb[:, -1] - 7).abs().max()) == 0
+print("K32P %.3e" % worst)
+"""
+
+
+def test_persistent_16x16x32_convolution_on_wide_and_non_square_images():
+    """vd_conv_k32p.hip (round 4): the persistent tile walk of the 16x16x32 split-precision convolution on 64 .. 256-pixel-wide and non-square
+    images (BASELINE configs #4 / #5: reference model.py:706-776), full epilogue (bias, time-embedding row, residual, accumulate, GroupNorm
+    partial sums, the 2x2 sums of the upsample gradient) against torch's f32 convolution."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _K32P_PROBE], capture_output=True, text=True, env=e, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("K32P")][0].split()[1])
+    print(f"[parity] persistent k32 convolution: worst rel_err {worst:.2e}")
+    assert worst <= BX3_TOL

@@ -175,14 +175,16 @@ def test_cli_train_and_sampling_end_to_end(tmp_path):
         assert os.path.exists(os.path.join(run, f)), f                 # grids carry the 0-based epoch index + 'final' (reference :1177-1195)
     assert not os.path.exists(os.path.join(run, "samples", "0001.png"))
     assert json.load(open(os.path.join(run, "config.json")))["gradient_accumulation_steps"] == 2
-    assert torch.load(os.path.join(run, "data.ckpt")) == {"epoch": 0, "step": 4}
+    dck = torch.load(os.path.join(run, "data.ckpt"))
+    assert (dck["epoch"], dck["step"]) == (0, 4) and dck["loader"]["flip_gen"] is not None      # + the device flip generator's state (resume)
     # --mode resume with --result that is not the cwd: the model comes from the run directory setup() resolved; the loop restarts AT
     # the recorded epoch index like the reference (:457-461 + range(start_epoch, epoch))
     os.remove(os.path.join(run, "samples", "final.png"))
     argv_r = ["--mode", "resume", "--ckpt", os.path.basename(run), "--result", res]
     out = subprocess.run([sys.executable, "-c", code % (argv_r,)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert torch.load(os.path.join(run, "data.ckpt")) == {"epoch": 0, "step": 8} and os.path.exists(os.path.join(run, "samples", "final.png"))
+    dck = torch.load(os.path.join(run, "data.ckpt"))
+    assert (dck["epoch"], dck["step"]) == (0, 8) and os.path.exists(os.path.join(run, "samples", "final.png"))
     assert torch.load(os.path.join(run, "ckpt", "trainer.pt"), map_location="cpu")["optimizer"]["step"] == 4      # 2 + 2 sync steps at G = 2
     argv2 = ["--mode", "sampling", "--ckpt", run, "--sched", "DPM_SOLVER_PP_O2-SCHED", "--infer_steps", "5"]
     out = subprocess.run([sys.executable, "-c", code % (argv2,)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

@@ -57,10 +57,12 @@ if "attn" in what:
                         ("bwd", lambda: ops.attn_core_bwd(qkv, P, o, do, dS, dqkv, heads, d, N, sc))):
             ms = timeit(fn, n=30)
             print(f"attn_core heads={heads} d={d:3d} {tag:11s}: {ms * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF")
-if "conv3" in what:
+if "conv3" in what or "conv3w" in what:
     from villandiffusion_amd.lib import B_CONV3, B_CONV3_T
     # (cin, cout, H): the 3x3 convolutions of the ResNet blocks (forward, and the flipped-tap input gradient with the roles of cin / cout swapped)
-    for cin, cout, H in [(128, 3, 32), (3, 128, 32), (128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (256, 256, 8), (512, 256, 8),
+    if "conv3w" in what:       # BASELINE configs #4 / #5 at per-GPU batch 8: the wide levels
+        B = 8
+    for cin, cout, H in [(128, 128, 256), (128, 128, 128), (256, 128, 128), (256, 256, 64), (512, 256, 64), (224, 224, 64), (448, 224, 64), (448, 448, 32)] if "conv3w" in what else [(128, 3, 32), (3, 128, 32), (128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (256, 256, 8), (512, 256, 8),
                          (256, 256, 4), (512, 256, 4)]:
         x = torch.randn(B, cin, H, H, device="cuda")
         w = torch.randn(cout, cin * 9, device="cuda") / math.sqrt(cin * 9)

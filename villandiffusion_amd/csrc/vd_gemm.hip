@@ -16,6 +16,10 @@
 #include <string.h>
 #include <stdlib.h>
 
+// vd_conv_k32p.hip: the persistent 16x16x32 split-precision 3x3 convolution (its own translation unit)
+bool vd_conv3_k32p_eligible(const vd_gemm_desc& d);
+int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st);
+
 namespace {
 
 constexpr int NT = 256;  // threads per workgroup
@@ -2092,6 +2096,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             bx3_plan(d, splits, c_per);
             static const int big_off = getenv("VD_BX3_BIG_OFF") ? atoi(getenv("VD_BX3_BIG_OFF")) : 0;
             if (bx3_big_split(d)) return 16;                           // 16: 8x8 layers, 128 x 256 tiles with the channel loop split
+            if (k32p_pick(d)) return 18;                               // 18: conv3_k32p_kernel (persistent 16x16x32 kernel, any image of 8 x 32 segments)
             const int big = (big_off || d.b_mode == VD_B_CONV3_S2) ? 0 : bx3_big_tile(d, splits);
             static const int keep_huge = getenv("VD_BX3_K32_KEEP_HUGE") ? atoi(getenv("VD_BX3_K32_KEEP_HUGE")) : 0;
             static const int k32_up32 = getenv("VD_BX3_K32_UP32") ? atoi(getenv("VD_BX3_K32_UP32")) : 0;
@@ -2148,10 +2153,11 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(tile != -1, "vd_gemm: a_packed (split-precision bf16) needs a 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, "
                            "C %% 16 == 0, M >= 64, or a VD_B_PLAIN product with shared A, NP %% 128 == 0, K %% 16 == 0, M >= 64; "
                            "a_packed_mpad = M rounded up to 128; math = 1 needs per-batch A, PLAIN / KCONTIG B, NP %% 128 == 0, K %% 16 == 0, K >= 32, M >= 64");
-    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15 || tile == 17,
+    VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15 || tile == 17 || tile == 18,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
-    VD_REQUIRE(!d.pool2 || tile == 8 || tile == 12 || tile == 17, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
-    VD_REQUIRE(!d.gn_part || (tile == 17 && !d.pool2), "vd_gemm: gn_part is written by the 16x16x32 split-precision 3x3 kernel only (vd_gemm_tile() == 17)");
+    VD_REQUIRE(!d.pool2 || tile == 8 || tile == 12 || tile == 17 || tile == 18, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
+    VD_REQUIRE(!d.gn_part || ((tile == 17 || tile == 18) && !d.pool2),
+               "vd_gemm: gn_part is written by the 16x16x32 split-precision 3x3 kernels only (vd_gemm_tile() == 17 / 18)");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (tile) {
@@ -2161,7 +2167,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 4:
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
-        case 8: case 12: case 15: case 16: case 17: rc = launch_bx3(d, st); break;
+        case 8: case 12: case 15: case 16: case 17: case 18: rc = launch_bx3(d, st); break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 13:
             hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d);
