@@ -144,6 +144,35 @@ def test_fused_groupnorm_backward_side_passes_equal_the_separate_launches(pair):
     assert 0 < float(grads[True].abs().max()) and e < 2e-6, e
 
 
+@pytest.mark.parametrize("B,stream", [(4, True), (4, False), (64, True)])
+def test_training_forward_with_folded_groupnorm_is_bit_identical(B, stream):
+    """Round 4: the training forward folds GroupNorm + SiLU into the 16x16 / 32x32 convolutions' loaders (a statistics pass instead of the
+    normalise pass on the critical path) and the backward recomputes silu(gn(.)) for the weight gradients on their side stream
+    (UNet2DModel.defer_gn_fwd).  Same expressions on the same numbers: output, loss gradient and EVERY parameter gradient are bit-identical to
+    the normalise-pass forward, on small (128 x 128 tiles, split grids) and on full-size batches, with and without the side stream."""
+    torch.manual_seed(3)
+    net = UNet2DModel()
+    net.reset_parameters(seed=5)
+    net.wgrad_stream = stream
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(2)).cuda()
+    dy = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    res = {}
+    for defer in (False, True, False, True):
+        net.defer_gn_fwd = defer
+        net.zero_grad()
+        y = net(x, t, return_dict=False)[0]
+        y.backward(dy)
+        torch.cuda.synchronize()
+        cur = (y.detach().clone(), net.flat_grad.detach().clone())
+        if defer in res:
+            assert torch.equal(res[defer][0], cur[0]) and torch.equal(res[defer][1], cur[1])        # run-to-run determinism of each path
+        res[defer] = cur
+    assert torch.equal(res[True][0], res[False][0]), float((res[True][0] - res[False][0]).abs().max())
+    assert torch.equal(res[True][1], res[False][1]), float((res[True][1] - res[False][1]).abs().max())
+    assert float(res[True][1].abs().max()) > 0
+
+
 def test_gradient_buckets_are_final_when_their_hook_fires(pair):
     """The trainer overlaps the all-reduce of bucket i with the rest of backward: at hook(i) the bucket must already hold
     its final value."""

@@ -219,15 +219,30 @@ class _Norm:
                           net.eps, self.silu)
         return mean, rstd
 
-    def stats(self, x):
-        """Statistics-only pass for the inference path: [B, C, 2] scale / shift pairs consumed by _Conv.fwd(gn_ss=...)."""
+    def stats(self, x, full=False):
+        """Statistics-only pass: [B, C, 2] scale / shift pairs consumed by _Conv.fwd(gn_ss=...) (inference path; round 4: the training forward
+        too).  full: also the (mean, rstd) the backward pass needs."""
         net = self.net
         B = x.shape[0]
         ss = torch.empty((B, self.ch, 2), device=x.device, dtype=torch.float32)
         mean = torch.empty(B * self.groups, device=x.device, dtype=torch.float32)
-        ops.groupnorm_stats(x, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], ss, mean, torch.empty_like(mean),
-                            self.groups, net.eps)
-        return ss
+        rstd = torch.empty_like(mean)
+        ops.groupnorm_stats(x, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], ss, mean, rstd, self.groups, net.eps)
+        return (ss, mean, rstd) if full else ss
+
+    def fwd_later(self, x):
+        """silu(gn(x)) for a weight gradient of the backward pass, computed on the weight-gradient side stream right before the grouped launch
+        that reads it (UNet2DModel.gn_later): the training forward folds the normalisation into the convolution's loader, so this tensor is
+        needed by nobody else and never sits on the critical path."""
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        self.net.gn_later(self, x, y)
+        return y
+
+    def _fwd_now(self, x, y):
+        B = x.shape[0]
+        mean = torch.empty(B * self.groups, device=x.device, dtype=torch.float32)
+        ops.groupnorm_fwd(x, self.net.P[self.prefix + ".weight"], self.net.P[self.prefix + ".bias"], y, mean, torch.empty_like(mean),
+                          self.groups, self.net.eps, self.silu)
 
     def stats_from_partials(self, part, tiles, B, HW):
         """stats() of a tensor whose producing convolution left its per-tile channel sums in `part` (vd_gemm_desc.gn_part)."""
@@ -294,6 +309,25 @@ class _Resnet:
             else:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
             return None
+        if save and net.defer_gn_fwd and fuse and net.conv_math == "bf16x3" and ops.gn_fusable(x, self.cout) \
+                and self.cin % 32 == 0 and self.cout % 32 == 0 and self.cin * H * W // net.groups <= 12288 \
+                and self.cout * H * W // net.groups <= 12288:
+            # training forward (round 4): GroupNorm + SiLU folded into the convolutions' loaders as in the no-grad path -- a statistics pass (one
+            # read) instead of the normalise pass (read + write) on the critical path; bit-identical activations (the folded loader evaluates the
+            # same expression on the same scale / shift pairs).  silu(gn(.)) itself is only an operand of the WEIGHT gradients: it is recomputed
+            # on their side stream in the backward pass (_Norm.fwd_later), where the HBM-bound pass runs beside MFMA-bound kernels.
+            ss1, m1, r1 = self.norm1.stats(x, full=True)
+            h1 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
+            self.conv1.fwd(x, h1, rowadd=st.temb_all[:, self.temb_off:], rowadd_bstride=st.temb_all.stride(0), gn_ss=ss1)
+            ss2, m2, r2 = self.norm2.stats(h1, full=True)
+            if self.has_sc:
+                ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
+                            net.P[self.prefix + ".conv_shortcut.bias"], out,
+                            a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W, B))
+                self.conv2.fwd(h1, out, residual=out, gn_ss=ss2)
+            else:
+                self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
+            return (x, None, m1, r1, h1, None, m2, r2)
         a1 = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
         m1, r1 = self.norm1.fwd(x, a1)
         h1 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
@@ -318,6 +352,9 @@ class _Resnet:
         x, a1, m1, r1, h1, a2, m2, r2 = saved
         B, _, H, W = x.shape
         dev = x.device
+        if a2 is None:                                        # folded-GroupNorm forward: the weight gradients' operands are made on their side stream
+            a2 = self.norm2.fwd_later(h1)
+            a1 = self.norm1.fwd_later(x)
         # conv2 (+ shortcut bias: both biases receive rowsum(dout))
         if dout_rs is None:
             bias_ws = net.scratch_bc(B, self.cout).view(B, self.cout)
@@ -713,6 +750,13 @@ class UNet2DModel(nn.Module):
         # no-grad forward: the statistics of a ResnetBlock2D's second GroupNorm are summed in the first convolution's epilogue
         # (vd_gemm_desc.gn_part) instead of a read of its output; False: the statistics pass
         self.gn_stats_in_epilogue = os.environ.get("VILLAN_GN_STATS_IN_EPILOGUE", "1") != "0"
+        # opt-in (round 4, measured and NOT the default): training forward with GroupNorm + SiLU folded into the 16x16 / 32x32 convolutions'
+        # loaders; silu(gn(.)) for the weight gradients is recomputed on the side stream in the backward pass.  Bit-identical results, 1.7 GB
+        # less saved activations at B = 128, but 18.07 -> 18.44 ms per step (profiles/r04_gn_defer_ab.txt): the statistics pass plus the
+        # recomputation move MORE bytes than the normalise pass they replace, and on a power-bound chip an HBM-bound pass running beside the
+        # MFMA-bound kernels is not free (the clock drops for both)
+        self.defer_gn_fwd = os.environ.get("VILLAN_DEFER_GN_FWD", "0") != "0"
+        self._gn_jobs = []
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
@@ -826,7 +870,18 @@ class UNet2DModel(nn.Module):
                 if self.wgrad_stream and self.wgrad_flush_jobs and sum(len(v) for v in self._wg_jobs.values()) >= self.wgrad_flush_jobs:
                     self._wg_flush()
                 return
+        if self._gn_jobs:                                     # an ungrouped weight gradient runs NOW: its operand may be a deferred silu(gn(.))
+            for norm, xx, yy in self._gn_jobs:
+                norm._fwd_now(xx, yy)
+            self._gn_jobs = []
         ops.conv_wgrad(dy, x, dw2d, mode, self.wgrad_ws, accumulate=True, pad=pad, math_mode=math_mode)
+
+    def gn_later(self, norm, x, y):
+        """y = norm(x) (+SiLU) before the next grouped weight-gradient launch, on its stream (see _Norm.fwd_later)."""
+        if self.wgrad_stream and self.group_wgrad:
+            self._gn_jobs.append((norm, x, y))
+        else:
+            norm._fwd_now(x, y)
 
     def rowsum(self, x, ws, ws_ld=None):
         """Bias-gradient partials ws[b][m] = sum_p x[b][m][p]: consumed only when the bucket is flushed, so with the side stream they
@@ -837,7 +892,7 @@ class UNet2DModel(nn.Module):
             ops.rowsum(x, ws, ws_ld=ws_ld)
 
     def _wg_flush(self):
-        if not any(self._wg_jobs.values()) and not self._rs_jobs:
+        if not any(self._wg_jobs.values()) and not self._rs_jobs and not self._gn_jobs:
             return
         if self.wgrad_stream:
             # Weight gradients are off the critical path of the backward pass: run the grouped launches on a SIDE stream so that they
@@ -849,14 +904,19 @@ class UNet2DModel(nn.Module):
             main = torch.cuda.current_stream(self._dev)
             self._wg_side.wait_stream(main)
             with torch.cuda.stream(self._wg_side):
+                for norm, x, y in self._gn_jobs:               # operands of the queued weight gradients (folded-GroupNorm forward)
+                    norm._fwd_now(x, y)
                 for x, ws, ld in self._rs_jobs:
                     ops.rowsum(x, ws, ws_ld=ld)
                 for cls, jobs in self._wg_jobs.items():
                     if jobs:
                         ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
-            self._wg_keep.append((self._wg_jobs, self._rs_jobs))
-            self._rs_jobs = []
+            self._wg_keep.append((self._wg_jobs, self._rs_jobs, self._gn_jobs))
+            self._rs_jobs, self._gn_jobs = [], []
         else:
+            for norm, x, y in self._gn_jobs:
+                norm._fwd_now(x, y)
+            self._gn_jobs = []
             for cls, jobs in self._wg_jobs.items():
                 if jobs:
                     ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
@@ -907,7 +967,7 @@ class UNet2DModel(nn.Module):
         # a backward pass that raised midway leaves queued weight-gradient / row-sum jobs behind: they must never run in THIS pass
         if self._wg_keep:
             self._wg_join()
-        self._wg_jobs, self._rs_jobs = {}, []
+        self._wg_jobs, self._rs_jobs, self._gn_jobs = {}, [], []
         if self._wt_buf is None:
             self._wt_buf = torch.empty(self._wt_total, device=self._dev, dtype=torch.float32)
         self._wt_fresh = set()
