@@ -124,7 +124,8 @@ int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
  * convolution kernel with 128x128 / 128x256 tiles, 5: plain GEMM kernel, 7: direct 3x3 convolution for <= 4 output
  * channels, 8 / 9 / 10: split-precision bf16 3x3 convolution / plain product (a_packed) / activation product (math = 1), 11: the persistent
  * variant of 9 (grids of >= 1024 tiles), 12 / 15 / 16: the 128 x 256 / 128 x 512 / split 128 x 256 tiles of 8, 13: the 128 x 256 tile of 9,
- * 17: the 16x16x32-MFMA 3x3 convolution (32-channel K-steps, 128 x 256 tile), -1: a_packed given for an unsupported problem (profiling / tests). */
+ * 17: the 16x16x32-MFMA 3x3 convolution (32-channel K-steps, 128 x 256 tile), 18: its persistent variant (LDS-DMA weight stages, 8 x 32 pixel
+ * segments of images of any size), 19: the persistent 16x16x32 kernel for 9's problems, -1: a_packed given for an unsupported problem (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):

@@ -125,7 +125,7 @@ def test_split_precision_planner_agrees_with_the_python_side_eligibility():
                 d.M, d.N, d.K, d.NP = M, nb * NP, K, NP
                 d.a_mode, d.b_mode = A_ROW, B_PLAIN
                 d.lda, d.ldb, d.b_bstride, d.ldd, d.d_bstride, d.alpha = K, NP, K * NP, NP, M * NP, 1.0
-                assert (h.vd_gemm_tile(C.byref(d)) in (9, 11, 13)) == ops.gemm_bx3_eligible(M, K, NP, nb), (NP, M, K, nb)
+                assert (h.vd_gemm_tile(C.byref(d)) in (9, 11, 13, 19)) == ops.gemm_bx3_eligible(M, K, NP, nb), (NP, M, K, nb)
                 for a_mode, b_mode in ((A_COL, B_PLAIN), (A_ROW, B_PLAIN), (A_ROW, B_KCONTIG)):
                     e = GemmDesc()
                     e.A, e.B, e.D, e.math = FAKE, FAKE, FAKE, 1

@@ -1127,3 +1127,48 @@ def test_persistent_16x16x32_convolution_on_wide_and_non_square_images():
     worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("K32P")][0].split()[1])
     print(f"[parity] persistent k32 convolution: worst rel_err {worst:.2e}")
     assert worst <= BX3_TOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(128, 256, 768, 16), (128, 384, 128, 32), (128, 192, 200, 16), (512, 64, 256, 8), (8, 128, 128, 128)])
+def test_persistent_16x16x32_1x1_convolution_and_its_input_gradient(B, Cin, Cout, H):
+    """vd_gemm_k32p.hip (round 4): the persistent 16x16x32 kernel for the 1x1 family on full-size grids (vd_gemm_tile() == 19): the attention
+    projection 256 -> 768, a shortcut at 32x32, a ragged channel tile (M = 200), tiles that span four 8x8 images, a 128x128 image (config #4);
+    operands are channel slices of wider buffers; forward (+ bias + residual), accumulate, and the input gradient through the transposed
+    packed operand, against torch."""
+    x = torch.randn(B, Cin, H, H, generator=g(0))
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g(1)) / math.sqrt(Cin))
+    b = torch.randn(Cout, generator=g(2))
+    res = torch.randn(B, Cout, H, H, generator=g(3))
+    wd = w.to(DEV).view(Cout, Cin)
+    pk = ops.conv3_pack_weights(wd, Cout, Cin, taps=1)
+    xbuf = torch.zeros(B, Cin + 2, H, H, device=DEV)
+    xbuf[:, 2:] = x.to(DEV)
+    obuf = torch.full((B, Cout + 2, H, H), 7.0, device=DEV)
+    ops.conv1x1(xbuf[:, 2:], wd, b.to(DEV), obuf[:, 1:1 + Cout], residual=res.to(DEV), a_packed=pk)
+    assert ops.LAST_GEMM_TILE == 19, ops.LAST_GEMM_TILE
+    y_ref = torch.empty(B, Cout, H, H)
+    for s0 in range(0, B, 64):                               # (the reference in chunks: the 128 x 128 case is 1 GB as one tensor on the host)
+        y_ref[s0:s0 + 64] = F.conv2d(x[s0:s0 + 64], w, b) + res[s0:s0 + 64]
+    check(obuf[:, 1:1 + Cout], y_ref, BX3_TOL, f"k32p 1x1 {Cin}->{Cout}@{H}")
+    assert float((obuf[:, 0] - 7).abs().max()) == 0 and float((obuf[:, -1] - 7).abs().max()) == 0
+    HW = H * H
+    if Cout % 32 == 0 and Cin >= 64:
+        dy = torch.randn(B, Cout, H, H, generator=g(4))
+        pkt = ops.conv3_pack_weights(wd, Cin, Cout, transposed=True, taps=1)
+        dx = torch.full((B, Cin, H, H), 2.0, device=DEV)
+        ops.gemm(wd, dy.to(DEV), dx, M=Cin, N=B * HW, K=Cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=Cin, ldb=HW, b_bstride=Cout * HW,
+                 ldd=HW, d_bstride=Cin * HW, a_packed=pkt, accumulate=True)
+        if vd_cdiv_py(Cin, 128) * (B * HW // 256) >= 192:
+            assert ops.LAST_GEMM_TILE == 19, ops.LAST_GEMM_TILE
+        dx_ref = torch.empty(B, Cin, H, H)
+        for s0 in range(0, B, 64):
+            dx_ref[s0:s0 + 64] = F.conv_transpose2d(dy[s0:s0 + 64], w)
+        check(dx - 2.0, dx_ref, BX3_TOL, f"k32p 1x1 dgrad {Cin}->{Cout}@{H}")
+        dx2 = torch.full((B, Cin, H, H), 2.0, device=DEV)     # determinism
+        ops.gemm(wd, dy.to(DEV), dx2, M=Cin, N=B * HW, K=Cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=Cin, ldb=HW, b_bstride=Cout * HW,
+                 ldd=HW, d_bstride=Cin * HW, a_packed=pkt, accumulate=True)
+        assert torch.equal(dx, dx2)
+
+
+def vd_cdiv_py(a, b):
+    return (a + b - 1) // b

@@ -19,6 +19,9 @@
 // vd_conv_k32p.hip: the persistent 16x16x32 split-precision 3x3 convolution (its own translation unit)
 bool vd_conv3_k32p_eligible(const vd_gemm_desc& d);
 int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st);
+// vd_gemm_k32p.hip: the persistent 16x16x32 split-precision 1x1 convolution / plain product
+bool vd_gemm1x1_k32p_pick(const vd_gemm_desc& d);
+int vd_launch_gemm1x1_k32p(const vd_gemm_desc& d, hipStream_t st);
 
 namespace {
 
@@ -2104,6 +2107,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             return big == 2 ? 15 : (big == 1 ? 12 : 8);                // 12 / 15: the 128 x 256 / 128 x 512 tile, eight waves
         }
         if (!gemm_bx3_eligible(d)) return -1;
+        if (vd_gemm1x1_k32p_pick(d)) return 19;                 // 19: gemm1x1_k32p_kernel (persistent 16x16x32 kernel, 128 x 256 tiles, LDS-DMA weights)
         // >= 2 tiles per resident workgroup (512 slots): the persistent variant walks them with the next tile's loads in flight
         static const int gbig_off = getenv("VD_GEMM_BX3_BIG_OFF") ? atoi(getenv("VD_GEMM_BX3_BIG_OFF")) : 0;
         if (!gbig_off && gemm_bx3_big_tile(d)) return 13;       // 13: the 128 x 256 tile, eight waves
@@ -2168,6 +2172,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 6: rc = launch_patch(d, st); break;
         case 7: rc = launch_smallm(d, st); break;
         case 8: case 12: case 15: case 16: case 17: case 18: rc = launch_bx3(d, st); break;
+        case 19: rc = vd_launch_gemm1x1_k32p(d, st) == 0 ? 0 : VD_EINVAL; break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 13:
             hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d);

@@ -174,6 +174,8 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     tl = LAST_GEMM_TILE
     if tl == 10:
         name = f"gemm_bx3_act_kernel<{int(a_mode == A_ROW)}, {int(b_mode == B_KCONTIG)}>"
+    elif tl == 19:
+        name = "gemm1x1_k32p_kernel"
     elif tl in (9, 11, 13):
         name = "gemm_bx3_persist_kernel" if tl == 11 else f"gemm_bx3_kernel<{512 if tl == 13 else 256}>"
     elif tl == 17:
