@@ -616,12 +616,12 @@ def main():
         net.sampler_graph = g0
         if rank == 0:
             sample_kernels = summarise(rec_s)
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
 
     def traffic_of(kname):      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
             with open(pmc_file) as f:
-                return json.load(f)["kernels"].get(kname.split("(+")[0], {}).get("traffic_bytes_per_launch")
+                return json.load(f)["kernels"].get(kname.split("(+")[0].split("@")[0], {}).get("traffic_bytes_per_launch")
         except OSError:
             return None
 
@@ -644,7 +644,17 @@ def main():
     src = kernels if kernels else sample_kernels
     if src:
         mf = [k for k in src if k["mfma_peak"]]
-        roofline = roof_entry(mf[0], "the MFMA kernel symbol with the largest TOTAL TIME in the profiled step (HIP events around every launch)")
+        # dominant kernel: the kernel TEMPLATE (all its instantiations: one source kernel) with the largest total time in the profiled step, and of
+        # it the instantiation with the largest total time -- a symbol that collects every shape of a small family (the 1x1 kernel: 35 launches)
+        # would otherwise outrank the instantiations of the family that takes three times as long (the 3x3 convolution)
+        fam = {}
+        for k in mf:
+            fam[k["kernel"].split("<")[0].split("(")[0]] = fam.get(k["kernel"].split("<")[0].split("(")[0], 0.0) + k["ms"]
+        top_fam = max(fam, key=fam.get)
+        dom = next(k for k in mf if k["kernel"].split("<")[0].split("(")[0] == top_fam)
+        roofline = roof_entry(dom, "the MFMA kernel template with the largest TOTAL TIME in the profiled step (HIP events around every launch; all its "
+                                   f"instantiations: {round(fam[top_fam], 3)} ms), and its instantiation with the largest total time")
+        roofline["family_ms_per_step"] = round(fam[top_fam], 3)
         roofline["all_mfma_kernels_ms"] = round(sum(k["ms"] for k in mf), 2)
         roofline["note"] = ("per-launch durations are taken with the weight gradients on the launch stream (bench.py --serial-wgrad is the same setting for "
                             "a whole run, used for the rocprofv3 summaries); the timed region overlaps them with the backward pass on a side stream")
