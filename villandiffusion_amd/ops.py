@@ -516,9 +516,7 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
     flops = sum(2.0 * d.M * d.C * d.T * d.nb * d.NP for d in descs)
     nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
     var = lib.vd_conv_wgrad_group_variant(ent["cls"])
-    if ent["cls"] > 2000:                                        # stride-2 3x3 classes (2000 + output width)
-        name = f"wgrad_bx3_group_kernel<{ent['cls'] - 2000}, 4, false>(+group_reduce)"
-    elif ent["cls"] == 1000:                                     # symbol names as rocprofv3 prints them
+    if ent["cls"] == 1000:                                       # symbol names as rocprofv3 prints them
         name = "wgrad1x1_wide_group_kernel(+group_reduce)" if var == 256 else "wgrad1x1_bx3_group_kernel(+group_reduce)"
     elif var == 9:
         name = f"wgrad9_group_kernel<{ent['cls'] // 4}>(+group_reduce)"
@@ -570,8 +568,6 @@ def wgrad_bx3_eligible(M, Cc, OH, OW, mode) -> bool:
         return (OH * OW) % 8 == 0 and M >= 64 and Cc >= 64
     if (mode == B_CONV3 and OW == 4 and OH == 4) or (mode in (B_CONV3, B_CONV3_UP) and OW >= 64 and OW % 32 == 0):
         return M >= 64 and Cc >= 64      # 4x4: two images per K-step; wide images: 32-pixel row segments
-    if mode == B_CONV3_S2:                   # round 4: the Downsample2D convolution (stride 2) at 16x16 / 8x8 outputs (VILLAN_WGRAD_S2_F32=1: exact-f32 kernel)
-        return OH == OW and OW in (8, 16) and M >= 64 and Cc >= 64 and os.environ.get("VILLAN_WGRAD_S2_F32", "0") != "1"
     return mode in (B_CONV3, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
 
 
