@@ -127,7 +127,12 @@ def setup(args: argparse.Namespace, preflight: bool = False) -> TrainingConfig:
             setattr(cfg, k, v)
     cfg.mode = mode
     cfg.clip = cfg.fclip == "w"                                        # :252-258
-    cfg.mixed_precision = "no"                                         # fp32 everywhere (reference: fp16 autocast for VP/LDM)
+    # f32 tensors everywhere by default (reference :260-264: fp16 autocast + GradScaler for SDE-VP / SDE-LDM).  VILLAN_MIXED_PRECISION=fp16 opts
+    # into the library's mixed-precision arithmetic (UNet2DModel.conv_math = "f16": single f16 products in the full-size convolutions, loss scaling)
+    mp = os.environ.get("VILLAN_MIXED_PRECISION", "no")
+    if mp not in ("no", "fp16"):
+        raise ValueError(f"VILLAN_MIXED_PRECISION={mp!r}: 'no' or 'fp16'")
+    cfg.mixed_precision = mp if cfg.sde_type in ("SDE-VP", "SDE-LDM") else "no"
     cfg.device_ids = [int(i) for i in range(len(cfg.gpu.split(",")))]  # :245 (indices into the visible set main() exported from --gpu)
     if isinstance(cfg.sample_ep, int) and cfg.sample_ep < 0:           # :248-251
         cfg.sample_ep = None
@@ -444,6 +449,8 @@ def train_loop(cfg: TrainingConfig, dsl, rank: int, world: int):
         src = cfg.ckpt if cfg.ckpt is not None else DiffuserModelSched.MODEL_DEFAULT
     model, vae, noise_sched, get_pipeline = DiffuserModelSched.get_model_sched(
         image_size=dsl.image_size, channels=dsl.channel, ckpt=src, sde_type=cfg.sde_type, clip_sample=cfg.clip, noise_sched_type=cfg.sched)
+    if cfg.mixed_precision == "fp16" and hasattr(model, "conv_math"):
+        model.conv_math = "f16"
     if world > 1:                                                      # identical replicas
         torch.distributed.broadcast(model.flat_param, src=0)
     loss_fn = LossFn(noise_sched=noise_sched, sde_type=cfg.sde_type, loss_type="l2", psi=cfg.psi, solver_type=cfg.solver_type,

@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-f32 leg (profiling runs: the summary then covers the default arithmetic only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
+    ap.add_argument("--no-f16", action="store_true",
+                    help="skip the opt-in mixed-precision legs (conv_math = 'f16': the reference's GPU arithmetic is fp16 autocast; reported beside the headline)")
     ap.add_argument("--cpu-true-1000", action="store_true",
                     help="CPU leg: also one TRUE 1000-step DDPM run of one image on the oracle and on the product with the same noise (about a minute of CPU)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -122,6 +124,9 @@ def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=N
         if i == 0 and parity is not None:
             parity["loss_step0_rel_err"] = abs(parity.pop("loss") - l_) / abs(l_)
             parity["grad_norm_rel_err"] = abs(parity.pop("grad_norm") - g_) / g_
+            if "loss_f16" in parity:          # the opt-in mixed-precision mode on the same inputs (reported, not gated: never the headline arithmetic)
+                parity["f16_mode_loss_rel_err"] = abs(parity.pop("loss_f16") - l_) / abs(l_)
+                parity["f16_mode_grad_norm_rel_err"] = abs(parity.pop("grad_norm_f16") - g_) / g_
     dt_train = time.perf_counter() - t0
     train_ips = n_steps * batch / dt_train
     # sampling: 8 images x the last 20 steps of the 1000-step DDPM chain, extrapolated x50 (stated in "sample")
@@ -458,6 +463,7 @@ def main():
     train_ips = dt = final_loss = None
     host_submit_ms = host_sync_ms = None
     exact = None
+    f16 = None
     if do_train:
         for i in range(args.warmup):
             one_step(i)
@@ -511,6 +517,30 @@ def main():
             net.conv_math = mode0
             log(f"exact-f32 mode: {exact}")
 
+        # ---- ... and in the opt-in mixed-precision mode (one f16 product per term in the full-size 3x3 / 1x1 forward and input-gradient
+        # contractions, loss scaling in the trainer): the reference trains this config under fp16 autocast (VillanDiffusion.py:260-264).
+        # Reported beside the headline, never as `value`. ----
+        if net.conv_math == "bf16x3" and not args.no_f16:
+            net.conv_math = "f16"
+            for i in range(3):
+                one_step(i)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(args.warmup + i)
+            torch.cuda.synchronize()
+            barrier()
+            tf = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            f16 = {"train_images_per_sec": round(world * B * args.steps / float(tf), 2), "ms_per_step": round(1e3 * float(tf) / args.steps, 3),
+                   "loss_scale": trainer.loss_scale,
+                   "note": "same run, net.conv_math = 'f16': 3x3 / 1x1 forward + input gradients as single f16 products (v_mfma_f32_16x16x32_f16), weight "
+                           "gradients and attention as in the default arithmetic, f32 master weights and accumulation, loss scaling"}
+            net.conv_math = "bf16x3"
+            log(f"f16 mixed-precision mode: {f16}")
+
     # ---- 1000-step DDPM sampling (second half of the metric), embarrassingly parallel ----
     sample_ips, sample_s, secondary, sample_eager = None, None, None, None
     pipe = DDPMPipeline(net, sched)
@@ -559,6 +589,14 @@ def main():
             net.sampler_graph = True
             sample_eager = {"images_per_sec": round(world * n_img / s_eager, 4), "seconds": round(s_eager, 2)}
             log(f"sample (eager launches): {sample_eager}")
+        if net.conv_math == "bf16x3" and not args.no_f16 and n_img >= 4 * B:      # the same loop in the f16 mode on 4 chunks (one round of streams)
+            net.conv_math = "f16"
+            init_full, init = init, init[:4 * B]
+            s16 = timed_sampling()
+            f16 = dict(f16 or {}, sample_ddpm1000_images_per_sec=round(world * len(init) / s16, 4))
+            init = init_full
+            net.conv_math = "bf16x3"
+            log(f"f16 mode sampling: {f16.get('sample_ddpm1000_images_per_sec')} img/s")
         sched.device_rng_seed = None
         # secondary samplers of SURVEY.md §8d (configs #2-#4): same network, same init, whole loop incl. post-processing
         from villandiffusion_amd.pipelines import DDIMPipeline, PNDMPipeline
@@ -664,13 +702,21 @@ def main():
 
     # ---- CPU oracle on the host cores (rank 0, N = 1): the reported baseline AND the parity gates printed with the number ----
     def gpu_train_side(x0, R, t, eps):
-        net.zero_grad()
-        batch = {"target": x0.to(dev), "pixel_values": R.to(dev)}
-        loss = loss_fn.p_loss_by_keys(batch, net, "target", "pixel_values", t.to(dev), noise=eps.to(dev))
-        loss.backward()
-        gn = float(torch.sqrt((net.flat_grad.double() ** 2).sum()))
-        net.zero_grad()
-        return {"loss": float(loss), "grad_norm": gn}
+        out_ = {}
+        gs0 = loss_fn.grad_scale
+        for tag, mode in (("", net.conv_math),) + ((("_f16", "f16"),) if (net.conv_math == "bf16x3" and not args.no_f16) else ()):
+            mode0, net.conv_math = net.conv_math, mode
+            loss_fn.grad_scale = 4096.0 if mode == "f16" else 1.0          # the trainer's loss scale, divided out below
+            net.zero_grad()
+            batch = {"target": x0.to(dev), "pixel_values": R.to(dev)}
+            loss = loss_fn.p_loss_by_keys(batch, net, "target", "pixel_values", t.to(dev), noise=eps.to(dev))
+            loss.backward()
+            out_["loss" + tag] = float(loss)
+            out_["grad_norm" + tag] = float(torch.sqrt((net.flat_grad.double() ** 2).sum())) / loss_fn.grad_scale
+            net.zero_grad()
+            net.conv_math = mode0
+        loss_fn.grad_scale = gs0
+        return out_
 
     def gpu_sample_side(init_cpu, seed, start_from, ref_timesteps):
         sch = DDPMScheduler(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02)
@@ -713,6 +759,7 @@ def main():
                                    % (args.sample_steps, args.sample_images, B, min(args.sample_streams, max(1, -(-args.sample_images // B)))),
                        "global_batch": B * world, "image": "3x32x32", "parallelism": f"dp{world}", "mode": args.mode},
             "exact_f32_mode": None if exact is None else {k: exact[k] for k in ("train_images_per_sec", "ms_per_step")},
+            "f16_mode": None if f16 is None else {k: f16[k] for k in ("train_images_per_sec", "ms_per_step", "sample_ddpm1000_images_per_sec", "loss_scale") if k in f16},
             "sample_ddpm1000_images_per_sec": None if sample_ips is None else round(sample_ips, 4),
             "sample_seconds": None if sample_s is None else round(sample_s, 2),
             "sample_hip_graph": bool(net.sampler_graph), "sample_streams": min(args.sample_streams, -(-args.sample_images // B)) if args.sample_images > B else 1,
@@ -735,7 +782,7 @@ def main():
         # communicator lines) goes to a side file and to stderr: the driver keeps only the tail of stdout, and the ONE line must survive it
         detail = dict(out)
         detail.update({"roofline": roofline, "roofline_largest_flops": roofline_by_flops, "train_step_kernels": kernels,
-                       "sampler_step_kernels": sample_kernels, "exact_f32_mode": exact, "sample_eager_launches": sample_eager,
+                       "sampler_step_kernels": sample_kernels, "exact_f32_mode": exact, "f16_mode": f16, "sample_eager_launches": sample_eager,
                        "process_group": ranks_seen,
                        "dtype_note": ("f32 tensors and accumulation; 3x3 / 1x1 convolutions and the attention contractions (forward, input and weight "
                                       "gradients) as hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32 per contraction; the "

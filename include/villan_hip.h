@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 8
+#define VD_ABI_VERSION 9
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -97,7 +97,10 @@ typedef struct vd_gemm_desc {
                                 accumulation; ~1e-5 relative to the exact-f32 kernel) instead of on the f32 MFMA.  A is still
                                 required (shape checks) but not read.  Problems outside that set fail with VD_EINVAL.   */
     int32_t a_packed_mpad;   /* row count the packed operand was built with (M rounded up to 128)                      */
-    int32_t math;            /* 0: exact f32 MFMA (or a_packed).  1: split-precision product of two ACTIVATION matrices (attention
+    int32_t math;            /* 2: a_packed holds f16 operands (vd_conv3_pack_weights_f16_multi): ONE f16 MFMA per product term, f32 accumulation
+                                (~2e-4 relative per contraction) -- only problems the persistent 16x16x32 kernels take (vd_gemm_tile() 18 / 19),
+                                else VD_EINVAL.
+                                0: exact f32 MFMA (or a_packed).  1: split-precision product of two ACTIVATION matrices (attention
                                 scores / values and their gradients): per-batch A (a_bstride != 0), VD_B_PLAIN or VD_B_KCONTIG,
                                 NP % 128 == 0, K % 16 == 0, K >= 32, M >= 64, 16-byte aligned operands and strides; both operands
                                 are split into bf16 (hi, lo) inside the kernel.  Anything else fails with VD_EINVAL.           */
@@ -185,6 +188,10 @@ int vd_conv3_pack_weights(const float* W, void* packed, int M, int C, int taps, 
  * int64 [n_jobs][8] = {W address, packed address, M, C, row_stride, chan_stride, first workgroup of the job, taps}; job j owns
  * ceil(Mpad_j * C_j / 8 / 256) workgroups of 256 threads, first-workgroup numbers ascending from 0; total_blocks = their sum. */
 int vd_conv3_pack_weights_multi(const int64_t* table, int n_jobs, int64_t total_blocks, void* stream);
+/* The same job table, f16 operands (round 4, opt-in mixed precision -- the reference's GPU arithmetic is fp16 autocast, VillanDiffusion.py:260-264):
+ * unit ((cc * taps + t) * 2 + q) * Mpad + m = channels cc*16 + q*8 + j of tap t, row m, rounded to f16; a job's image holds
+ * vd_conv3_packed_bytes(M, C, taps) / 2 bytes.  Consumed by vd_gemm with vd_gemm_desc.math = 2. */
+int vd_conv3_pack_weights_f16_multi(const int64_t* table, int n_jobs, int64_t total_blocks, void* stream);
 
 /* W[M][C][T] -> Wt[C][M][T]  (operand for the dgrad GEMMs). */
 int vd_weight_transpose(const float* W, float* Wt, int M, int C, int T, void* stream);
@@ -305,7 +312,8 @@ int vd_loss_fwd_bwd(const float* pred, const float* y, const float* pscale, floa
  * K9 -- global grad-norm clip + Adam on flat buffers (VillanDiffusion.py:445,1165-1169).
  * ------------------------------------------------------------------------------------------ */
 int vd_l2norm_sq(const float* g, int64_t n, float* partial, float* out_sq, void* stream);
-/* clip = min(1, max_norm/(sqrt(*norm_sq)*inv_scale + 1e-6)); g' = g*inv_scale*clip; torch.optim.Adam update. */
+/* clip = min(1, max_norm/(sqrt(*norm_sq)*inv_scale + 1e-6)); g' = g*inv_scale*clip; torch.optim.Adam update.  With norm_sq given and
+ * *norm_sq not finite the kernel leaves p / m / v untouched (GradScaler.step's overflow skip, for the f16 mixed-precision mode). */
 int vd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float max_norm,
                  float inv_scale, float lr, float beta1, float beta2, float eps, int step, void* stream);
 

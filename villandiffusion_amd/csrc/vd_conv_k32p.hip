@@ -24,6 +24,15 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// F16 kernels (round 4, opt-in mixed precision: vd_gemm_desc.math = 2): ONE f16 product per term instead of the three bf16 ones.
+__device__ __forceinline__ u32x4 to_f16x8(const float (&v)[8]) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];           // v_cvt_f16_f32: round to nearest even
+    return __builtin_bit_cast(u32x4, h);
+}
 
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
     bf16x8 h, l;
@@ -47,23 +56,27 @@ struct k32p_args {
     unsigned long long* stamps;   // diagnostic build (-DVD_K32P_STAMPS) only: [grid][16] s_memrealtime / s_memtime stamps per workgroup
 };
 
-template <int TW, int MODE, bool DMA, bool PIPE>   // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP, 3: CONV3 of silu(GroupNorm(x))
+// F16 (math = 2): the operands are single f16 planes -- packed weights [chunk][tap][q][Mpad] (vd_conv3_pack_weights_f16), patch planes [c2][q] --
+// and a product term is ONE v_mfma_f32_16x16x32_f16.  NPART = planes per operand (2: bf16 hi / lo, 1: f16); every index below is written in it.
+template <int TW, int MODE, bool DMA, bool PIPE, bool F16>   // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP, 3: CONV3 of silu(GroupNorm(x))
 __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     const vd_gemm_desc& d = a.d;
     constexpr int BM = 128, NPIX = 256, NTH = 512;
+    constexpr int NPART = F16 ? 1 : 2;
+    constexpr int RUNS = 3 * NPART * 2;                            // 2 KB runs of one chunk's tap row: (s, part, q)
     constexpr int TR = NPIX / TW;
     constexpr int PW = TW + 2, PR = TR + 2, PIMG = PR * PW;
     constexpr int PLANE = (PIMG + 15) / 16 * 16;
-    constexpr int A_HALF = 3 * 2 * 2 * BM;                        // 1536 units: one tap row of ONE chunk
-    constexpr int A_UNITS = 2 * A_HALF;                           // 3072 units = 48 KB per buffer
-    constexpr int A_IT = A_UNITS / NTH;                           // 6
+    constexpr int A_HALF = RUNS * BM;                              // 1536 (768) units: one tap row of ONE chunk
+    constexpr int A_UNITS = 2 * A_HALF;                           // 3072 units = 48 KB per buffer (f16: 24 KB)
+    constexpr int A_IT = A_UNITS / NTH;                           // 6 (3)
     constexpr int P_IT = (PIMG + 127) / 128;                      // 3
     constexpr int RED_UNITS = 8 * 64 * 2 * 4 / 16;                // gn_part scratch: [wave][64 channels][2] floats = 4 KB
     // ONE LDS object (a second __shared__ array beside an LDS-DMA target makes hipcc wait vmcnt(0) before every ds_read: guide §5 item 4a)
-    __shared__ u32x4 lds[2 * A_UNITS + 8 * PLANE + RED_UNITS];
+    __shared__ u32x4 lds[2 * A_UNITS + 4 * NPART * PLANE + RED_UNITS];
     u32x4* const As = lds;
     u32x4* const Ps = lds + 2 * A_UNITS;
-    float* const red = reinterpret_cast<float*>(lds + 2 * A_UNITS + 8 * PLANE);
+    float* const red = reinterpret_cast<float*>(lds + 2 * A_UNITS + 4 * NPART * PLANE);
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
         ppy[i] = rem / PW;
         ppx[i] = rem - ppy[i] * PW;
         pvalid |= (rem < PIMG ? 1u : 0u) << i;
-        pdst[i] = ((cq >> 1) * 4 + (cq & 1)) * PLANE + rem;      // Ps[c2][part = 0][q][pixel]; the lo part sits 2 * PLANE further
+        pdst[i] = ((cq >> 1) * 2 * NPART + (cq & 1)) * PLANE + rem;      // Ps[c2][part = 0][q][pixel]; the lo part sits 2 * PLANE further
     }
     unsigned poff[P_IT];
     unsigned pmask = 0;
@@ -146,14 +159,14 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
 
     u32x4 ra[DMA ? 1 : A_IT];
     float rp[P_IT][8];
-    unsigned aoff[A_IT];
+    unsigned aoff[6];             // (A_IT <= 6; sized by a constant: with `aoff[A_IT]`, A_IT depending on F16, hipcc 7.2 emits no host stubs for this template)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int run = (tid + i * NTH) >> 7;                     // 0..23 = c2 * 12 + (s, part, q); chunk c2 = 1 is 36 runs further in the packed operand
-        aoff[i] = 16u * (unsigned)(((run % 12) + 36 * (run / 12)) * Mpad + (tid & 127));
+        aoff[i] = 16u * (unsigned)(((run % RUNS) + 3 * RUNS * (run / RUNS)) * Mpad + (tid & 127));
     }
     auto load_a = [&](int m0_, int cp, int r, int buf) {         // stage (m-tile, chunk pair, tap row): registers, or straight into As[buf] (DMA)
-        const unsigned so = 16u * (unsigned)((cp * 72 + r * 12) * Mpad + m0_);               // wave-uniform
+        const unsigned so = 16u * (unsigned)((cp * 6 * RUNS + r * RUNS) * Mpad + m0_);        // wave-uniform
         if constexpr (DMA) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
@@ -200,7 +213,8 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (MODE != 3 || ok) ? rp[i][j] : 0.f;
-            split8(v, cph[i], cpl[i]);
+            if constexpr (F16) cph[i] = to_f16x8(v);
+            else split8(v, cph[i], cpl[i]);
         }
     };
     auto write_p = [&]() {
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
         for (int i = 0; i < P_IT; ++i) {
             if ((pvalid >> i) & 1u) {
                 Ps[pdst[i]] = cph[i];
-                Ps[pdst[i] + 2 * PLANE] = cpl[i];
+                if constexpr (!F16) Ps[pdst[i] + 2 * PLANE] = cpl[i];
             }
         }
     };
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     for (int ni = 0; ni < 4; ++ni) {
         const int qx = wn * 64 + ni * 16 + l15;
         const int ty = qx / TW, x = qx - ty * TW;
-        p_base[ni] = Ps + (c2 * 4 + q) * PLANE + ty * PW + x;
+        p_base[ni] = Ps + (c2 * 2 * NPART + q) * PLANE + ty * PW + x;
     }
 
     auto mfma_row = [&](int r, int buf) {
@@ -292,6 +306,40 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                         wh[mi] = __builtin_bit_cast(bf16x8, a_cur[((s + 1) * 4 + 0) * BM + mi * 16]);
                         wl[mi] = __builtin_bit_cast(bf16x8, a_cur[((s + 1) * 4 + 2) * BM + mi * 16]);
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // F16: the same pipeline with one fragment per operand and one MFMA per (pixel tile, channel tile)
+    auto mfma_row_f16 = [&](int r, int buf) {
+        const int pr = (MODE == 1) ? 2 - r : r;
+        const u32x4* __restrict__ a_cur = a_base + buf * A_UNITS;
+        f16x8 wh[4], xh[2];
+        auto tap_col = [&](int s) { return (MODE == 1) ? 2 - s : s; };
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) wh[mi] = __builtin_bit_cast(f16x8, a_cur[mi * 16]);
+        xh[0] = __builtin_bit_cast(f16x8, p_base[0][pr * PW + tap_col(0)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int cur = (s * 4 + ni) & 1, nxt = cur ^ 1;
+                if (!(s == 2 && ni == 3)) {
+                    const int ns = (ni == 3) ? s + 1 : s, nn = (ni == 3) ? 0 : ni + 1;
+                    xh[nxt] = __builtin_bit_cast(f16x8, p_base[nn][pr * PW + tap_col(ns)]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cur], wh[mi], acc[ni][mi], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (ni == 3 && s < 2) {
+                        wh[mi] = __builtin_bit_cast(f16x8, a_cur[((s + 1) * 2) * BM + mi * 16]);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
             }
@@ -473,7 +521,8 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT) : "memory");   // the patch loads (older than this stage's DMAs)
                     convert_p(more ? cp + 1 : 0);
                 }
-                if constexpr (PIPE) mfma_row_pipe(r, buf);
+                if constexpr (F16) mfma_row_f16(r, buf);
+                else if constexpr (PIPE) mfma_row_pipe(r, buf);
                 else mfma_row(r, buf);
                 if (!DMA && !late && ex1) store_a(buf ^ 1);       // W(s+1)
                 if (r == 2 && pnext) {
@@ -499,12 +548,56 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     }
 }
 
+// f16 packed weights (math = 2): unit ((cc * T + t) * 2 + q) * Mpad + m = the 8 channels cc * 16 + q * 8 + j of tap t, row m, as f16 (one plane:
+// half the bytes of the bf16 (hi, lo) operand).  Job table as vd_conv3_pack_weights_multi: {src, dst, M, C, row_stride, chan_stride, first block,
+// taps}; one thread per (m, chunk, q), lanes along m.
+template <int T>
+__device__ __forceinline__ void pack_f16_one(const float* __restrict__ src, u32x4* __restrict__ dst, int M, int C, int Mpad, int64_t rs, int64_t cs,
+                                             int local) {
+    if (local >= Mpad * (C / 16) * 2) return;
+    const int m = local % Mpad;
+    const int rest = local / Mpad;
+    const int q = rest & 1, cc = rest >> 1;
+    const float* __restrict__ s0 = src + (int64_t)(m < M ? m : 0) * rs + (int64_t)(cc * 16 + q * 8) * cs;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (m < M) ? s0[(int64_t)j * cs + t] : 0.f;
+        dst[((int64_t)(cc * T + t) * 2 + q) * Mpad + m] = to_f16x8(w);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_f16_multi_kernel(const int64_t* __restrict__ table, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    const int64_t blk = blockIdx.x;
+    while (lo < hi) {                                            // last job whose first block <= blk (block-uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t* __restrict__ jb = table + lo * 8;
+    const int M = (int)jb[2], C = (int)jb[3];
+    const int local = (int)(blk - jb[6]) * 256 + threadIdx.x;
+    if (jb[7] == 1)
+        pack_f16_one<1>(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<u32x4*>(jb[1]), M, C, (M + 127) / 128 * 128, jb[4], jb[5], local);
+    else
+        pack_f16_one<9>(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<u32x4*>(jb[1]), M, C, (M + 127) / 128 * 128, jb[4], jb[5], local);
+}
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
 }  // namespace
+
+extern "C" int vd_conv3_pack_weights_f16_multi(const int64_t* table, int n_jobs, int64_t total_blocks, void* stream) {
+    VD_REQUIRE(table && n_jobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "vd_conv3_pack_weights_f16_multi: bad arguments");
+    hipLaunchKernelGGL(pack_f16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_jobs);
+    VD_LAUNCH_CHECK("vd_conv3_pack_weights_f16_multi");
+    return 0;
+}
 
 // What launch_bx3 (vd_gemm.hip) asks: can the persistent 16x16x32 kernel take this problem?  Output tiles of 256 pixels (16 x 16, or 8 rows x 32
 // columns of any image whose sides divide), whole chunk pairs, aligned float4 epilogue, and enough tiles to give every CU at least one.
@@ -558,16 +651,17 @@ int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st) {
 #ifdef VD_K32P_VARIANTS
 #define VD_K32P_CASE(WW, MD)                                                                                         \
     if (TW == WW && mode == MD) {                                                                                    \
-        if (dma && pipe) hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, true>), dim3(grid), dim3(512), 0, st, a);        \
-        else if (dma) hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, false>), dim3(grid), dim3(512), 0, st, a);          \
-        else if (pipe) hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, false, true>), dim3(grid), dim3(512), 0, st, a);         \
-        else hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, false, false>), dim3(grid), dim3(512), 0, st, a);                  \
+        if (dma && pipe) hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, true, false>), dim3(grid), dim3(512), 0, st, a);        \
+        else if (dma) hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, false, false>), dim3(grid), dim3(512), 0, st, a);          \
+        else if (pipe) hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, false, true, false>), dim3(grid), dim3(512), 0, st, a);         \
+        else hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, false, false, false>), dim3(grid), dim3(512), 0, st, a);                  \
         return 0;                                                                                                    \
     }
 #else
 #define VD_K32P_CASE(WW, MD)                                                                                         \
     if (TW == WW && mode == MD) {                                                                                    \
-        hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, true>), dim3(grid), dim3(512), 0, st, a);                \
+        if (d.math == 2) hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, true, true>), dim3(grid), dim3(512), 0, st, a);   \
+        else hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, true, false>), dim3(grid), dim3(512), 0, st, a);    \
         return 0;                                                                                                    \
     }
 #endif

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float eps, float bc1, float bc2_sqrt) {
     float gs = inv_scale;
     if (norm_sq) {
+        // a non-finite gradient (f16 mixed-precision mode: an operand overflowed under the loss scale) skips the whole update, as
+        // torch.cuda.amp.GradScaler.step does (reference VillanDiffusion.py:260-264 -> accelerate); Trainer halves the scale when it sees it
+        if (!(*norm_sq <= 3.0e38f)) return;
         const float norm = sqrtf(*norm_sq) * inv_scale;
         gs *= fminf(1.0f, max_norm / (norm + 1e-6f));
     }

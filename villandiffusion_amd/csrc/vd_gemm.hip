@@ -2093,6 +2093,11 @@ extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
 extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
     if (!desc) return 0;
     const vd_gemm_desc& d = *desc;
+    if (d.a_packed && d.math == 2) {      // opt-in f16 operands (vd_conv3_pack_weights_f16_multi): only the persistent 16x16x32 kernels read them
+        if (bx3_eligible(d) && !bx3_big_split(d) && k32p_pick(d)) return 18;
+        if (gemm_bx3_eligible(d) && vd_gemm1x1_k32p_pick(d)) return 19;
+        return -1;
+    }
     if (d.a_packed) {
         if (bx3_eligible(d)) {
             int splits, c_per;

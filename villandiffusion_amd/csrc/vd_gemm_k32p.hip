@@ -22,6 +22,14 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u32x4 to_f16x8(const float (&v)[8]) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+    return __builtin_bit_cast(u32x4, h);
+}
 
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
     bf16x8 h, l;
@@ -41,12 +49,16 @@ struct g32p_args {
     int tiles_m;
 };
 
+// F16 (vd_gemm_desc.math = 2, opt-in mixed precision): single f16 planes for both operands (packed weights: vd_conv3_pack_weights_f16_multi), one
+// v_mfma_f32_16x16x32_f16 per product term.  NPART = planes per operand.
+template <bool F16>
 __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a) {
     const vd_gemm_desc& d = a.d;
     constexpr int BM = 128, NPIX = 256, NTH = 512;
-    constexpr int A_UNITS = 2 * 2 * 2 * BM;                       // 1024 units = 16 KB per stage: [c2][part][q][m]
-    constexpr int A_IT = A_UNITS / NTH;                           // 2
-    constexpr int P_UNITS = 8 * NPIX;                             // 2048 units = 32 KB per stage: [c2][part][q][pixel]
+    constexpr int NPART = F16 ? 1 : 2;
+    constexpr int A_UNITS = 2 * NPART * 2 * BM;                   // 1024 units = 16 KB per stage: [c2][part][q][m] (f16: 8 KB)
+    constexpr int A_IT = A_UNITS / NTH;                           // 2 (1)
+    constexpr int P_UNITS = 4 * NPART * NPIX;                     // 2048 units = 32 KB per stage: [c2][part][q][pixel] (f16: 16 KB)
     constexpr int P_IT = 2;                                       // (k-octet, pixel) items per thread: 4 octets x 256 pixels / 512 threads
     __shared__ u32x4 lds[2 * A_UNITS + 2 * P_UNITS];              // ONE LDS object (see vd_conv_k32p.hip)
     u32x4* const As = lds;
@@ -69,11 +81,11 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     const unsigned ldb4 = 4u * (unsigned)d.ldb;
 
     // weights: unit u = tid + i * 512 of a stage: run = u >> 7 = c2 * 4 + part * 2 + q, m = u & 127; global unit (cp * 8 + run) * Mpad + m0 + m
-    unsigned aoff[A_IT];
+    unsigned aoff[2];             // (A_IT <= 2; a constant size: see vd_conv_k32p.hip)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) aoff[i] = 16u * (unsigned)(((tid + i * NTH) >> 7) * Mpad + (tid & 127));
     auto dma_a = [&](int m0_, int cp, int buf) {
-        const unsigned so = 16u * (unsigned)(cp * 8 * Mpad + m0_);                            // wave-uniform
+        const unsigned so = 16u * (unsigned)(cp * 4 * NPART * Mpad + m0_);                    // wave-uniform
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(As + buf * A_UNITS + i * NTH + wave * 64);
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     unsigned poff[P_IT];
     int pdst[P_IT];
 #pragma unroll
-    for (int i = 0; i < P_IT; ++i) pdst[i] = ((cq >> 1) * 4 + (cq & 1)) * NPIX + (tid & 127) + 128 * i;       // plane (c2, part 0, q); lo: + 2 planes
+    for (int i = 0; i < P_IT; ++i) pdst[i] = ((cq >> 1) * 2 * NPART + (cq & 1)) * NPIX + (tid & 127) + 128 * i;   // plane (c2, part 0, q); lo: + 2 planes
     auto set_tile_px = [&](int n0_) {
 #pragma unroll
         for (int i = 0; i < P_IT; ++i) {
@@ -123,23 +135,47 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     auto write_p = [&](int buf, const float (&r)[P_IT][8]) {
 #pragma unroll
         for (int i = 0; i < P_IT; ++i) {
-            u32x4 hi, lo;
-            split8(r[i], hi, lo);
-            Ps[buf * P_UNITS + pdst[i]] = hi;
-            Ps[buf * P_UNITS + pdst[i] + 2 * NPIX] = lo;
+            if constexpr (F16) {
+                Ps[buf * P_UNITS + pdst[i]] = to_f16x8(r[i]);
+            } else {
+                u32x4 hi, lo;
+                split8(r[i], hi, lo);
+                Ps[buf * P_UNITS + pdst[i]] = hi;
+                Ps[buf * P_UNITS + pdst[i] + 2 * NPIX] = lo;
+            }
         }
     };
 
     f32x4 acc[4][4];                                              // [pixel tile ni][channel tile mi]
     const int wm = wave >> 2, wn = wave & 3;
     const int c2 = g >> 1, q = g & 1;
-    const u32x4* __restrict__ a_base = As + (c2 * 4 + q) * BM + wm * 64 + l15;
-    const u32x4* __restrict__ p_base = Ps + (c2 * 4 + q) * NPIX + wn * 64 + l15;
+    const u32x4* __restrict__ a_base = As + (c2 * 2 * NPART + q) * BM + wm * 64 + l15;
+    const u32x4* __restrict__ p_base = Ps + (c2 * 2 * NPART + q) * NPIX + wn * 64 + l15;
 
     // 48 MFMAs of one stage; the next pixel tile's fragments are read before the current tile's 12 MFMAs (see vd_conv_k32p.hip mfma_row_pipe)
     auto mfma_stage = [&](int buf) {
         const u32x4* __restrict__ a_cur = a_base + buf * A_UNITS;
         const u32x4* __restrict__ p_cur = p_base + buf * P_UNITS;
+        if constexpr (F16) {
+            f16x8 wh[4], xh[2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) wh[mi] = __builtin_bit_cast(f16x8, a_cur[mi * 16]);
+            xh[0] = __builtin_bit_cast(f16x8, p_cur[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int cur = ni & 1, nxt = cur ^ 1;
+                if (ni < 3) {
+                    xh[nxt] = __builtin_bit_cast(f16x8, p_cur[(ni + 1) * 16]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cur], wh[mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         bf16x8 wh[4], wl[4], xh[2], xl[2];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -317,6 +353,7 @@ int vd_launch_gemm1x1_k32p(const vd_gemm_desc& d, hipStream_t st) {
     a.tiles_m = vd_cdiv(d.M, 128);
     a.n_tiles = a.tiles_m * (d.N / 256);
     const int grid = a.n_tiles < n_cu ? ((a.n_tiles + 7) & ~7) : n_cu;
-    hipLaunchKernelGGL(gemm1x1_k32p_kernel, dim3(grid), dim3(512), 0, st, a);
+    if (d.math == 2) hipLaunchKernelGGL(gemm1x1_k32p_kernel<true>, dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(gemm1x1_k32p_kernel<false>, dim3(grid), dim3(512), 0, st, a);
     return 0;
 }

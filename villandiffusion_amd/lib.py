@@ -62,6 +62,7 @@ PROTOTYPES = {
     "vd_conv3_packed_bytes": (_i64, [_i32, _i32, _i32]),
     "vd_conv3_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
     "vd_conv3_pack_weights_multi": (_i32, [_vp, _i32, _i64, _vp]),
+    "vd_conv3_pack_weights_f16_multi": (_i32, [_vp, _i32, _i64, _vp]),
     "vd_weight_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
     "vd_col2im_s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
@@ -140,7 +141,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 8:
+    if lib.vd_abi_version() != 9:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

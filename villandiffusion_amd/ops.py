@@ -125,6 +125,9 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     d.pad = pad
     d.pool2 = int(pool2)
     d.math = math_mode
+    a_packed16 = None
+    if isinstance(a_packed, tuple):            # (split-precision operand, f16 operand): opt-in mixed precision, decided per problem below
+        a_packed, a_packed16 = a_packed
     if a_packed is not None:
         d.a_packed, d.a_packed_mpad = a_packed.data_ptr(), (M + 127) // 128 * 128
     d.gn_ss = _p(gn_ss)
@@ -147,7 +150,14 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         d.ws = _gemm_ws(need, D.device).data_ptr()
     elif FORCE_WS is not None:                 # diagnostic builds only (tools/k32p_stamps.py: the stamp buffer travels in the unused ws pointer)
         d.ws = FORCE_WS.data_ptr()
-    global LAST_GEMM_TILE
+    global LAST_GEMM_TILE, LAST_GEMM_MATH
+    if a_packed16 is not None and gn_part is None:
+        # f16 operands are read by the persistent 16x16x32 kernels only (vd_gemm_tile 18 / 19 with math = 2); every other problem keeps the
+        # split-precision operand
+        d.a_packed, d.math = a_packed16.data_ptr(), 2
+        if lib.vd_gemm_tile(C.byref(d)) not in (18, 19):
+            d.a_packed, d.math = a_packed.data_ptr(), math_mode
+    LAST_GEMM_MATH = d.math
     LAST_GEMM_TILE = lib.vd_gemm_tile(C.byref(d))            # kernel family the library picks for this problem (tests assert on it)
     GN_PART_WRITTEN = gn_part is not None and not pool2 and LAST_GEMM_TILE in (17, 18)
     if GN_PART_WRITTEN:
@@ -175,7 +185,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     if tl == 10:
         name = f"gemm_bx3_act_kernel<{int(a_mode == A_ROW)}, {int(b_mode == B_KCONTIG)}>"
     elif tl == 19:
-        name = "gemm1x1_k32p_kernel"
+        name = "gemm1x1_k32p_kernel<true>" if d.math == 2 else "gemm1x1_k32p_kernel<false>"
     elif tl in (9, 11, 13):
         name = "gemm_bx3_persist_kernel" if tl == 11 else f"gemm_bx3_kernel<{512 if tl == 13 else 256}>"
     elif tl == 17:
@@ -183,7 +193,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = f"conv3_k32_kernel<{d.OW}, {md}>"
     elif tl == 18:          # the persistent kernel: template width 16 (16x16 images) or 32 (8-row x 32-column segments of any image); image width beside it
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
-        name = f"conv3_k32p_kernel<{16 if d.OW == 16 else 32}, {md}, true, true>" + (f"@{d.OW}" if d.OW > 32 else "")
+        name = f"conv3_k32p_kernel<{16 if d.OW == 16 else 32}, {md}, true, true{', true' if d.math == 2 else ''}>" + (f"@{d.OW}" if d.OW > 32 else "")
     elif tl in (8, 12, 15, 16):
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
         name = f"conv3_bx3_kernel<{d.OW if d.OW <= 64 else 128}, {md}, {4 if tl == 15 else 2}, {256 if tl == 8 else 512}, 2>"
@@ -221,6 +231,26 @@ def conv3_pack_weights(w2d, M, Cc, transposed=False, out=None, taps=9):
     return out
 
 
+def conv3_pack_weights_f16(w2d, M, Cc, transposed=False, taps=9):
+    """f16 operand (vd_gemm_desc.math = 2) of ONE convolution -- tests and tools; the network packs all of them in one launch
+    (unet._PackedConvWeights(f16=True)).  Pass it to conv3x3 / conv1x1 / gemm as a_packed=(split-precision operand, this)."""
+    nbytes = _lib().vd_conv3_packed_bytes(M, Cc, taps) // 2
+    assert nbytes > 0 and w2d.is_contiguous(), (M, Cc, taps)
+    out = torch.empty(nbytes // 4, device=w2d.device, dtype=torch.int32)
+    rs, cs = (taps, M * taps) if transposed else (Cc * taps, taps)
+    mpad = (M + 127) // 128 * 128
+    tab = torch.tensor([[w2d.data_ptr(), out.data_ptr(), M, Cc, rs, cs, 0, taps]], dtype=torch.int64).to(w2d.device)
+    conv3_pack_weights_f16_multi(tab, 1, (mpad * (Cc // 16) * 2 + 255) // 256)
+    torch.cuda.current_stream(w2d.device).synchronize()       # the one-row table is a temporary
+    return out
+
+
+def conv3_pack_weights_f16_multi(table, n_jobs, total_blocks):
+    """The same job table, f16 operands (vd_gemm_desc.math = 2): half the bytes per job."""
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.numel() >= 8 * n_jobs
+    L.check(_lib().vd_conv3_pack_weights_f16_multi(_p(table), n_jobs, total_blocks, _s()), "vd_conv3_pack_weights_f16_multi")
+
+
 def conv3_pack_weights_multi(table, n_jobs, total_blocks):
     """table: device int64 [n_jobs, 8] = (W address, packed address, M, C, row_stride, chan_stride, first workgroup, 0)."""
     assert table.dtype == torch.int64 and table.is_contiguous() and table.numel() >= 8 * n_jobs
@@ -251,6 +281,7 @@ def bx3_pool2_eligible(M, Cc, OH, OW, nb) -> bool:
 
 GN_PART_WRITTEN = False
 LAST_GEMM_TILE = 0
+LAST_GEMM_MATH = 0
 FORCE_WS = None
 
 

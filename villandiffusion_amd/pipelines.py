@@ -55,7 +55,7 @@ class GraphedForward:
                     unet._run_forward(self.x, self.t, save=False)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self._keep = (ops.gemm_ws_buffer(dev, slot), getattr(unet, "_packed", None))     # buffers whose addresses are baked into the graph
+            self._keep = (ops.gemm_ws_buffer(dev, slot), getattr(unet, "_packed", None), getattr(unet, "_packed16", None))     # buffers whose addresses are baked into the graph
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: a HIP call from ANOTHER thread during capture (the RCCL watchdog of a DDP run whose rank 0 samples) must not abort it
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -70,8 +70,8 @@ class GraphedForward:
 
     def __call__(self, x, t):
         u = self.unet
-        if u._packed is not None:                         # weights changed since the last replay: rebuild the packed operands (one launch)
-            u._packed.refresh(False)
+        if hasattr(u, "refresh_packed"):                  # weights changed since the last replay: rebuild the packed operands (one launch)
+            u.refresh_packed(False)
         self.x.copy_(x)
         self.t.copy_(t)
         self.graph.replay()
@@ -192,11 +192,11 @@ class DiffusionPipeline:
         off0 = getattr(base, "_rng_offset", 0)
         main = torch.cuda.current_stream(dev)
         streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-        if getattr(unet, "_packed", None) is not None:
+        if hasattr(unet, "refresh_packed"):
             # ONE rebuild of the packed split-precision weights, on `main`, before any chunk stream branches off it: GraphedForward.__call__
             # refreshes on whichever stream is current and marks the version fresh, so a refresh left to chunk 0's stream would race with the
             # replays of chunks 1.. on their own streams (they would skip it and read the buffer while it is being rewritten).
-            unet._packed.refresh(False)
+            unet.refresh_packed(False)
         numel = max(c.numel() for c in inits)
         chunk_ids = list(range(len(inits))) if chunk_ids is None else [int(c) for c in chunk_ids]
         for first in range(0, len(inits), n_streams):

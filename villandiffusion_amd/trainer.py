@@ -34,15 +34,15 @@ class FusedAdam:
         self._partial = torch.empty(1024, device=model.flat_param.device, dtype=torch.float32)
         self.grad_norm_sq = torch.zeros(1, device=model.flat_param.device, dtype=torch.float32)
 
-    def step(self, lr: Optional[float] = None, grad_inv_scale: float = 1.0):
+    def step(self, lr: Optional[float] = None, grad_inv_scale: float = 1.0, need_norm: bool = False):
         m = self.model
         self.step_count += 1
         nsq = None
-        if self.max_grad_norm is not None:
+        if self.max_grad_norm is not None or need_norm:          # need_norm: the overflow guard of the f16 mode reads it (no clipping: max_norm = inf)
             ops.l2norm_sq(m.flat_grad, self._partial, self.grad_norm_sq)
             nsq = self.grad_norm_sq
         ops.adam_step(m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, nsq,
-                      float(self.max_grad_norm or 0.0), grad_inv_scale, self.lr if lr is None else lr, self.betas[0],
+                      float(self.max_grad_norm if self.max_grad_norm is not None else 3.0e38), grad_inv_scale, self.lr if lr is None else lr, self.betas[0],
                       self.betas[1], self.eps, self.step_count)
 
     def grad_norm(self, grad_inv_scale: float = 1.0) -> float:
@@ -123,7 +123,7 @@ class GraphedMicroStep:
         if _DEBUG:
             print("[graph] warm-up done", flush=True)
         net.flat_grad.copy_(keep)                         # the warm-up passes accumulated gradients: undo
-        self._keep = (ops.gemm_ws_buffer(dev, 0), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws)
+        self._keep = (ops.gemm_ws_buffer(dev, 0), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws, getattr(net, "_packed16", None))
         self.graph = torch.cuda.CUDAGraph()
         ops.capture_begin(dev)                            # job tables built during the capture are uploaded right after it (ops.upload_table)
         try:
@@ -155,7 +155,10 @@ class GraphedMicroStep:
 
     def __call__(self, x0, R, noise, t):
         net = self.net
-        if net._packed is not None:                       # weights changed since the last replay: rebuild the packed operands (one launch each)
+        if hasattr(net, "refresh_packed"):                # weights changed since the last replay: rebuild the packed operands (one launch each)
+            net.refresh_packed(False)
+            net.refresh_packed(True)
+        elif getattr(net, "_packed", None) is not None:
             net._packed.refresh(False)
             net._packed.refresh(True)
         self.x0.copy_(x0)
@@ -181,7 +184,15 @@ class Trainer:
         self.sched_step = 0                       # LambdaLR.last_epoch
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.n_buckets = n_allreduce_buckets
-        self.loss_fn.grad_scale = 1.0 / self.grad_accum
+        # f16 mixed-precision mode (model.conv_math == "f16", opt-in): the loss gradient is multiplied by `loss_scale` (a power of two: exact in
+        # f32) so that the input gradients survive their conversion to f16 operands, and divided out again inside the Adam kernel; a step whose
+        # gradient is not finite is skipped by the kernel and the scale halved at the next check (GradScaler semantics with a lazy host check:
+        # the norm is read back every `scale_check_every` optimiser steps, doubled again after `scale_growth_every` clean ones)
+        self.loss_scale = float(2 ** 12)
+        self.scale_check_every, self.scale_growth_every = 100, 2000
+        self._since_growth = 0
+        self.overflow_steps_seen = 0
+        self.loss_fn.grad_scale = self._scale() / self.grad_accum
         self._pending = []                        # async all-reduce handles of the current optimiser step
         self._sync_now = False
         # HIP-graph replay of the micro-step: on by default where a step is launch-bound (gradient accumulation = small micro-batches), single process
@@ -198,6 +209,22 @@ class Trainer:
         s, e = self.model.grad_buckets[i]
         self._pending.append(dist.all_reduce(self.model.flat_grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
+    def _scale(self) -> float:
+        return self.loss_scale if getattr(self.model, "conv_math", None) == "f16" else 1.0
+
+    def _check_scale(self):
+        """Lazy GradScaler: read the last gradient norm back once in a while; halve the scale after an overflow, double it after a clean stretch."""
+        self._since_growth += 1
+        if self._scale() == 1.0 or self.sched_step % self.scale_check_every:
+            return
+        if not math.isfinite(float(self.opt.grad_norm_sq)):
+            self.loss_scale = max(1.0, self.loss_scale * 0.5)
+            self.overflow_steps_seen += 1
+            self._since_growth = 0
+        elif self._since_growth >= self.scale_growth_every:
+            self.loss_scale = min(float(2 ** 24), self.loss_scale * 2.0)
+            self._since_growth = 0
+
     @property
     def lr(self) -> float:
         return self.base_lr * self.lr_lambda(self.sched_step)
@@ -207,6 +234,9 @@ class Trainer:
         """One micro-step; returns the (un-divided) loss tensor of this micro-batch."""
         sync = (self.micro + 1) % self.grad_accum == 0 or last_batch   # accelerate: sync on every G-th and on the last batch
         self._sync_now = sync and self.model.bucket_ready_hook is not None
+        if self.micro == 0:                                            # (the scale never changes inside an accumulation window)
+            self._step_scale = self._scale()
+        self.loss_fn.grad_scale = self._step_scale / self.grad_accum
         loss = self._graphed(batch, timesteps, noise, target_key, poison_key)
         if loss is None:
             loss = self.loss_fn.p_loss_by_keys(batch, self.model, target_latent_key=target_key, poison_latent_key=poison_key,
@@ -222,8 +252,9 @@ class Trainer:
             else:
                 allreduce_flat_grad(self.model.flat_grad, self.n_buckets)
             self._sync_now = False
-            self.opt.step(lr=self.lr, grad_inv_scale=1.0 / self.world)
+            self.opt.step(lr=self.lr, grad_inv_scale=1.0 / (self.world * self._step_scale), need_norm=self._step_scale != 1.0)
             self.sched_step += 1
+            self._check_scale()
             self.model.zero_grad()
         return loss
 

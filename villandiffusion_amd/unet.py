@@ -46,7 +46,7 @@ def _ensure_path(root: nn.Module, parts: Sequence[str]) -> nn.Module:
 
 # ----------------------------------------------------------------------------------------------------------- layers
 CONV_MATH_DEFAULT = os.environ.get("VILLAN_CONV_MATH", "bf16x3")
-if CONV_MATH_DEFAULT not in ("bf16x3", "f32"):
+if CONV_MATH_DEFAULT not in ("bf16x3", "f32", "f16"):
     raise ValueError(f"VILLAN_CONV_MATH must be 'bf16x3' or 'f32', got {CONV_MATH_DEFAULT!r}")
 
 
@@ -55,8 +55,9 @@ class _PackedConvWeights:
     weights as bf16 (hi, lo) pairs in MFMA fragment order -- one image for the forward convolution and one (transposed) for the
     stride-1 input gradient.  Each set is rebuilt in ONE launch when the weights have changed since it was built."""
 
-    def __init__(self, net):
+    def __init__(self, net, f16: bool = False):
         self.net = net
+        self.f16 = f16                                   # round 4, opt-in mixed precision: ONE f16 plane per operand (half the bytes), vd_gemm_desc.math = 2
         self.off = {False: {}, True: {}}                 # bwd? -> key -> (offset, n) in int32 elements
         self.jobs = {False: [], True: []}                # (key, source tensor getter, M, C, taps, row_stride, chan_stride)
         self.total = 0
@@ -79,7 +80,7 @@ class _PackedConvWeights:
                 plan.append((key + "::s2g", get, True, cin * 9, cout, 1, 1, cin * 9))
         for key, get, bwd, M, Cc, T, rs, cs in plan:
             if Cc % 16 == 0 and M >= 64:
-                n = (M + 127) // 128 * 128 * Cc * T
+                n = (M + 127) // 128 * 128 * Cc * T // (2 if f16 else 1)
                 self.off[bwd][key] = (self.total, n)
                 self.jobs[bwd].append((key, get, M, Cc, T, rs, cs))
                 self.total += n
@@ -112,38 +113,55 @@ class _PackedConvWeights:
                     blk += ((M + 127) // 128 * 128 * (Cc // 16) * 2 + 255) // 256
                 self.tables[bwd] = (torch.tensor(rows, dtype=torch.int64).to(self.buf.device), len(rows), blk)
             tab, nj, blk = self.tables[bwd]
-            ops.conv3_pack_weights_multi(tab, nj, blk)
+            (ops.conv3_pack_weights_f16_multi if self.f16 else ops.conv3_pack_weights_multi)(tab, nj, blk)
             self.key[bwd] = key
+
+
+def _split(net) -> bool:
+    """Contractions on the bf16 matrix cores: "bf16x3" (default), and "f16" -- the opt-in mixed-precision mode (round 4), which ADDITIONALLY runs
+    the full-size 3x3 / 1x1 forward and input-gradient contractions as single f16 products (everything else as in "bf16x3")."""
+    return getattr(net, "conv_math", "f32") in ("bf16x3", "f16")
+
+
+def _with_f16(net, pk, key, bwd):
+    """In "f16" mode the operand handed to ops.gemm is the pair (split-precision operand, f16 operand); ops.gemm picks per problem."""
+    if pk is None or getattr(net, "conv_math", "f32") != "f16":
+        return pk
+    p16 = getattr(net, "_packed16", None)
+    if p16 is None:
+        p16 = net._packed16 = _PackedConvWeights(net, f16=True)
+    v16 = p16.view(key, bwd)
+    return pk if v16 is None else (pk, v16)
 
 
 def _bx3_packed(net, prefix, bwd, M, Cc, OH, OW, mode):
     """The packed operand to hand to ops.conv3x3 for this call, or None (exact-f32 kernels)."""
-    if getattr(net, "conv_math", "f32") != "bf16x3" or not ops.bx3_eligible(M, Cc, OH, OW, mode):
+    if not _split(net) or not ops.bx3_eligible(M, Cc, OH, OW, mode):
         return None
     pk = getattr(net, "_packed", None)
     if pk is None:
         pk = net._packed = _PackedConvWeights(net)
-    return pk.view(prefix, bwd)
+    return _with_f16(net, pk.view(prefix, bwd), prefix, bwd)
 
 
 def _bx3_packed_1x1(net, key, bwd, M, K, NP, nb=None):
     """Packed operand of a 1x1 convolution / projection for ops.conv1x1 / ops.gemm(a_packed=...), or None (exact-f32 kernels)."""
-    if getattr(net, "conv_math", "f32") != "bf16x3" or not ops.gemm_bx3_eligible(M, K, NP, nb):
+    if not _split(net) or not ops.gemm_bx3_eligible(M, K, NP, nb):
         return None
     pk = getattr(net, "_packed", None)
     if pk is None:
         pk = net._packed = _PackedConvWeights(net)
-    return pk.view(key, bwd)
+    return _with_f16(net, pk.view(key, bwd), key, bwd)
 
 
 def _amath(net, M, K, NP) -> int:
     """vd_gemm_desc.math for a product of two activation matrices (attention scores / values and their gradients)."""
-    return int(getattr(net, "conv_math", "f32") == "bf16x3" and ops.gemm_bx3_act_eligible(M, K, NP))
+    return int(_split(net) and ops.gemm_bx3_act_eligible(M, K, NP))
 
 
 def _wgrad1x1_math(net, dy, x) -> int:
     """vd_wgrad_desc.math for a 1x1 weight gradient dW[M, C] = sum dy x^T."""
-    ok = getattr(net, "conv_math", "f32") == "bf16x3" and ops.wgrad_bx3_eligible(dy.shape[1], x.shape[1], dy.shape[2], dy.shape[3], B_PLAIN) \
+    ok = _split(net) and ops.wgrad_bx3_eligible(dy.shape[1], x.shape[1], dy.shape[2], dy.shape[3], B_PLAIN) \
         and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0
     return int(ok)
 
@@ -170,7 +188,7 @@ class _Conv:
     def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
         """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
         net = self.net
-        bx3 = getattr(net, "conv_math", "f32") == "bf16x3" and ops.wgrad_bx3_eligible(self.cout, self.cin, dout.shape[2], dout.shape[3],
+        bx3 = _split(net) and ops.wgrad_bx3_eligible(self.cout, self.cin, dout.shape[2], dout.shape[3],
                                                                                        self.mode) and x.stride(0) % 4 == 0
         net.wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=int(bx3))
         if not skip_bias:
@@ -286,7 +304,7 @@ class _Resnet:
         net = self.net
         B, _, H, W = x.shape
         dev = x.device
-        fuse = net.fuse_gn_inference if net.fuse_gn_inference is not None else (net.conv_math == "bf16x3")
+        fuse = net.fuse_gn_inference if net.fuse_gn_inference is not None else _split(net)
         if not save and fuse and ops.gn_fusable(x, self.cout) and self.cin * H * W // net.groups <= 12288 \
                 and self.cout * H * W // net.groups <= 12288:
             # inference: GroupNorm + SiLU folded into the convolutions' patch loaders -- a statistics pass (one read) replaces the
@@ -309,7 +327,7 @@ class _Resnet:
             else:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
             return None
-        if save and net.defer_gn_fwd and fuse and net.conv_math == "bf16x3" and ops.gn_fusable(x, self.cout) \
+        if save and net.defer_gn_fwd and fuse and _split(net) and ops.gn_fusable(x, self.cout) \
                 and self.cin % 32 == 0 and self.cout % 32 == 0 and self.cin * H * W // net.groups <= 12288 \
                 and self.cout * H * W // net.groups <= 12288:
             # training forward (round 4): GroupNorm + SiLU folded into the convolutions' loaders as in the no-grad path -- a statistics pass (one
@@ -415,7 +433,7 @@ class _Attn:
         ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", False, 3 * Cc, Cc, N, B))
         o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
-        if getattr(net, "conv_math", "f32") == "bf16x3" and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
+        if _split(net) and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
             # one launch: scores and probabilities stay in registers; P reaches HBM only when a backward pass will read it
             P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32) if save else None
             ops.attn_core_fwd(qkv, o, P, nh, dh, N, self.scale)
@@ -472,7 +490,7 @@ class _Attn:
                  b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N, B))
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
-        if getattr(net, "conv_math", "f32") == "bf16x3" and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
+        if _split(net) and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
             # dP, the softmax gradient and dq in one launch (dP never reaches HBM); dv and dk are products of the saved P / of dS
             dS = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
             ops.attn_core_bwd(qkv, P, o, do, dS, dqkv, nh, dh, N, self.scale)
@@ -761,6 +779,7 @@ class UNet2DModel(nn.Module):
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
         self._packed: Optional[_PackedConvWeights] = None
+        self._packed16: Optional[_PackedConvWeights] = None     # f16 operands of the opt-in mixed-precision mode (conv_math = "f16")
         self._wt_fresh = set()
         self.reset_parameters()
 
@@ -804,12 +823,20 @@ class UNet2DModel(nn.Module):
         self.weights_changed()
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
+    def refresh_packed(self, bwd: bool):
+        """Rebuild whatever packed operand sets exist (split-precision, f16) for the current weights -- what a captured graph's caller does before
+        a replay (the graph reads the packed buffers, it does not rebuild them)."""
+        for pk in (self._packed, self._packed16):
+            if pk is not None:
+                pk.refresh(bwd)
+
     def weights_changed(self):
         """Drop the packed split-precision operands.  They are rebuilt automatically after optimiser steps, `load_state_dict`,
         `reset_parameters` and any in-place torch op on a parameter (keyed on the flat buffer's version counter); call this after
         writing parameters behind autograd's back (`p.data.copy_(...)`, raw pointers), which no counter sees."""
-        if self._packed is not None:
-            self._packed.key = {False: None, True: None}
+        for pk in (self._packed, self._packed16):
+            if pk is not None:
+                pk.key = {False: None, True: None}
 
     def to(self, *args, **kwargs):          # parameters are views of one flat device buffer: never re-materialise
         return self
