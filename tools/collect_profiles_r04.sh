@@ -9,8 +9,8 @@ O=gpurun_out/r04p
 mkdir -p $O
 export TMPDIR=/tmp
 VD_BENCH_DETAIL=$O/bench_detail.json timeout 1200 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python3 bench.py --mode train --serial-wgrad --no-cpu --no-exact --no-roofline > $O/bench_train_under_rocprof.json 2> $O/stats_train.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sample -- python3 bench.py --mode sample --no-cpu --no-roofline --no-secondary --sample-images 128 > $O/bench_sample_under_rocprof.json 2> $O/stats_sample.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python3 bench.py --mode train --serial-wgrad --no-cpu --no-exact --no-f16 --no-roofline > $O/bench_train_under_rocprof.json 2> $O/stats_train.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sample -- python3 bench.py --mode sample --no-cpu --no-f16 --no-roofline --no-secondary --sample-images 128 > $O/bench_sample_under_rocprof.json 2> $O/stats_sample.err
 for w in train sample; do
   f=$(find $O/stats_$w -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then cp $f $O/${w}_kernel_stats.csv; fi
@@ -18,21 +18,21 @@ for w in train sample; do
 done
 if [ -z "${SKIP_PMC:-}" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_$c.err
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-f16 --no-roofline > /dev/null 2> $O/pmc_$c.err
     python3 tools/pmc_summary.py $O/pmc_$c > $O/pmc_$c.json
     rm -rf $O/pmc_$c
   done
-  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_mfma.err
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-f16 --no-roofline > /dev/null 2> $O/pmc_mfma.err
   python3 tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma.json
   rm -rf $O/pmc_mfma
 fi
 if [ -z "${SKIP_PMC:-}" ]; then          # the sampler's dispatches: traffic and MFMA counters of a 30-step DDPM loop (eager launches: one dispatch per kernel)
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmcs_$c -- python3 bench.py --mode sample --sample-steps 30 --sample-images 128 --no-cpu --no-roofline --no-secondary > /dev/null 2> $O/pmcs_$c.err
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmcs_$c -- python3 bench.py --mode sample --sample-steps 30 --sample-images 128 --no-cpu --no-f16 --no-roofline --no-secondary > /dev/null 2> $O/pmcs_$c.err
     python3 tools/pmc_summary.py $O/pmcs_$c > $O/pmc_sample_$c.json
     rm -rf $O/pmcs_$c
   done
-  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcs_mfma -- python3 bench.py --mode sample --sample-steps 30 --sample-images 128 --no-cpu --no-roofline --no-secondary > /dev/null 2> $O/pmcs_mfma.err
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcs_mfma -- python3 bench.py --mode sample --sample-steps 30 --sample-images 128 --no-cpu --no-f16 --no-roofline --no-secondary > /dev/null 2> $O/pmcs_mfma.err
   python3 tools/pmc_summary.py $O/pmcs_mfma > $O/pmc_sample_mfma.json
   rm -rf $O/pmcs_mfma
 fi
@@ -40,7 +40,7 @@ python3 tools/shape_probe.py > $O/shape_probe.txt 2>&1
 # sustained matrix-pipe rates from registers / from LDS / with random operand bits (hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o build/mfma_peak)
 if [ -x tools/mfma_peak ]; then timeout 300 tools/mfma_peak > $O/mfma_sustained.txt 2>&1; fi
 if [ -z "${SKIP_PMC:-}" ]; then
-  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_wait -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-roofline > /dev/null 2> $O/pmc_wait.err
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_wait -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 --no-cpu --no-exact --no-f16 --no-roofline > /dev/null 2> $O/pmc_wait.err
   python3 tools/pmc_summary.py $O/pmc_wait > $O/pmc_wait.json
   rm -rf $O/pmc_wait
 fi

@@ -193,7 +193,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = f"conv3_k32_kernel<{d.OW}, {md}>"
     elif tl == 18:          # the persistent kernel: template width 16 (16x16 images) or 32 (8-row x 32-column segments of any image); image width beside it
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
-        name = f"conv3_k32p_kernel<{16 if d.OW == 16 else 32}, {md}, true, true{', true' if d.math == 2 else ''}>" + (f"@{d.OW}" if d.OW > 32 else "")
+        name = f"conv3_k32p_kernel<{16 if d.OW == 16 else 32}, {md}, true, true, {'true' if d.math == 2 else 'false'}>" + (f"@{d.OW}" if d.OW > 32 else "")
     elif tl in (8, 12, 15, 16):
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
         name = f"conv3_bx3_kernel<{d.OW if d.OW <= 64 else 128}, {md}, {4 if tl == 15 else 2}, {256 if tl == 8 else 512}, 2>"
