@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 9
+#define VD_ABI_VERSION 10
 #define VD_EINVAL (-22)
 
 int vd_abi_version(void);
@@ -117,6 +117,11 @@ typedef struct vd_gemm_desc {
                                 [B][NP / 256][M][2] = (sum, sum of squares) of the FINAL result (after bias / rowadd / residual) of channel m
                                 over each 256-pixel tile -- the GroupNorm that follows (ResnetBlock2D: conv1 -> norm2) gets its statistics
                                 from vd_groupnorm_stats_from_partials() instead of a read of the whole tensor.  Fixed-order sums.           */
+    float* act_out;          /* optional OUTPUT of the persistent 16x16x32 3x3 convolution with gn_ss (vd_gemm_tile() == 18, else VD_EINVAL): the
+                                normalised activation silu(x * scale + shift) the loader computes anyway, written once per element
+                                ([nb][C][H][W], batch stride act_bstride) by the workgroups of the first channel tile.  The TRAINING forward
+                                saves it for the weight gradient instead of running a separate GroupNorm + SiLU pass (round 4).           */
+    int64_t act_bstride;
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);

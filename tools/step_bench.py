@@ -74,6 +74,15 @@ tot = sum(v[2] for v in agg.values())
 print(f"profiled kernels: {tot:.1f} ms, {sum(v[1] for v in agg.values()) / tot / 1e9:.1f} TF avg")
 for nm, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:int(os.environ.get("STEP_BENCH_TOP", 14))]:
     print(f"  {nm:55s} n={v[0]:3d} {v[2]:8.2f} ms {v[1] / v[2] / 1e9:6.1f} TF")
+if os.environ.get("STEP_BENCH_SHAPES"):                               # GEMM-family launches by (kernel, M, K, NP, batch, OH, OW)
+    ag2 = {}
+    for r in rec:
+        if "shape" in r:
+            d = ag2.setdefault((r["name"],) + tuple(r["shape"]), [0, 0.0, 0.0])
+            d[0] += 1; d[1] += r["flops"]; d[2] += r["e0"].elapsed_time(r["e1"])
+    print("by shape (kernel, M, K, NP, batch, OH, OW):")
+    for k, v in sorted(ag2.items(), key=lambda kv: -kv[1][2])[:int(os.environ["STEP_BENCH_SHAPES"])]:
+        print(f"  {k[0]:45s} {str(k[1:]):40s} n={v[0]:3d} {v[2]:8.3f} ms {v[1] / v[2] / 1e9:6.1f} TF")
 
 # ---- BASELINE config #1 shape: batch 4 with gradient accumulation (a micro-step is launch-bound when launched eagerly) ----
 if name == "cifar10" and os.environ.get("STEP_BENCH_MICRO", "1") == "1":

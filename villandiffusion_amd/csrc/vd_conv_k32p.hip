@@ -138,8 +138,11 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     unsigned poff[P_IT];
     unsigned pmask = 0;
     __amdgpu_buffer_rsrc_t xrs;
+    __amdgpu_buffer_rsrc_t ors;                                  // MODE 3, d.act_out: the normalised activation's image of the tile's batch item
+    unsigned pinner = 0;                                          // ... items that are pixels OF the tile (not its halo): written by this workgroup
+    bool act_store = false;
     const float* __restrict__ ssg = nullptr;
-    auto set_patch_tile = [&](int b0_, int y0_, int x0_) {       // per-tile source offsets of the patch items (fixed for the tile's chunk pairs)
+    auto set_patch_tile = [&](int b0_, int y0_, int x0_, int m0_) {       // per-tile source offsets of the patch items (fixed for the tile's chunk pairs)
         pmask = 0;
 #pragma unroll
         for (int i = 0; i < P_IT; ++i) {
@@ -152,6 +155,16 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
             }
             poff[i] = ok ? 4u * (unsigned)(cq * 8 * HWs + iy * d.W + ix) : 0xFFFFFFFFu;
             pmask |= (ok ? 1u : 0u) << i;
+        }
+        act_store = MODE == 3 && d.act_out != nullptr && m0_ == 0;      // every element once: the workgroups of the first channel tile
+        if (act_store) {
+            pinner = 0;
+#pragma unroll
+            for (int i = 0; i < P_IT; ++i) {
+                const bool in = ((pmask >> i) & 1u) && ppy[i] >= 1 && ppy[i] <= TR && ppx[i] >= 1 && ppx[i] <= TW;
+                pinner |= (in ? 1u : 0u) << i;
+            }
+            ors = __builtin_amdgcn_make_buffer_rsrc(d.act_out + (int64_t)b0_ * d.act_bstride, 0, 0xFFFFFFF0, 0x00020000);
         }
         xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B + (int64_t)b0_ * d.b_bstride), 0, 0xFFFFFFF0, 0x00020000);
         if (MODE == 3) ssg = d.gn_ss + (int64_t)b0_ * 2 * d.C + 16 * cq;
@@ -209,6 +222,11 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                 for (int j = 0; j < 8; ++j) {
                     const float z = rp[i][j] * ss[2 * j] + ss[2 * j + 1];
                     rp[i][j] = z * sigmoidf_(z);
+                }
+                if (act_store && ((pinner >> i) & 1u)) {          // the training forward keeps silu(gn(x)) for the weight gradient: same offsets as the loads
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rp[i][j]), ors, poff[i], 4u * (unsigned)((cp * 32 + j) * HWs), 0);
                 }
             }
 #pragma unroll
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     int m0n = m0, b0n = b0, y0n = y0, x0n = x0, tixn = tix;
     if (has_next) decode(id + G8, m0n, b0n, y0n, x0n, tixn);
 
-    set_patch_tile(b0, y0, x0);
+    set_patch_tile(b0, y0, x0, m0);
     load_a(m0, 0, 0, 0);
     load_p(0);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * P_IT) : "memory");        // the DMA stage (issued first) has landed
@@ -512,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                     if (more) {
                         load_p(cp + 1);
                     } else {                                      // the next tile's first patch
-                        set_patch_tile(b0n, y0n, x0n);
+                        set_patch_tile(b0n, y0n, x0n, m0n);
                         load_p(0);
                     }
                 }
@@ -609,6 +627,7 @@ bool vd_conv3_k32p_eligible(const vd_gemm_desc& d) {
     if (d.OW == 16 && d.OH != 16) return false;
     if (d.b_mode == VD_B_CONV3_UP && (d.H * 2 != d.OH || d.W * 2 != d.OW)) return false;
     if (d.gn_ss && d.b_mode != VD_B_CONV3) return false;
+    if (d.act_out && (!d.gn_ss || (d.act_bstride & 3) || d.math == 2)) return false;
     const int ldd_mult = d.pool2 ? 2 : 4;
     if ((d.ldd % ldd_mult) || (d.d_bstride % ldd_mult) || (((uintptr_t)d.D) & (4 * ldd_mult - 1))) return false;
     if (d.residual && ((d.res_bstride & 3) || (((uintptr_t)d.residual) & 15))) return false;

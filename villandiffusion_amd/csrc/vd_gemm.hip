@@ -2165,6 +2165,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(!d.gn_ss || tile == 4 || tile == 6 || tile == 8 || tile == 12 || tile == 15 || tile == 17 || tile == 18,
                "vd_gemm: gn_ss (GroupNorm folded into the loader) needs the patch-staged 3x3 kernel (OW 16/32, C %% 8 == 0, M >= 64)");
     VD_REQUIRE(!d.pool2 || tile == 8 || tile == 12 || tile == 17 || tile == 18, "vd_gemm: pool2 needs the split-precision 3x3 kernel (VD_B_CONV3_T with a_packed)");
+    VD_REQUIRE(!d.act_out || (tile == 18 && d.gn_ss), "vd_gemm: act_out is written by the persistent 16x16x32 3x3 convolution with gn_ss only (vd_gemm_tile() == 18)");
     VD_REQUIRE(!d.gn_part || ((tile == 17 || tile == 18) && !d.pool2),
                "vd_gemm: gn_part is written by the 16x16x32 split-precision 3x3 kernels only (vd_gemm_tile() == 17 / 18)");
     hipStream_t st = (hipStream_t)stream;

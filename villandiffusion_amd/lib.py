@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32), ("nb2", _i32),
                 ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32), ("pool2", _i32),
                 ("kh", _i32), ("kw", _i32), ("conv_stride", _i32), ("pad_h", _i32), ("pad_w", _i32), ("act", _i32),
-                ("gn_part", _vp)]
+                ("gn_part", _vp), ("act_out", _vp), ("act_bstride", _i64)]
 
 
 class WgradDesc(C.Structure):
@@ -141,7 +141,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 9:
+    if lib.vd_abi_version() != 10:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

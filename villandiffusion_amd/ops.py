@@ -114,7 +114,7 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False, convg=None, act=0, gn_part=None):
+         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False, convg=None, act=0, gn_part=None, act_out=None):
     """gn_part: optional [B, NP // 256, M, 2] buffer for the per-tile channel sums of the result (vd_gemm_desc.gn_part); it is filled only when the
     launch goes to the 16x16x32 split-precision convolution -- ops.GN_PART_WRITTEN tells the caller right after the call."""
     global GN_PART_WRITTEN
@@ -159,6 +159,16 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
             d.a_packed, d.math = a_packed.data_ptr(), math_mode
     LAST_GEMM_MATH = d.math
     LAST_GEMM_TILE = lib.vd_gemm_tile(C.byref(d))            # kernel family the library picks for this problem (tests assert on it)
+    global ACT_OUT_WRITTEN
+    ACT_OUT_WRITTEN = False
+    if act_out is not None and gn_ss is not None and a_packed16 is None:
+        # side output of the persistent kernel's GroupNorm-folding loader (vd_gemm_desc.act_out): taken only where that kernel runs the problem
+        d.act_out, d.act_bstride = act_out.data_ptr(), _img(act_out)[4]
+        if lib.vd_gemm_tile(C.byref(d)) == 18:
+            ACT_OUT_WRITTEN = True
+        else:
+            d.act_out, d.act_bstride = None, 0
+        LAST_GEMM_TILE = lib.vd_gemm_tile(C.byref(d))
     GN_PART_WRITTEN = gn_part is not None and not pool2 and LAST_GEMM_TILE in (17, 18)
     if GN_PART_WRITTEN:
         assert gn_part.is_contiguous() and gn_part.numel() >= (N // 256) * M * 2
@@ -208,7 +218,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = "conv3_fewout_kernel<4>" if few else f"conv3_smallm_kernel<{32 if d.W % 32 == 0 else 16}, 4>"
     else:
         name = f"gemm_kernel<{_TILE_NAMES[tl]},{'ROW' if a_mode == A_ROW else 'COL'},{_B_NAMES[b_mode]}>"
-    _PROF.append({"name": name, "flops": flops, "bytes": nbytes, "e0": e0, "e1": e1, "kind": "mfma"})
+    _PROF.append({"name": name, "flops": flops, "bytes": nbytes, "e0": e0, "e1": e1, "kind": "mfma", "shape": (M, K, d.NP, N // d.NP, d.OH, d.OW)})
     return D
 
 
@@ -280,13 +290,14 @@ def bx3_pool2_eligible(M, Cc, OH, OW, nb) -> bool:
 
 
 GN_PART_WRITTEN = False
+ACT_OUT_WRITTEN = False
 LAST_GEMM_TILE = 0
 LAST_GEMM_MATH = 0
 FORCE_WS = None
 
 
 def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, residual=None, accumulate=False, tile=0, debug=0,
-            pad=0, gn_ss=None, a_packed=None, pool2=False, gn_part=None):
+            pad=0, gn_ss=None, a_packed=None, pool2=False, gn_part=None, act_out=None):
     """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9].
     pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1).
     pool2 (B_CONV3_T with a_packed only): `out` has HALF the resolution and receives the 2x2 block sums of the result."""
@@ -307,7 +318,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
                 ldd=OHo * OWo, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
-                pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2, gn_part=gn_part)
+                pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2, gn_part=gn_part, act_out=act_out)
 
 
 def conv2d_general(x, w2d, bias, out, kh, kw, stride=1, pad_h=0, pad_w=0, relu=False):

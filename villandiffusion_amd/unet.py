@@ -177,13 +177,13 @@ class _Conv:
     def w2d(self):
         return self.net.P[self.prefix + ".weight"].view(self.cout, self.cin * 9)
 
-    def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None, gn_ss=None, gn_part=None):
+    def fwd(self, x, out, rowadd=None, rowadd_bstride=0, residual=None, gn_ss=None, gn_part=None, act_out=None):
         """gn_part: buffer for the per-tile channel sums of `out` (ops.conv3x3); ops.GN_PART_WRITTEN says whether this launch filled it."""
         pk = _bx3_packed(self.net, self.prefix, False, self.cout, self.cin, out.shape[2], out.shape[3], self.mode)
         if gn_ss is not None and (out.shape[3] not in (16, 32) or self.mode != B_CONV3):
             pk = None                                      # the folded-GroupNorm loader of the split-precision kernel: 16x16 / 32x32 only
         return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
-                           rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk, gn_part=gn_part)
+                           rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk, gn_part=gn_part, act_out=act_out)
 
     def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
         """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
@@ -262,14 +262,15 @@ class _Norm:
         ops.groupnorm_fwd(x, self.net.P[self.prefix + ".weight"], self.net.P[self.prefix + ".bias"], y, mean, torch.empty_like(mean),
                           self.groups, self.net.eps, self.silu)
 
-    def stats_from_partials(self, part, tiles, B, HW):
+    def stats_from_partials(self, part, tiles, B, HW, full=False):
         """stats() of a tensor whose producing convolution left its per-tile channel sums in `part` (vd_gemm_desc.gn_part)."""
         net = self.net
         ss = torch.empty((B, self.ch, 2), device=part.device, dtype=torch.float32)
         mean = torch.empty(B * self.groups, device=part.device, dtype=torch.float32)
-        ops.groupnorm_stats_from_partials(part, tiles, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], ss, mean,
-                                          torch.empty_like(mean), HW, self.groups, net.eps)
-        return ss
+        rstd = torch.empty_like(mean)
+        ops.groupnorm_stats_from_partials(part, tiles, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], ss, mean, rstd, HW,
+                                          self.groups, net.eps)
+        return (ss, mean, rstd) if full else ss
 
     def bwd(self, dy, x, mean, rstd, dx, extra=None, extra2=None, rowsum=None):
         """extra / extra2: residual gradients added into dx; rowsum ([B, C] view, row stride free): per-image channel sums of the dx
@@ -327,6 +328,37 @@ class _Resnet:
             else:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
             return None
+        if save and net.fold_gn_train and fuse and net.conv_math == "bf16x3" and not net.defer_gn_fwd and ops.gn_fusable(x, self.cout) \
+                and self.cin % 32 == 0 and self.cout % 32 == 0 and self.cin * H * W // net.groups <= 12288 \
+                and self.cout * H * W // net.groups <= 12288:
+            # Training forward without a normalise pass (round 4): the persistent convolution's loader applies GroupNorm + SiLU (as in the no-grad
+            # path) and WRITES the normalised activation it computes anyway (vd_gemm_desc.act_out) -- the operand the weight gradient needs;
+            # norm2's statistics come out of conv1's epilogue (gn_part), norm1's from a statistics pass (one read).  Per resnet: two normalise
+            # passes (read + write each) become one read; mean / rstd saved for the backward are the ones the forward used.
+            tiles = (H * W) // 256
+            ss1, m1, r1 = self.norm1.stats(x, full=True)
+            a1 = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+            h1 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
+            part = torch.empty((B, tiles, self.cout, 2), device=dev, dtype=torch.float32) if tiles > 0 else None
+            self.conv1.fwd(x, h1, rowadd=st.temb_all[:, self.temb_off:], rowadd_bstride=st.temb_all.stride(0), gn_ss=ss1, gn_part=part, act_out=a1)
+            wrote_a1, wrote_part = ops.ACT_OUT_WRITTEN, part is not None and ops.GN_PART_WRITTEN
+            if not wrote_a1:                                      # (a grid the persistent kernel does not take: small batches)
+                m1, r1 = self.norm1.fwd(x, a1)
+            if wrote_part:
+                ss2, m2, r2 = self.norm2.stats_from_partials(part, tiles, B, H * W, full=True)
+            else:
+                ss2, m2, r2 = self.norm2.stats(h1, full=True)
+            a2 = torch.empty_like(h1)
+            if self.has_sc:
+                ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
+                            net.P[self.prefix + ".conv_shortcut.bias"], out,
+                            a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W, B))
+                self.conv2.fwd(h1, out, residual=out, gn_ss=ss2, act_out=a2)
+            else:
+                self.conv2.fwd(h1, out, residual=x, gn_ss=ss2, act_out=a2)
+            if not ops.ACT_OUT_WRITTEN:
+                m2, r2 = self.norm2.fwd(h1, a2)
+            return (x, a1, m1, r1, h1, a2, m2, r2)
         if save and net.defer_gn_fwd and fuse and _split(net) and ops.gn_fusable(x, self.cout) \
                 and self.cin % 32 == 0 and self.cout % 32 == 0 and self.cin * H * W // net.groups <= 12288 \
                 and self.cout * H * W // net.groups <= 12288:
@@ -774,6 +806,9 @@ class UNet2DModel(nn.Module):
         # recomputation move MORE bytes than the normalise pass they replace, and on a power-bound chip an HBM-bound pass running beside the
         # MFMA-bound kernels is not free (the clock drops for both)
         self.defer_gn_fwd = os.environ.get("VILLAN_DEFER_GN_FWD", "0") != "0"
+        # round 4: training forward of the 16x16 / 32x32 resnets without normalise passes -- the convolution's GroupNorm-folding loader writes
+        # silu(gn(x)) as a side output, norm2's statistics come from conv1's epilogue.  Opt-in: measured +0.2 ms / step (profiles/r04_gn_actout_ab.txt)
+        self.fold_gn_train = os.environ.get("VILLAN_FOLD_GN_TRAIN", "0") != "0"
         self._gn_jobs = []
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
