@@ -276,6 +276,20 @@ int vd_attn_core_fwd(const float* qkv, float* out, float* P, int B, int heads, i
 int vd_attn_core_bwd(const float* qkv, const float* P, const float* out, const float* dout, float* dS, float* dqkv, int B, int heads,
                      int head_dim, int N, float scale, void* stream);
 
+/* K4 flash (round 4; same reference code as above, multi-head blocks with MORE than 256 tokens -- the 32x32-token level of the
+ * `LDM-CELEBA-HQ-256` UNet, reference model.py:706-776): the N x N score matrix never reaches HBM.
+ *   head_dim == 32, N a multiple of 256 (N >= 256); qkv [B][3C][N] with batch stride qkv_bstride, out [B][C][N] (out_bstride).
+ * vd_attn_flash_fwd: online softmax over 256-key blocks; lse [B*heads][N] = log sum_j exp(scale s_ji) is written when non-NULL
+ *   (the backward pass needs it; NULL in the no-grad path).
+ * vd_attn_flash_bwd: two launches -- (1) dq and delta_i = sum_c dout[c][i] out[c][i] (delta: [B*heads][N] scratch, written), with
+ *   P = exp(scale s - lse_i) recomputed per key block; (2) dk and dv, the transposed walk (a workgroup owns 128 keys).  All three
+ *   slices of dqkv [B][3C][N] are written (no accumulation).  Other shapes -> VD_EINVAL. */
+int vd_attn_flash_fwd(const float* qkv, float* out, float* lse, int B, int heads, int head_dim, int N, float scale, int64_t qkv_bstride,
+                      int64_t out_bstride, void* stream);
+int vd_attn_flash_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv, int B, int heads,
+                      int head_dim, int N, float scale, int64_t qkv_bstride, int64_t out_bstride, int64_t dout_bstride,
+                      int64_t dqkv_bstride, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K3 -- timestep embedding + small elementwise helpers.
  * ------------------------------------------------------------------------------------------ */

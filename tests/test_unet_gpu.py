@@ -268,6 +268,20 @@ def test_multihead_attention_config_matches_oracle():
     _fwd_bwd_parity(cfg, B=3)
 
 
+def test_flash_attention_config_matches_oracle(monkeypatch):
+    """head_dim 32 at 32x32 tokens (the shape of BASELINE config #5's first attention level): the blocks run vd_attn_flash_fwd / _bwd
+    (score matrix never in HBM, lse saved instead of P) and the network still matches the oracle, forward and every parameter gradient."""
+    from villandiffusion_amd import ops
+    calls = {"fwd": 0, "bwd": 0}
+    f0, b0 = ops.attn_flash_fwd, ops.attn_flash_bwd
+    monkeypatch.setattr(ops, "attn_flash_fwd", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), f0(*a, **k))[1])
+    monkeypatch.setattr(ops, "attn_flash_bwd", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), b0(*a, **k))[1])
+    cfg = dict(sample_size=64, block_out_channels=(32, 64), attention_head_dim=32, layers_per_block=1, norm_num_groups=8,
+               down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
+    _fwd_bwd_parity(cfg, B=2)
+    assert calls["fwd"] >= 4 and calls["bwd"] >= 4, calls
+
+
 def test_ldm_style_config_matches_oracle():
     """The switches of the CompVis/ldm-celebahq-256 UNet (BASELINE config #5) at a small size: symmetric downsample padding,
     flipped sin/cos, freq_shift 0, eps 1e-5, head_dim attention in 3 of 4 levels."""

@@ -2077,7 +2077,20 @@ int launch_wgrad_t(const vd_wgrad_desc& d, int splits, int kk_per, hipStream_t s
 
 }  // namespace
 
+#ifdef VD_WG_STAMPS
+extern "C" int vd_wg_stamps_set(void* buf) {          // diagnostic build only: per-wave stamp buffer of wgrad_bx3_body ([blocks][4 waves][12] u64), or NULL
+    unsigned long long* p = (unsigned long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamps), &p, sizeof(p));
+}
+#endif
+
 extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
+    if (desc && desc->a_packed && !bx3_eligible(*desc) && gemm_bx3_eligible(*desc) && desc->math != 2) {
+        if (vd_gemm_tile(desc) != 9) return 0;
+        int splits, st_per;
+        gemm_bx3_plan(*desc, splits, st_per);
+        return splits > 1 ? (int64_t)splits * desc->M * desc->N : 0;
+    }
     if (desc && desc->a_packed) {
         if (!bx3_eligible(*desc)) return 0;
         int splits, c_per;
@@ -2181,13 +2194,18 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 19: rc = vd_launch_gemm1x1_k32p(d, st) == 0 ? 0 : VD_EINVAL; break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 13:
-            hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d);
+            hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d, 1 << 30);
             rc = 0;
             break;
-        case 9:
-            hipLaunchKernelGGL(gemm_bx3_kernel<256>, dim3(vd_cdiv(d.M, 128) * (d.N / 128)), dim3(NT), 0, st, d);
+        case 9: {
+            int splits, st_per;
+            gemm_bx3_plan(d, splits, st_per);
+            VD_REQUIRE(splits == 1 || d.ws, "vd_gemm: split-K 1x1 launch needs the workspace (vd_gemm_ws_floats)");
+            hipLaunchKernelGGL(gemm_bx3_kernel<256>, dim3(vd_cdiv(d.M, 128) * (d.N / 128), splits), dim3(NT), 0, st, d, st_per);
+            if (splits > 1) launch_splitk_epilogue(d, splits, st);
             rc = 0;
             break;
+        }
         case 11:
             hipLaunchKernelGGL(gemm_bx3_persist_kernel, dim3(512), dim3(NT), 0, st, d, vd_cdiv(d.M, 128) * (d.N / 128));
             rc = 0;
@@ -2419,7 +2437,7 @@ static int wgrad_group_class(const vd_wgrad_desc& d) {
 extern "C" int vd_conv_wgrad_group_class(const vd_wgrad_desc* desc) { return desc ? wgrad_group_class(*desc) : 0; }
 extern "C" int64_t vd_conv_wgrad_group_job_bytes(void) { return (int64_t)sizeof(vd_wgrad_job); }
 // Which kernel vd_conv_wgrad_group_launch runs for a class: 9 = wgrad9_group_kernel (all nine taps per workgroup), 32 = wgrad_k32_group_kernel
-// (opt-in 16x16x32 one-tap-row kernel), 0 = wgrad_bx3_group_kernel / wgrad1x1_bx3_group_kernel (profiling names, tests).
+// (16x16x32 one-tap-row kernel, the default where it applies), 0 = wgrad_bx3_group_kernel / wgrad1x1_bx3_group_kernel (profiling names, tests).
 extern "C" int vd_conv_wgrad_group_variant(int cls) {
     if (wgrad9_class(cls)) return 9;
     if (cls == 1000) return wgrad1x1_wide_enabled() ? 256 : 0;
@@ -2466,7 +2484,9 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     static const int cap9 = getenv("VD_WGRAD9_KCAP") ? atoi(getenv("VD_WGRAD9_KCAP")) : 128;
     static const int tw = getenv("VD_W1X1_WIDE_TARGET") ? atoi(getenv("VD_W1X1_WIDE_TARGET")) : 256;
     static const int capw = getenv("VD_W1X1_WIDE_KCAP") ? atoi(getenv("VD_W1X1_WIDE_KCAP")) : 64;
-    const int target = wide1 ? tw : (one ? t1 : (nine ? t9 : t3));
+    const bool k32 = !one && !nine && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled();      // two workgroups per CU: 512 resident slots
+    static const int t32 = getenv("VD_WGRAD_K32_TARGET") ? atoi(getenv("VD_WGRAD_K32_TARGET")) : 512;
+    const int target = wide1 ? tw : (one ? t1 : (nine ? t9 : (k32 ? t32 : t3)));
     const int min_ks = one ? (wide1 ? 8 : 4) : 8;
     int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
     const int cap = wide1 ? capw : (one ? cap1 : (nine ? cap9 : cap3));

@@ -683,8 +683,13 @@ __global__ __launch_bounds__(256) void gn_chunk_bwd_apply_kernel(const float* __
                                                                  float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws,
                                                                  const float* __restrict__ part, int C, int HW, int G, int S,
                                                                  int apply_silu, int64_t dy_bs, int64_t x_bs, int64_t ex_bs,
-                                                                 int64_t dx_bs) {
+                                                                 int64_t dx_bs, const float* __restrict__ extra2, int64_t e2_bs,
+                                                                 float* __restrict__ rs_part) {
+    // extra2 / rs_part (round 4): the second residual gradient and the per-chunk sums of dx (the bias-gradient rows of the producing
+    // convolution; gn_chunk_rowsum_kernel adds a channel's chunks in fixed order) ride in this pass instead of vd_add_strided + vd_rowsum
+    // passes over dx (3 + 1 tensor sweeps at 256x256 images).
     __shared__ float ch_s1[64], ch_s2[64];
+    __shared__ float red[4];
     const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
     const int b = bg / G, g = bg - b * G;
     const int cpg = C / G;
@@ -719,14 +724,17 @@ __global__ __launch_bounds__(256) void gn_chunk_bwd_apply_kernel(const float* __
     const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff) + (int64_t)sc * c4;
     const f32x4* __restrict__ d4 = reinterpret_cast<const f32x4*>(dy + (int64_t)b * dy_bs + goff) + (int64_t)sc * c4;
     const f32x4* __restrict__ e4 = extra ? reinterpret_cast<const f32x4*>(extra + (int64_t)b * ex_bs + goff) + (int64_t)sc * c4 : nullptr;
+    const f32x4* __restrict__ f4 = extra2 ? reinterpret_cast<const f32x4*>(extra2 + (int64_t)b * e2_bs + goff) + (int64_t)sc * c4 : nullptr;
     f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(dx + (int64_t)b * dx_bs + goff) + (int64_t)sc * c4;
     const float mean = mean_in[bg], rstd = rstd_in[bg];
     const int c = g * cpg + sc / spc;
     const float ga = gamma[c], be = beta[c];
+    float rs = 0.f;
     for (int idx = tid; idx < c4; idx += 256) {
         const f32x4 xv = x4[idx], dv = d4[idx];
-        f32x4 ev = {0.f, 0.f, 0.f, 0.f}, o;
+        f32x4 ev = {0.f, 0.f, 0.f, 0.f}, fv = {0.f, 0.f, 0.f, 0.f}, o;
         if (e4) ev = e4[idx];
+        if (f4) fv = f4[idx];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (xv[j] - mean) * rstd;
@@ -735,10 +743,29 @@ __global__ __launch_bounds__(256) void gn_chunk_bwd_apply_kernel(const float* __
                 const float z = xh * ga + be, sg = sigmoidf_(z);
                 dz *= sg * (1.f + z * (1.f - sg));
             }
-            o[j] = rstd * (dz * ga - m1 - xh * m2) + ev[j];
+            o[j] = (rstd * (dz * ga - m1 - xh * m2) + ev[j]) + fv[j];
         }
+        rs += (o[0] + o[1]) + (o[2] + o[3]);
         o4[idx] = o;
     }
+    if (rs_part) {                                        // block-uniform
+        rs = block_sum_256(rs, red);
+        if (tid == 0) rs_part[blockIdx.x] = rs;
+    }
+}
+
+// rowsum[b][c] = the sum of channel c's chunk sums (fixed order): one thread per (b, c)
+__global__ __launch_bounds__(256) void gn_chunk_rowsum_kernel(const float* __restrict__ rs_part, float* __restrict__ rowsum, int B, int C, int G,
+                                                              int S, int64_t ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const int cpg = C / G, spc = S / cpg;
+    const int g = c / cpg, cl = c - g * cpg;
+    const float* __restrict__ pp = rs_part + ((int64_t)(b * G + g) * S + (int64_t)cl * spc);
+    float a = 0.f;
+    for (int k = 0; k < spc; ++k) a += pp[k];
+    rowsum[(int64_t)b * ld + c] = a;
 }
 
 // Chunks per group for the multi-workgroup path (0: not applicable): chunk <= 8192 floats, inside one channel, S <= 256.
@@ -764,7 +791,7 @@ static int gn_chunks(int B, int C, int HW, int G) {
 extern "C" int64_t vd_groupnorm_ws_floats(int B, int C, int HW, int G) {
     if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
     const int S = gn_chunks(B, C, HW, G);
-    return S ? 2 * (int64_t)B * G * S : 0;
+    return S ? 3 * (int64_t)B * G * S : 0;                 // per chunk: two statistics + the sum of its dx (vd_groupnorm_bwd_fused rowsum)
 }
 
 extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -928,9 +955,15 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
     if (S) {
         hipLaunchKernelGGL(gn_chunk_bwd_stats_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
                            beta, ws, C, HW, G, S, apply_silu, dy_bstride, x_bstride);
+        float* rs_part = rowsum ? ws + 2 * (int64_t)B * G * S : nullptr;
         hipLaunchKernelGGL(gn_chunk_bwd_apply_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
                            beta, extra, dx, dgamma_ws, dbeta_ws, ws, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride,
-                           dx_bstride);
+                           dx_bstride, extra2, extra2_bstride, rs_part);
+        if (rowsum)
+            hipLaunchKernelGGL(gn_chunk_rowsum_kernel, dim3(vd_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, rs_part, rowsum, B, C, G, S,
+                               rowsum_ld);
+        VD_LAUNCH_CHECK("vd_groupnorm_bwd");
+        return 0;
     } else {
         hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
                            dgamma_ws, dbeta_ws, C, HW, G, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride);

@@ -81,6 +81,8 @@ PROTOTYPES = {
     "vd_attn_small_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i64, _i64, _i64, _vp]),
     "vd_attn_core_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "vd_attn_core_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "vd_attn_flash_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i64, _i64, _vp]),
+    "vd_attn_flash_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i64, _i64, _i64, _i64, _vp]),
     "vd_timestep_embedding": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_silu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "vd_silu_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -767,6 +767,34 @@ def attn_core_bwd(qkv, P, out, dout, dS, dqkv, heads, head_dim, N, scale):
     return dqkv
 
 
+def attn_flash_eligible(heads, head_dim, N) -> bool:
+    """Shapes the flash attention takes (vd_attn_flash_fwd / _bwd): heads of 32 channels and a multiple of 256 tokens (at 256 tokens it
+    replaces attn_core + the dk / dv products: no probability matrix is saved)."""
+    return head_dim == 32 and heads >= 1 and N >= 256 and N % 256 == 0
+
+
+def attn_flash_fwd(qkv, out, lse, heads, head_dim, N, scale):
+    """Attention of qkv [B, 3C, H, W] without the score matrix in HBM; lse [B, heads, N] (None in the no-grad path) for the backward pass."""
+    Bn = qkv.shape[0]
+    assert qkv.is_contiguous() and out.is_contiguous() and (lse is None or lse.is_contiguous())
+    _timed("attn_flash_kernel<0>", 4.0 * Bn * heads * N * N * head_dim, "mfma", lambda: L.check(
+        _lib().vd_attn_flash_fwd(_p(qkv), _p(out), _p(lse), Bn, heads, head_dim, N, scale, qkv.stride(0), out.stride(0), _s()), "vd_attn_flash_fwd"),
+        nbytes=4.0 * (qkv.numel() + out.numel()))
+    return out
+
+
+def attn_flash_bwd(qkv, out, dout, lse, dqkv, heads, head_dim, N, scale):
+    """dq, dk, dv (all of dqkv [B, 3C, H, W]) from the saved forward output and lse; P is recomputed block by block."""
+    Bn = qkv.shape[0]
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and lse.is_contiguous() and dqkv.is_contiguous()
+    delta = torch.empty_like(lse)
+    _timed("attn_flash_kernel<1>+<2>", 10.0 * Bn * heads * N * N * head_dim, "mfma", lambda: L.check(
+        _lib().vd_attn_flash_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), Bn, heads, head_dim, N, scale, qkv.stride(0),
+                                 out.stride(0), dout.stride(0), dqkv.stride(0), _s()), "vd_attn_flash_bwd"),
+        nbytes=4.0 * (2 * qkv.numel() + 2 * dout.numel()))
+    return dqkv
+
+
 def attn_small_fwd(qkv, out, P, Cc, N, scale):
     Bn = qkv.shape[0]
     L.check(_lib().vd_attn_small_fwd(_p(qkv), _p(out), _p(P), Bn, Cc, N, scale, qkv.stride(0), out.stride(0), _s()),

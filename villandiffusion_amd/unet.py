@@ -465,6 +465,13 @@ class _Attn:
         ops.conv1x1(g, net.Pq[self.qkv_w], net.Pq[self.qkv_b], qkv, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", False, 3 * Cc, Cc, N, B))
         o = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
+        if _split(net) and getattr(net, "fused_attention", False) and ops.attn_flash_eligible(nh, dh, N):
+            # more than 256 tokens per head (config #5's 32x32 level): online softmax over key blocks, only lse [B, heads, N] is saved
+            lse = torch.empty((B, nh, N), device=dev, dtype=torch.float32) if save else None
+            ops.attn_flash_fwd(qkv, o, lse, nh, dh, N, self.scale)
+            ops.conv1x1(o, net.P[self.prefix + ".to_out.0.weight"], net.P[self.prefix + ".to_out.0.bias"], out, residual=x,
+                        a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", False, Cc, Cc, N, B))
+            return (x, mean, rstd, g, qkv, lse, o) if save else None
         if _split(net) and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
             # one launch: scores and probabilities stay in registers; P reaches HBM only when a backward pass will read it
             P = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32) if save else None
@@ -522,7 +529,9 @@ class _Attn:
                  b_bstride=ops._img(dout)[4], ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + ".to_out.0", True, Cc, Cc, N, B))
         dqkv = torch.empty((B, 3 * Cc, H, W), device=dev, dtype=torch.float32)
         nh, dh = self.heads, Cc // self.heads
-        if _split(net) and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
+        if P.dim() == 3:                                   # saved by the flash forward: P is lse [B, heads, N]
+            ops.attn_flash_bwd(qkv, o, do, P, dqkv, nh, dh, N, self.scale)
+        elif _split(net) and getattr(net, "fused_attention", False) and ops.attn_core_eligible(nh, dh, N):
             # dP, the softmax gradient and dq in one launch (dP never reaches HBM); dv and dk are products of the saved P / of dS
             dS = torch.empty((B, nh, N, N), device=dev, dtype=torch.float32)
             ops.attn_core_bwd(qkv, P, o, do, dS, dqkv, nh, dh, N, self.scale)
