@@ -44,6 +44,14 @@ if [ -z "${SKIP_PMC:-}" ]; then
   python3 tools/pmc_summary.py $O/pmc_wait > $O/pmc_wait.json
   rm -rf $O/pmc_wait
 fi
+# BASELINE configs #4 / #5: secondary bench lines + their kernel summaries (rocprofv3 --kernel-trace --stats over the same command)
+for c in celebahq256 ldm64; do
+  timeout 600 python3 bench.py --config $c --steps 8 --warmup 3 > $O/bench_$c.json 2> $O/bench_$c.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$c -- python3 bench.py --config $c --steps 8 --warmup 3 > /dev/null 2> $O/stats_$c.err
+  f=$(find $O/stats_$c -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then cp $f $O/${c}_kernel_stats.csv; fi
+  rm -rf $O/stats_$c
+done
 tail -1 $O/bench_default.json | cut -c1-600
 head -8 $O/train_kernel_stats.csv | cut -c1-160
 head -8 $O/sample_kernel_stats.csv | cut -c1-160

@@ -13,6 +13,8 @@ per-kernel tables:
   r04_pmc_sq_wait.json                   SQ wait / LDS counters per launch (their own pass)
   r04_pmc_sample.json                    the sampler's dispatches: traffic and MfmaUtil per kernel (30-step DDPM loop)
   r04_shape_probe.txt                    tools/shape_probe.py: per-SHAPE timings of the 1x1 / 3x3 convolutions, GroupNorm and the attention core
+  r04_bench_cfg4.json / _cfg5.json       bench.py --config celebahq256 | ldm64 (BASELINE configs #4 / #5, per-GPU batch 8) and
+  r04_cfg4_kernel_stats.csv / _cfg5_...  the rocprofv3 kernel summaries of the same commands
   r04_mfma_sustained.txt                 tools/mfma_peak.hip: what the matrix pipe sustains from registers / from LDS / with random operand bits
 
     python tools/update_profiles_r04.py
@@ -45,6 +47,14 @@ for w in ("train", "sample"):
     p = os.path.join(src, f"{w}_kernel_stats.csv")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"r04_{w}_kernel_stats.csv"))
+for cfg, tag in (("celebahq256", "cfg4"), ("ldm64", "cfg5")):      # BASELINE configs #4 / #5: secondary bench lines + kernel summaries
+    p = os.path.join(src, f"bench_{cfg}.json")
+    if os.path.exists(p) and os.path.getsize(p):
+        with open(os.path.join(dst, f"r04_bench_{tag}.json"), "w") as f:
+            f.write(last_line(p) + "\n")
+    p = os.path.join(src, f"{cfg}_kernel_stats.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"r04_{tag}_kernel_stats.csv"))
 
 for name, out in (("shape_probe.txt", "r04_shape_probe.txt"), ("mfma_sustained.txt", "r04_mfma_sustained.txt"), ("pmc_wait.json", "r04_pmc_sq_wait.json")):
     p = os.path.join(src, name)
