@@ -184,7 +184,9 @@ def test_linear_family():
                                         (2, 512, 8, True),
                                         (2, 256, 32, True),          # 8 K-element groups: the 512-thread backward (as (2, 384, 32): 12 K)
                                         # groups of > 12 K elements: the multi-workgroup (chunked) kernels
-                                        (1, 128, 256, True), (2, 256, 128, True), (2, 128, 64, False)])
+                                        (1, 128, 256, True), (2, 256, 128, True), (2, 128, 64, False),
+                                        # 14 336- and 28 672-element groups (config #5's 32x32 / 64x64 levels): register-resident with 512 / 1024 threads
+                                        (2, 448, 32, True), (1, 224, 64, True), (2, 192, 64, False)])
 def test_groupnorm_silu(B, C, H, silu):
     x = (torch.randn(B, C, H, H, generator=g(0)) * 2 + 0.5).requires_grad_()
     gamma = (torch.randn(C, generator=g(1)) * 0.5 + 1).requires_grad_()
@@ -1206,6 +1208,32 @@ def test_persistent_16x16x32_1x1_convolution_and_its_input_gradient(B, Cin, Cout
         ops.gemm(wd, dy.to(DEV), dx2, M=Cin, N=B * HW, K=Cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=Cin, ldb=HW, b_bstride=Cout * HW,
                  ldd=HW, d_bstride=Cin * HW, a_packed=pkt, accumulate=True)
         assert torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(8, 896, 2688, 8), (8, 2688, 896, 8), (8, 672, 672, 16), (2, 448, 1344, 32), (4, 320, 200, 8)])
+def test_split_k_1x1_convolution_of_small_grids(B, Cin, Cout, H):
+    """Round 4: 1x1 products with fewer than one round of 128 x 128 tiles and a long K (the attention projections of BASELINE config #5's 8x8 /
+    16x16 levels at per-GPU batch 8) split K inside gemm_bx3_kernel<256> (vd_gemm_tile() == 9, vd_gemm_ws_floats() > 0) and add the slabs in fixed
+    order: forward (+ bias + residual) and accumulate against torch, run-to-run identical; VD_GEMM_BX3_SPLIT_OFF=1 is the unsplit launch."""
+    x = torch.randn(B, Cin, H, H, generator=g(0))
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g(1)) / math.sqrt(Cin))
+    b = torch.randn(Cout, generator=g(2))
+    res = torch.randn(B, Cout, H, H, generator=g(3))
+    wd = w.to(DEV).view(Cout, Cin)
+    pk = ops.conv3_pack_weights(wd, Cout, Cin, taps=1)
+    out = torch.full((B, Cout, H, H), 7.0, device=DEV)
+    ops.conv1x1(x.to(DEV), wd, b.to(DEV), out, residual=res.to(DEV), a_packed=pk)
+    assert ops.LAST_GEMM_TILE == 9, ops.LAST_GEMM_TILE
+    y_ref = F.conv2d(x, w, b) + res
+    check(out, y_ref, BX3_TOL, f"split-K 1x1 {Cin}->{Cout}@{H}")
+    out2 = torch.full((B, Cout, H, H), 7.0, device=DEV)
+    ops.conv1x1(x.to(DEV), wd, b.to(DEV), out2, residual=res.to(DEV), a_packed=pk)
+    assert torch.equal(out, out2)
+    HW = H * H
+    acc = torch.full((B, Cout, H, H), 2.0, device=DEV)
+    ops.gemm(wd, x.to(DEV), acc, M=Cout, N=B * HW, K=Cin, a_mode=A_ROW, b_mode=B_PLAIN, NP=HW, lda=Cin, ldb=HW, b_bstride=Cin * HW, ldd=HW,
+             d_bstride=Cout * HW, a_packed=pk, accumulate=True)
+    check(acc - 2.0, F.conv2d(x, w), BX3_TOL, f"split-K 1x1 accumulate {Cin}->{Cout}@{H}")
 
 
 def vd_cdiv_py(a, b):

@@ -12,13 +12,30 @@ namespace {
 
 // Register-resident variant: the whole (batch item, group) slab (<= NV float4 per thread) is read ONCE, kept in
 // registers for the mean / variance / normalise passes and written once: HBM traffic = the algorithmic 8 B / element.
-template <int NV>
-__global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// Block-wide sum for blockDim.x == NTH (NTH / 64 waves, fixed order); result valid in every thread. red: >= NTH / 64 floats of LDS.
+template <int NTH>
+__device__ __forceinline__ float block_sum_t(float v, float* red) {
+    if (NTH == 256) return block_sum_256(v, red);
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTH / 64; ++k) a += red[k];
+    return a;
+}
+
+// NTH = 512 / 1024 (round 4): groups of up to 28 672 elements (7 float4 per thread) -- the 14 336- and 28 672-element groups of BASELINE config #5's
+// 32x32 / 64x64 levels -- stay register-resident (2 tensor sweeps instead of the chunked kernels' 3; backward 3 instead of 5).
+template <int NV, int NTH = 256>
+__global__ __launch_bounds__(NTH) void gn_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, int C,
                                                          int HW, int G, float eps, int apply_silu, int64_t x_bs, int64_t y_bs,
                                                          float* __restrict__ ss_out) {
-    __shared__ float red[8];
+    __shared__ float red[2 * (NTH / 64 < 4 ? 4 : NTH / 64)];
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int cpg = C / G;
     const int n4 = (cpg * HW) >> 2;
@@ -29,21 +46,21 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float* __restrict
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTH;
         v[i] = (idx < n4) ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float inv_n = 1.f / (float)(cpg * HW);
-    const float mean = block_sum_256(s, red) * inv_n;
+    const float mean = block_sum_t<NTH>(s, red) * inv_n;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        if (tid + i * 256 < n4) {
+        if (tid + i * NTH < n4) {
             const float a0 = v[i][0] - mean, a1 = v[i][1] - mean, a2 = v[i][2] - mean, a3 = v[i][3] - mean;
             q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
         }
     }
-    const float rstd = rsqrtf(block_sum_256(q, red + 4) * inv_n + eps);
+    const float rstd = rsqrtf(block_sum_t<NTH>(q, red + (NTH / 64 < 4 ? 4 : NTH / 64)) * inv_n + eps);
     if (tid == 0) {
         mean_out[blockIdx.x] = mean;
         rstd_out[blockIdx.x] = rstd;
@@ -59,7 +76,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float* __restrict
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTH;
         if (idx < n4) {
             const int c = g * cpg + (idx * 4) / HW;
             const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
@@ -768,6 +785,8 @@ __global__ __launch_bounds__(256) void gn_chunk_rowsum_kernel(const float* __res
     rowsum[(int64_t)b * ld + c] = a;
 }
 
+constexpr int GN_REG_MAX = 28 * 1024;          // largest group the register-resident kernels take (7 float4 x 1024 threads)
+
 // Chunks per group for the multi-workgroup path (0: not applicable): chunk <= 8192 floats, inside one channel, S <= 256.
 static bool gn_wave_ok() {
     static const int off = getenv("VD_GN_WAVE_OFF") ? atoi(getenv("VD_GN_WAVE_OFF")) : 0;
@@ -777,7 +796,7 @@ static bool gn_wave_ok() {
 static int gn_chunks(int B, int C, int HW, int G) {
     const int cpg = C / G;
     const int64_t slab = (int64_t)cpg * HW;
-    if (slab <= 12 * 1024 || HW % 4 != 0 || cpg > 64) return 0;
+    if (slab <= GN_REG_MAX || HW % 4 != 0 || cpg > 64) return 0;
     int per_ch = 1;
     while (HW / per_ch > 8192 && (HW / per_ch) % 2 == 0) per_ch *= 2;
     if (HW / per_ch > 8192 || (HW / per_ch) % 4 != 0 || HW % per_ch != 0) return 0;
@@ -802,7 +821,7 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
     const int64_t slab = (int64_t)(C / G) * HW;
     const bool al = (HW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) && ((((uintptr_t)x) & 15) == 0) &&
                     ((((uintptr_t)y) & 15) == 0);
-    const bool reg_ok = al && slab <= 12 * 1024;
+    const bool reg_ok = al && slab <= GN_REG_MAX;
     const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
     if (S) {       // large slabs: S workgroups per group (partials in ws, vd_groupnorm_ws_floats())
         hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, ws, C, HW, G, S, x_bstride);
@@ -826,7 +845,13 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
     else if (reg_ok && slab <= 2048) VD_GN_FWD(2);
     else if (reg_ok && slab <= 4096) VD_GN_FWD(4);
     else if (reg_ok && slab <= 8192) VD_GN_FWD(8);
-    else if (reg_ok) VD_GN_FWD(12);
+    else if (reg_ok && slab <= 12 * 1024) VD_GN_FWD(12);
+    else if (reg_ok && slab <= 14 * 1024)
+        hipLaunchKernelGGL((gn_fwd_reg_kernel<7, 512>), dim3(B * G), dim3(512), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, C, HW, G, eps,
+                           apply_silu, x_bstride, y_bstride, (float*)nullptr);
+    else if (reg_ok)
+        hipLaunchKernelGGL((gn_fwd_reg_kernel<7, 1024>), dim3(B * G), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, C, HW, G, eps,
+                           apply_silu, x_bstride, y_bstride, (float*)nullptr);
     else
         hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, C, HW, G,
                            eps, apply_silu, x_bstride, y_bstride);
@@ -840,8 +865,8 @@ extern "C" int vd_groupnorm_stats(const float* x, const float* gamma, const floa
     VD_REQUIRE(x && gamma && beta && ss && mean && rstd, "vd_groupnorm_stats: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 256, "vd_groupnorm_stats: bad dims");
     const int64_t slab = (int64_t)(C / G) * HW;
-    VD_REQUIRE(HW % 4 == 0 && x_bstride % 4 == 0 && ((((uintptr_t)x) & 15) == 0) && slab <= 12 * 1024,
-               "vd_groupnorm_stats: needs 16-B aligned groups of at most 12288 elements (got %lld)", (long long)slab);
+    VD_REQUIRE(HW % 4 == 0 && x_bstride % 4 == 0 && ((((uintptr_t)x) & 15) == 0) && slab <= GN_REG_MAX,
+               "vd_groupnorm_stats: needs 16-B aligned groups of at most 28672 elements (got %lld)", (long long)slab);
 #define VD_GN_ST(NVV)                                                                                                          \
     hipLaunchKernelGGL((gn_fwd_reg_kernel<NVV>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)nullptr, \
                        mean, rstd, C, HW, G, eps, 0, x_bstride, (int64_t)0, ss)
@@ -857,7 +882,13 @@ extern "C" int vd_groupnorm_stats(const float* x, const float* gamma, const floa
     else if (slab <= 2048) VD_GN_ST(2);
     else if (slab <= 4096) VD_GN_ST(4);
     else if (slab <= 8192) VD_GN_ST(8);
-    else VD_GN_ST(12);
+    else if (slab <= 12 * 1024) VD_GN_ST(12);
+    else if (slab <= 14 * 1024)
+        hipLaunchKernelGGL((gn_fwd_reg_kernel<7, 512>), dim3(B * G), dim3(512), 0, (hipStream_t)stream, x, gamma, beta, (float*)nullptr, mean, rstd, C,
+                           HW, G, eps, 0, x_bstride, (int64_t)0, ss);
+    else
+        hipLaunchKernelGGL((gn_fwd_reg_kernel<7, 1024>), dim3(B * G), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta, (float*)nullptr, mean, rstd, C,
+                           HW, G, eps, 0, x_bstride, (int64_t)0, ss);
 #undef VD_GN_ST
     VD_LAUNCH_CHECK("vd_groupnorm_stats");
     return 0;
@@ -927,7 +958,7 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)extra) | ((uintptr_t)extra2)) & 15) == 0 &&
                     ((x_bstride | dy_bstride | dx_bstride | extra_bstride | extra2_bstride) & 3) == 0;
     const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
-    const bool reg_ok = !S && al && HW % 4 == 0 && slab <= 12 * 1024 &&
+    const bool reg_ok = !S && al && HW % 4 == 0 && slab <= GN_REG_MAX &&
                         ((L >= 64 && L % 64 == 0) || (L < 64 && (L & (L - 1)) == 0 && L > 0)) && getenv("VD_GN_BWD_GENERIC") == nullptr;
     if (reg_ok) {
 #define VD_GN_BWD(NVV, NT)                                                                                                          \
@@ -947,7 +978,9 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
         else if (slab <= 2048) VD_GN_BWD(2, 256);
         else if (slab <= 4096) VD_GN_BWD(4, 256);
         else if (slab <= 8192) VD_GN_BWD(4, 512);
-        else VD_GN_BWD(6, 512);
+        else if (slab <= 12 * 1024) VD_GN_BWD(6, 512);
+        else if (slab <= 14 * 1024) VD_GN_BWD(7, 512);
+        else VD_GN_BWD(7, 1024);
 #undef VD_GN_BWD
         VD_LAUNCH_CHECK("vd_groupnorm_bwd");
         return 0;
