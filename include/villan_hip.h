@@ -221,8 +221,11 @@ int vd_colsum_segmented(const int64_t* table, int n_jobs, int B, void* stream);
  * K1 -- GroupNorm (+SiLU) forward/backward.  Replaces F.group_norm + F.silu of
  * ResnetBlock2D.norm{1,2}, AttentionBlock.group_norm, conv_norm_out.
  * ------------------------------------------------------------------------------------------ */
-/* ws: vd_groupnorm_ws_floats() floats of scratch, or NULL.  Groups larger than 12 K elements (256x256 images) are cut
- * into chunks handled by separate workgroups when ws is given (fixed-order combination of the chunk statistics). */
+/* ws: vd_groupnorm_ws_floats() floats of scratch (16-byte aligned), or NULL.  Groups larger than 28 K elements (256x256 images) are cut
+ * into chunks handled by separate workgroups when ws is given (fixed-order combination of the chunk statistics).  Outside a HIP-graph
+ * capture the chunks of a group exchange their statistics inside ONE launch (bounded polling of (value, launch-epoch) words in ws; a
+ * chunk stays in registers between the statistics and the apply step); inside a capture, or with VD_GN_CHUNK1_OFF=1, a statistics
+ * launch and an apply launch. */
 int64_t vd_groupnorm_ws_floats(int B, int C, int HW, int G);
 int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                      int B, int C, int HW, int G, float eps, int apply_silu, int64_t x_bstride, int64_t y_bstride,

@@ -7,6 +7,8 @@
 // Replaces F.group_norm(+F.silu) of ResnetBlock2D.norm1/norm2, AttentionBlock.group_norm and conv_norm_out in the
 // diffusers UNet2DModel the reference trains (loss.py:993) and samples from (VillanDiffusion.py:579).
 #include "vd_common.h"
+#include <atomic>
+#include <stdlib.h>
 
 namespace {
 
@@ -785,9 +787,227 @@ __global__ __launch_bounds__(256) void gn_chunk_rowsum_kernel(const float* __res
     rowsum[(int64_t)b * ld + c] = a;
 }
 
+// ---- ONE-launch form of the chunked kernels (round 4): a chunk stays in its workgroup's registers between the statistics and the apply step --------
+// The two-launch form reads x (and dy) twice because the S workgroups of a group can only meet at a kernel boundary.  Here every workgroup publishes
+// its partial pair as two 64-bit words (value, launch epoch) with agent-scope atomic stores and then polls the words of its group's S chunks (thread t
+// polls chunk t) until all carry this launch's epoch: forward 3 -> 2 tensor sweeps, backward 5 -> 3.  Progress: the S <= 256 workgroups of a group are
+// consecutive block ids, workgroups are dispatched in order, and a workgroup only ever waits for blocks of its own group, i.e. for blocks that are resident
+// or next in line -- nothing waits for a later group.  The poll is BOUNDED all the same (a timeout publishes NaN statistics: the result is visibly wrong, never
+// a hang), value and epoch travel in one atomic word (no fence, no ordering assumption), and stale words of earlier launches carry older epochs (the
+// workspace is shared with the split-K slabs: an accidental match needs two specific 32-bit patterns).  HIP-graph captures bake the epoch into the launch, so
+// they take the two-launch form (hipStreamIsCapturing).  VD_GN_CHUNK1_OFF=1: always the two-launch form.
+constexpr int GN_POLL_MAX = 400000;
+
+__device__ __forceinline__ void gn_publish(unsigned long long* __restrict__ wa, unsigned long long* __restrict__ wb, float a, float b, unsigned epoch) {
+    __hip_atomic_store(wa, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(wb, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// thread t < S: the pair of chunk t of this group, into LDS pa[t], pb[t] (NaN after a timeout); all threads leave through a barrier
+__device__ __forceinline__ void gn_gather(const unsigned long long* __restrict__ words, int S, unsigned epoch, float* __restrict__ pa, float* __restrict__ pb) {
+    const int t = threadIdx.x;
+    if (t < S) {
+        const unsigned long long* __restrict__ wa = words + 2 * t;
+        unsigned long long a = 0, b = 0;
+        bool ok = false;
+        for (int it = 0; it < GN_POLL_MAX; ++it) {
+            a = __hip_atomic_load(wa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(wa + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        pa[t] = ok ? __uint_as_float((unsigned)a) : __builtin_nanf("");
+        pb[t] = ok ? __uint_as_float((unsigned)b) : __builtin_nanf("");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void gn_chunk1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            unsigned long long* __restrict__ words, int C, int HW, int G, int S, float eps, int apply_silu,
+                                                            int64_t x_bs, int64_t y_bs, unsigned epoch) {
+    __shared__ float red[8];
+    __shared__ float pa[256], pb[256];
+    constexpr int NV = 8;
+    const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
+    const int b = bg / G, g = bg - b * G;
+    const int cpg = C / G;
+    const int c4 = ((cpg * HW) >> 2) / S;                 // float4 per chunk (<= 2048)
+    const int64_t goff = (int64_t)g * cpg * HW;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff) + (int64_t)sc * c4;
+    f32x4* __restrict__ y4 = reinterpret_cast<f32x4*>(y + (int64_t)b * y_bs + goff) + (int64_t)sc * c4;
+    const int tid = threadIdx.x;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        v[i] = (idx < c4) ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float cmean = block_sum_256(s, red) / (float)(c4 * 4);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (tid + i * 256 < c4) {
+            const float a0 = v[i][0] - cmean, a1 = v[i][1] - cmean, a2 = v[i][2] - cmean, a3 = v[i][3] - cmean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    q = block_sum_256(q, red + 4);
+    if (tid == 0) gn_publish(words + 2 * (int64_t)blockIdx.x, words + 2 * (int64_t)blockIdx.x + 1, cmean, q, epoch);
+    gn_gather(words + 2 * (int64_t)bg * S, S, epoch, pa, pb);
+    // the S partials in FIXED order (Chan et al.), as gn_combine
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    const float n_c = (float)(c4 * 4);
+    for (int k = 0; k < S; ++k) {
+        const float mk = pa[k], qk = pb[k];
+        const float nn = n + n_c, delta = mk - mean;
+        mean += delta * (n_c / nn);
+        m2 += qk + delta * delta * (n * n_c / nn);
+        n = nn;
+    }
+    const float rstd = rsqrtf(m2 / (float)(cpg * HW) + eps);
+    if (sc == 0 && tid == 0) {
+        mean_out[bg] = mean;
+        rstd_out[bg] = rstd;
+    }
+    const int L = HW >> 2;
+    const int c = g * cpg + (sc * c4) / L;                // chunks never straddle a channel
+    const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < c4) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = v[i][j] * ga + be;
+                o[j] = apply_silu ? z * sigmoidf_(z) : z;
+            }
+            y4[idx] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_chunk1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ extra, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws,
+                                                            unsigned long long* __restrict__ words, int C, int HW, int G, int S, int apply_silu,
+                                                            int64_t dy_bs, int64_t x_bs, int64_t ex_bs, int64_t dx_bs, const float* __restrict__ extra2,
+                                                            int64_t e2_bs, float* __restrict__ rs_part, unsigned epoch) {
+    __shared__ float red[8];
+    __shared__ float pa[256], pb[256];
+    __shared__ float ch_s1[64], ch_s2[64];
+    constexpr int NV = 8;
+    const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
+    const int b = bg / G, g = bg - b * G;
+    const int cpg = C / G;
+    const int spc = S / cpg;                              // chunks per channel
+    const int c4 = ((cpg * HW) >> 2) / S;
+    const int tid = threadIdx.x;
+    const int64_t goff = (int64_t)g * cpg * HW;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff) + (int64_t)sc * c4;
+    const f32x4* __restrict__ d4 = reinterpret_cast<const f32x4*>(dy + (int64_t)b * dy_bs + goff) + (int64_t)sc * c4;
+    const f32x4* __restrict__ e4 = extra ? reinterpret_cast<const f32x4*>(extra + (int64_t)b * ex_bs + goff) + (int64_t)sc * c4 : nullptr;
+    const f32x4* __restrict__ f4 = extra2 ? reinterpret_cast<const f32x4*>(extra2 + (int64_t)b * e2_bs + goff) + (int64_t)sc * c4 : nullptr;
+    f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(dx + (int64_t)b * dx_bs + goff) + (int64_t)sc * c4;
+    const float mean = mean_in[bg], rstd = rstd_in[bg];
+    const int c = g * cpg + sc / spc;
+    const float ga = gamma[c], be = beta[c];
+    f32x4 xh[NV], dz[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        const bool in = idx < c4;
+        const f32x4 xv = in ? x4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 dv = in ? d4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h_ = (xv[j] - mean) * rstd;
+            float z_ = dv[j];
+            if (apply_silu) {
+                const float z = h_ * ga + be, sg = sigmoidf_(z);
+                z_ *= sg * (1.f + z * (1.f - sg));
+            }
+            if (!in) z_ = 0.f;
+            xh[i][j] = h_;
+            dz[i][j] = z_;
+            s1 += z_;
+            s2 += z_ * h_;
+        }
+    }
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red + 4);
+    if (tid == 0) gn_publish(words + 2 * (int64_t)blockIdx.x, words + 2 * (int64_t)blockIdx.x + 1, s1, s2, epoch);
+    gn_gather(words + 2 * (int64_t)bg * S, S, epoch, pa, pb);
+    if (tid < cpg) {                                      // channel sums: the channel's chunks in fixed order
+        float a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < spc; ++k) {
+            a1 += pa[tid * spc + k];
+            a2 += pb[tid * spc + k];
+        }
+        ch_s1[tid] = a1;
+        ch_s2[tid] = a2;
+        if (sc == 0) {
+            dbeta_ws[(int64_t)b * C + g * cpg + tid] = a1;
+            dgamma_ws[(int64_t)b * C + g * cpg + tid] = a2;
+        }
+    }
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const float ga_ = gamma[g * cpg + cl];
+        m1 += ga_ * ch_s1[cl];
+        m2 += ga_ * ch_s2[cl];
+    }
+    const float inv_n = 1.f / (float)(cpg * HW);
+    m1 *= inv_n;
+    m2 *= inv_n;
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < c4) {
+            f32x4 ev = {0.f, 0.f, 0.f, 0.f}, fv = {0.f, 0.f, 0.f, 0.f}, o;
+            if (e4) ev = e4[idx];
+            if (f4) fv = f4[idx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (rstd * (dz[i][j] * ga - m1 - xh[i][j] * m2) + ev[j]) + fv[j];
+            rs += (o[0] + o[1]) + (o[2] + o[3]);
+            o4[idx] = o;
+        }
+    }
+    if (rs_part) {                                        // block-uniform
+        rs = block_sum_256(rs, red);
+        if (tid == 0) rs_part[blockIdx.x] = rs;
+    }
+}
+
 constexpr int GN_REG_MAX = 28 * 1024;          // largest group the register-resident kernels take (7 float4 x 1024 threads)
 
 // Chunks per group for the multi-workgroup path (0: not applicable): chunk <= 8192 floats, inside one channel, S <= 256.
+static unsigned gn_next_epoch() {                  // never 0: zero-filled workspace words must not match
+    static std::atomic<unsigned> e{0};
+    unsigned v;
+    do v = ++e; while (v == 0);
+    return v;
+}
+
+// the one-launch chunked kernels: not inside a HIP-graph capture (the epoch would be baked into the launch), not with VD_GN_CHUNK1_OFF=1
+static bool gn_chunk1_ok(hipStream_t st) {
+    static const int off = getenv("VD_GN_CHUNK1_OFF") ? atoi(getenv("VD_GN_CHUNK1_OFF")) : 0;
+    if (off) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs == hipStreamCaptureStatusNone;
+}
+
 static bool gn_wave_ok() {
     static const int off = getenv("VD_GN_WAVE_OFF") ? atoi(getenv("VD_GN_WAVE_OFF")) : 0;
     return !off;
@@ -810,7 +1030,8 @@ static int gn_chunks(int B, int C, int HW, int G) {
 extern "C" int64_t vd_groupnorm_ws_floats(int B, int C, int HW, int G) {
     if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
     const int S = gn_chunks(B, C, HW, G);
-    return S ? 3 * (int64_t)B * G * S : 0;                 // per chunk: two statistics + the sum of its dx (vd_groupnorm_bwd_fused rowsum)
+    // per chunk: two statistics + the sum of its dx (vd_groupnorm_bwd_fused rowsum) + the two 64-bit (value, epoch) words of the one-launch form
+    return S ? 4 * (int64_t)B * G * S + 4 * (int64_t)B * G * S : 0;
 }
 
 extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -823,6 +1044,13 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
                     ((((uintptr_t)y) & 15) == 0);
     const bool reg_ok = al && slab <= GN_REG_MAX;
     const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
+    if (S && gn_chunk1_ok((hipStream_t)stream)) {       // one launch: the chunk stays in registers between statistics and apply
+        unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + 4 * (int64_t)B * G * S);
+        hipLaunchKernelGGL(gn_chunk1_fwd_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, words, C, HW, G, S,
+                           eps, apply_silu, x_bstride, y_bstride, gn_next_epoch());
+        VD_LAUNCH_CHECK("vd_groupnorm_fwd");
+        return 0;
+    }
     if (S) {       // large slabs: S workgroups per group (partials in ws, vd_groupnorm_ws_floats())
         hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, ws, C, HW, G, S, x_bstride);
         hipLaunchKernelGGL(gn_chunk_apply_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd,
@@ -982,6 +1210,18 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
         else if (slab <= 14 * 1024) VD_GN_BWD(7, 512);
         else VD_GN_BWD(7, 1024);
 #undef VD_GN_BWD
+        VD_LAUNCH_CHECK("vd_groupnorm_bwd");
+        return 0;
+    }
+    if (S && gn_chunk1_ok((hipStream_t)stream)) {
+        float* rs_part = rowsum ? ws + 2 * (int64_t)B * G * S : nullptr;
+        unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + 4 * (int64_t)B * G * S);
+        hipLaunchKernelGGL(gn_chunk1_bwd_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx, dgamma_ws,
+                           dbeta_ws, words, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride, extra2, extra2_bstride, rs_part,
+                           gn_next_epoch());
+        if (rowsum)
+            hipLaunchKernelGGL(gn_chunk_rowsum_kernel, dim3(vd_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, rs_part, rowsum, B, C, G, S,
+                               rowsum_ld);
         VD_LAUNCH_CHECK("vd_groupnorm_bwd");
         return 0;
     }
