@@ -297,6 +297,43 @@ def test_one_launch_chunked_groupnorm_matches_the_two_launch_form(tmp_path):
             check(u, v, 2e-6, f"one-launch vs two-launch GroupNorm backward: {what}")
 
 
+def test_chunked_groupnorm_inside_a_hip_graph_capture_replays_correctly():
+    """The one-launch chunked GroupNorm tags its exchange words with a per-launch epoch -- a HIP-graph capture would bake that epoch into the
+    launch, so inside a capture the library takes the two-launch form (hipStreamIsCapturing).  Capture forward + backward of a 256x256 group once,
+    replay it on new inputs twice: every replay equals the eager result on the same inputs (forward bit for bit)."""
+    B, C, H = 2, 128, 256
+    gamma = (torch.randn(C, generator=g(1)) * 0.5 + 1).to(DEV)
+    beta = (torch.randn(C, generator=g(2)) * 0.5).to(DEV)
+    x, dy = torch.empty(B, C, H, H, device=DEV), torch.empty(B, C, H, H, device=DEV)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+    wg, wb = torch.empty(B * C, device=DEV), torch.empty(B * C, device=DEV)
+
+    def run():
+        ops.groupnorm_fwd(x, gamma, beta, y, mean, rstd, 32, 1e-6, True)
+        ops.groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dx, wg, wb, 32, True)
+
+    x.copy_(torch.randn(B, C, H, H, generator=g(3)))
+    dy.copy_(torch.randn(B, C, H, H, generator=g(4)))
+    run()                                                     # warm-up outside the capture (workspace allocation)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        run()
+    for seed in (5, 6):
+        x.copy_(torch.randn(B, C, H, H, generator=g(seed)) * 1.5 + 0.3)
+        dy.copy_(torch.randn(B, C, H, H, generator=g(seed + 10)))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (y, mean, rstd, dx, wg, wb)]
+        run()                                                 # eager: the one-launch form
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], y) and torch.equal(got[1], mean) and torch.equal(got[2], rstd)
+        check(got[3], dx, 2e-6, "graph replay vs eager GroupNorm backward dx")
+        check(got[4], wg, 2e-6, "graph replay vs eager dgamma rows")
+        assert torch.equal(got[5], wb)
+
+
 def _attn_ref(qkv, C, scale):
     B, _, N = qkv.shape
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
