@@ -833,10 +833,11 @@ def test_conv_epilogue_channel_sums_give_the_groupnorm_statistics(B, Cin, Cout, 
     assert not ops.GN_PART_WRITTEN
 
 
-@pytest.mark.parametrize("H,pad", [(32, 1), (16, 1), (8, 1), (8, 0)])
+@pytest.mark.parametrize("H,pad", [(32, 1), (16, 1), (8, 1), (8, 0), (128, 0), (128, 1), (256, 0), (256, 1)])
 def test_split_precision_stride2_conv_with_symmetric_padding(H, pad):
-    """Downsample2D(padding=1) (the LDM / VQ-VAE variant) and padding=0 (F.pad (0,1,0,1), the DDPM UNets) on the stride-2 patch."""
-    B, Cin, Cout = 5, 64, 96
+    """Downsample2D(padding=1) (the LDM / VQ-VAE variant, SURVEY 8f.4) and padding=0 (F.pad (0,1,0,1), the DDPM UNets) on the stride-2 patch;
+    128 / 256-pixel inputs (round 4): the 64 / 128-pixel row-segment tiles of BASELINE config #4's first two Downsample2D layers."""
+    B, Cin, Cout = (5, 64, 96) if H <= 32 else (2, 64, 96)
     x = torch.randn(B, Cin, H, H, generator=g(0))
     w = torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)
     b = torch.randn(Cout, generator=g(2))

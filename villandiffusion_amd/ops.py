@@ -274,8 +274,9 @@ WEIGHTS_EPOCH = 0
 
 def bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision convolution kernel takes (vd_gemm_desc.a_packed)."""
-    if mode == B_CONV3_S2:                                  # stride 2 (OH, OW: the OUTPUT, half the input): square 4x4 .. 32x32 outputs
-        return Cc % 16 == 0 and M >= 64 and OH == OW and OW in (4, 8, 16, 32) and os.environ.get("VD_BX3_S2_OFF", "0") in ("", "0")
+    if mode == B_CONV3_S2:                                  # stride 2 (OH, OW: the OUTPUT, half the input): square 4x4 .. 32x32 outputs, 64 / 128 k wide ones
+        return Cc % 16 == 0 and M >= 64 and OH == OW and (OW in (4, 8, 16, 32, 64) or (OW >= 128 and OW % 128 == 0)) \
+            and os.environ.get("VD_BX3_S2_OFF", "0") in ("", "0")
     if mode not in (B_CONV3, B_CONV3_T, B_CONV3_UP) or Cc % 16 != 0 or M < 64 or (OW == 4 and mode == B_CONV3_UP):
         return False
     if OW == 64 or (OW >= 128 and OW % 128 == 0):           # row-segment tiles of wide images
