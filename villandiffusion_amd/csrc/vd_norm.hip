@@ -587,10 +587,10 @@ __device__ __forceinline__ void gn_combine(const float* __restrict__ part, int S
     }
 }
 
+template <int NV>
 __global__ __launch_bounds__(256) void gn_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int HW,
                                                              int G, int S, int64_t x_bs) {
     __shared__ float red[8];
-    constexpr int NV = 8;
     const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
     const int b = bg / G, g = bg - b * G;
     const int cpg = C / G;
@@ -823,17 +823,17 @@ __device__ __forceinline__ void gn_gather(const unsigned long long* __restrict__
     __syncthreads();
 }
 
+template <int NV>
 __global__ __launch_bounds__(256) void gn_chunk1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             unsigned long long* __restrict__ words, int C, int HW, int G, int S, float eps, int apply_silu,
                                                             int64_t x_bs, int64_t y_bs, unsigned epoch) {
     __shared__ float red[8];
     __shared__ float pa[256], pb[256];
-    constexpr int NV = 8;
     const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
     const int b = bg / G, g = bg - b * G;
     const int cpg = C / G;
-    const int c4 = ((cpg * HW) >> 2) / S;                 // float4 per chunk (<= 2048)
+    const int c4 = ((cpg * HW) >> 2) / S;                 // float4 per chunk (<= 256 NV)
     const int64_t goff = (int64_t)g * cpg * HW;
     const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x + (int64_t)b * x_bs + goff) + (int64_t)sc * c4;
     f32x4* __restrict__ y4 = reinterpret_cast<f32x4*>(y + (int64_t)b * y_bs + goff) + (int64_t)sc * c4;
@@ -890,6 +890,7 @@ __global__ __launch_bounds__(256) void gn_chunk1_fwd_kernel(const float* __restr
     }
 }
 
+template <int NV>
 __global__ __launch_bounds__(256) void gn_chunk1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ extra, float* __restrict__ dx,
@@ -900,7 +901,6 @@ __global__ __launch_bounds__(256) void gn_chunk1_bwd_kernel(const float* __restr
     __shared__ float red[8];
     __shared__ float pa[256], pb[256];
     __shared__ float ch_s1[64], ch_s2[64];
-    constexpr int NV = 8;
     const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
     const int b = bg / G, g = bg - b * G;
     const int cpg = C / G;
@@ -1013,13 +1013,19 @@ static bool gn_wave_ok() {
     return !off;
 }
 
-static int gn_chunks(int B, int C, int HW, int G) {
+// fwd: chunks of up to 16384 floats (16 float4 per thread: fewer chunks to wait for, 5.1 TB/s against 3.4-4.0 at 256x256); the backward keeps two
+// arrays per element in registers and stays at 8192 (profiles/r04_gn_chunk_probe.txt)
+static int gn_chunks(int B, int C, int HW, int G, bool fwd = false) {
     const int cpg = C / G;
     const int64_t slab = (int64_t)cpg * HW;
     if (slab <= GN_REG_MAX || HW % 4 != 0 || cpg > 64) return 0;
+    static const int cmax_f = getenv("VD_GN_CHUNK_MAX_FWD") ? atoi(getenv("VD_GN_CHUNK_MAX_FWD")) : 16384;
+    static const int cmax_b = getenv("VD_GN_CHUNK_MAX") ? atoi(getenv("VD_GN_CHUNK_MAX")) : 8192;
+    const int cmax = fwd ? cmax_f : cmax_b;
+    const int lim = cmax < 1024 ? 1024 : (cmax > (fwd ? 16384 : 8192) ? (fwd ? 16384 : 8192) : cmax);
     int per_ch = 1;
-    while (HW / per_ch > 8192 && (HW / per_ch) % 2 == 0) per_ch *= 2;
-    if (HW / per_ch > 8192 || (HW / per_ch) % 4 != 0 || HW % per_ch != 0) return 0;
+    while (HW / per_ch > lim && (HW / per_ch) % 2 == 0) per_ch *= 2;
+    if (HW / per_ch > lim || (HW / per_ch) % 4 != 0 || HW % per_ch != 0) return 0;
     const int S = cpg * per_ch;
     if (S > 256 || (int64_t)B * G * S > (1 << 22)) return 0;
     return S;
@@ -1043,16 +1049,21 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
     const bool al = (HW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) && ((((uintptr_t)x) & 15) == 0) &&
                     ((((uintptr_t)y) & 15) == 0);
     const bool reg_ok = al && slab <= GN_REG_MAX;
-    const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
+    const int S = (al && ws) ? gn_chunks(B, C, HW, G, true) : 0;
     if (S && gn_chunk1_ok((hipStream_t)stream)) {       // one launch: the chunk stays in registers between statistics and apply
         unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + 4 * (int64_t)B * G * S);
-        hipLaunchKernelGGL(gn_chunk1_fwd_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, words, C, HW, G, S,
-                           eps, apply_silu, x_bstride, y_bstride, gn_next_epoch());
+        if (slab / S > 8192)
+            hipLaunchKernelGGL((gn_chunk1_fwd_kernel<16>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, words, C, HW,
+                               G, S, eps, apply_silu, x_bstride, y_bstride, gn_next_epoch());
+        else
+            hipLaunchKernelGGL((gn_chunk1_fwd_kernel<8>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, words, C, HW,
+                               G, S, eps, apply_silu, x_bstride, y_bstride, gn_next_epoch());
         VD_LAUNCH_CHECK("vd_groupnorm_fwd");
         return 0;
     }
     if (S) {       // large slabs: S workgroups per group (partials in ws, vd_groupnorm_ws_floats())
-        hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, ws, C, HW, G, S, x_bstride);
+        if (slab / S > 8192) hipLaunchKernelGGL((gn_chunk_stats_kernel<16>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, ws, C, HW, G, S, x_bstride);
+        else hipLaunchKernelGGL((gn_chunk_stats_kernel<8>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, ws, C, HW, G, S, x_bstride);
         hipLaunchKernelGGL(gn_chunk_apply_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd,
                            ws, C, HW, G, S, eps, apply_silu, x_bstride, y_bstride);
         VD_LAUNCH_CHECK("vd_groupnorm_fwd");
@@ -1216,9 +1227,14 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
     if (S && gn_chunk1_ok((hipStream_t)stream)) {
         float* rs_part = rowsum ? ws + 2 * (int64_t)B * G * S : nullptr;
         unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + 4 * (int64_t)B * G * S);
-        hipLaunchKernelGGL(gn_chunk1_bwd_kernel, dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx, dgamma_ws,
-                           dbeta_ws, words, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride, extra2, extra2_bstride, rs_part,
-                           gn_next_epoch());
+        if (slab / S > 8192)
+            hipLaunchKernelGGL((gn_chunk1_bwd_kernel<16>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
+                               dgamma_ws, dbeta_ws, words, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride, extra2,
+                               extra2_bstride, rs_part, gn_next_epoch());
+        else
+            hipLaunchKernelGGL((gn_chunk1_bwd_kernel<8>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
+                               dgamma_ws, dbeta_ws, words, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride, extra2,
+                               extra2_bstride, rs_part, gn_next_epoch());
         if (rowsum)
             hipLaunchKernelGGL(gn_chunk_rowsum_kernel, dim3(vd_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, rs_part, rowsum, B, C, G, S,
                                rowsum_ld);
