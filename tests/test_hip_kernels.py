@@ -1339,3 +1339,42 @@ def test_split_k_1x1_convolution_of_small_grids(B, Cin, Cout, H):
 
 def vd_cdiv_py(a, b):
     return (a + b - 1) // b
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,pad", [(6, 128, 128, 32, 0), (128, 128, 128, 32, 0), (5, 256, 256, 16, 0), (3, 64, 200, 16, 1), (4, 192, 64, 32, 1),
+                                              (64, 256, 256, 16, 0), (3, 64, 96, 64, 0), (2, 128, 64, 64, 1), (2, 64, 64, 128, 0), (2, 64, 128, 128, 1),
+                                              (1, 64, 64, 256, 0), (2, 128, 128, 256, 1)])
+def test_split_precision_weight_gradient_of_the_stride2_convolution(B, Cin, Cout, H, pad, monkeypatch):
+    monkeypatch.setenv("VILLAN_WGRAD_S2", "all")             # (the default; ops._wgrad_s2_split)
+    """Round 4: the Downsample2D convolution's weight gradient on the split-precision kernel (wgrad_bx3 MODE 4: the octet's 8 output columns read
+    17 input columns, taps 0 / 2 share the even ones, tap 1 takes the odd ones) for both paddings (`F.pad (0,1,0,1)` of the DDPM UNets,
+    `padding = 1` of the LDM / NCSN++ ones), single launch (accumulate, forced splits = 1) and the grouped launch, against torch; 64 .. 256-pixel
+    inputs: 32x32 outputs and the 32-pixel row segments of wider ones (BASELINE config #4)."""
+    x = torch.randn(B, Cin, H, H, generator=g(0))
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(1)) / math.sqrt(Cin * 9)).requires_grad_()
+    y = F.conv2d(x, w, None, stride=2, padding=1) if pad else F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2)
+    dy = torch.randn(y.shape, generator=g(2))
+    y.backward(dy)
+    OH = H // 2
+    assert ops.wgrad_bx3_eligible(Cout, Cin, OH, OH, B_CONV3_S2)
+    xbuf = torch.zeros(B, Cin + 4, H, H, device=DEV)
+    xbuf[:, 4:] = x.to(DEV)
+    dyd = dy.to(DEV)
+    need = ops.wgrad_ws_floats(Cout, Cin, 9, B, OH * OH, mode=B_CONV3_S2, math_mode=1)
+    ws = torch.empty(max(need, 4), device=DEV)
+    dw = torch.full((Cout, Cin * 9), 0.5, device=DEV)
+    ops.conv_wgrad(dyd, xbuf[:, 4:], dw, B_CONV3_S2, ws, accumulate=True, pad=pad, math_mode=1)
+    check(dw - 0.5, w.grad.view(Cout, -1), BX3_TOL, f"bf16x3 stride-2 wgrad pad={pad} {Cin}->{Cout}@{H} B={B} (ws {need})")
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(dyd, xbuf[:, 4:], dw2, B_CONV3_S2, ws, accumulate=False, splits=1, pad=pad, math_mode=1)
+    check(dw2, w.grad.view(Cout, -1), BX3_TOL, "bf16x3 stride-2 wgrad splits=1")
+    dw3 = torch.zeros_like(dw)
+    d = ops.wgrad_desc(dyd, xbuf[:, 4:], dw3, B_CONV3_S2, None, accumulate=True, pad=pad, math_mode=1)
+    assert ops.wgrad_group_class(d) == (2033 if OH >= 64 else 2000 + OH)
+    ops.conv_wgrad_group([d], torch.device(DEV))
+    check(dw3, w.grad.view(Cout, -1), BX3_TOL, "bf16x3 stride-2 wgrad (grouped launch)")
+    # the exact-f32 kernel it replaces agrees as well (same reduction, other arithmetic)
+    dw4 = torch.empty_like(dw)
+    ws0 = torch.empty(max(ops.wgrad_ws_floats(Cout, Cin, 9, B, OH * OH, mode=B_CONV3_S2), 4), device=DEV)
+    ops.conv_wgrad(dyd, xbuf[:, 4:], dw4, B_CONV3_S2, ws0, accumulate=False, pad=pad)
+    assert float((dw4 - dw2).abs().max()) <= 2 * BX3_TOL * float(dw4.abs().max())

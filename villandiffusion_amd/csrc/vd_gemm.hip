@@ -1699,6 +1699,14 @@ static int ilog2_exact(int v) {  // log2 of a power of two, -1 otherwise
 
 // 0: not eligible; 1: wgrad_patch_kernel (OW 16 / 32); 2: wgrad_patch_gen_kernel (OW 4 / 8 / multiples of 32 from 64 up)
 static int wgrad_patch_kind(const vd_wgrad_desc& d) {
+    if (d.T == 9 && d.mode == VD_B_CONV3_S2 && d.math == 1) {    // round 4: the stride-2 Downsample2D convolution on the split-precision kernel (8x8 / 16x16 outputs)
+        if (d.NP != d.OH * d.OW || d.M < 64 || d.C < 64 || d.tile != 0) return -1;
+        // 8x8 / 16x16 / 32x32 outputs, or 32-pixel row segments of wider ones (config #4's 128x128 / 64x64 Downsample2D outputs)
+        if (d.OH == d.OW && (d.OW == 8 || d.OW == 16 || d.OW == 32 || (d.OW >= 64 && d.OW % 32 == 0)) && d.H == 2 * d.OH && d.W == 2 * d.OW &&
+            (d.pad == 0 || d.pad == 1) && (d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0) && (int64_t)d.C * d.H * d.W < (1ll << 29))
+            return 4;
+        return -1;
+    }
     if (d.T != 9 || (d.mode != VD_B_CONV3 && d.mode != VD_B_CONV3_UP)) return 0;
     if (d.NP != d.OH * d.OW || d.M < 64 || d.C < 64 || d.tile != 0) return 0;
     if (d.math == 1) {      // split-precision kernel (explicit request): stride-1 3x3 at 8x8 / 16x16 / 32x32
@@ -2310,7 +2318,7 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         VD_REQUIRE((d.x_bstride & 3) == 0 && ((((uintptr_t)d.X) & 15) == 0) && d.H * d.W == d.NP,
                    "vd_conv_wgrad: 1x1 X alignment");
     VD_REQUIRE(d.math == 0 || wgrad_patch_kind(d) == 4 || wgrad1x1_bx3_eligible(d),
-               "vd_conv_wgrad: math = 1 (split-precision bf16) needs a stride-1 3x3 convolution with 8x8 / 16x16 / 32x32 outputs or a "
+               "vd_conv_wgrad: math = 1 (split-precision bf16) needs a stride-1 3x3 convolution with 8x8 / 16x16 / 32x32 outputs, a stride-2 one with 8x8 / 16x16 outputs or a "
                "1x1 convolution with NP %% 8 == 0; M >= 64, C >= 64, 16-byte aligned operands");
     const int Ncols = d.C * d.T;
     int tile, splits, kk_per;
@@ -2332,7 +2340,12 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
         } else if (up) hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 2>), grid, dim3(NT), 0, st, d, kk_per); \
         else hipLaunchKernelGGL((wgrad_bx3_kernel<WW, 0>), grid, dim3(NT), 0, st, d, kk_per);           \
     } while (0)
-                if (d.OW >= 64 && up) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 2, true>), grid, dim3(NT), 0, st, d, kk_per);
+                if (d.mode == VD_B_CONV3_S2) {
+                    if (d.OW >= 64) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 4, true>), grid, dim3(NT), 0, st, d, kk_per);
+                    else if (d.OW == 32) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 4>), grid, dim3(NT), 0, st, d, kk_per);
+                    else if (d.OW == 16) hipLaunchKernelGGL((wgrad_bx3_kernel<16, 4>), grid, dim3(NT), 0, st, d, kk_per);
+                    else hipLaunchKernelGGL((wgrad_bx3_kernel<8, 4>), grid, dim3(NT), 0, st, d, kk_per);
+                } else if (d.OW >= 64 && up) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 2, true>), grid, dim3(NT), 0, st, d, kk_per);
                 else if (d.OW >= 64) hipLaunchKernelGGL((wgrad_bx3_kernel<32, 0, true>), grid, dim3(NT), 0, st, d, kk_per);
                 else if (d.OW == 4) hipLaunchKernelGGL((wgrad_bx3_kernel<4, 0>), grid, dim3(NT), 0, st, d, kk_per);
                 else if (d.OW == 32) VD_WBX3(32);
@@ -2419,11 +2432,12 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
 
 // ---- grouped weight gradients -----------------------------------------------------------------------------------------------
 // Class of a split-precision weight gradient = the kernel instantiation it runs on; only jobs of one class share a launch.
-//   3x3: 4 * W + 2 * (CONV3_UP) + (wide image)   (W = 32 / 16 / 8 / 4),   1x1: 1000,   0: not groupable
+//   3x3: 4 * W + 2 * (CONV3_UP) + (wide image)   (W = 32 / 16 / 8 / 4),   stride-2 3x3: 2000 + W (W = 16 / 8),   1x1: 1000,   0: not groupable
 static int wgrad_group_class(const vd_wgrad_desc& d) {
     if (d.math != 1 || d.splits != 0 || d.tile != 0) return 0;
     if (wgrad1x1_bx3_eligible(d)) return 1000;
     if (d.T != 9 || wgrad_patch_kind(d) != 4) return 0;
+    if (d.mode == VD_B_CONV3_S2) return d.OW >= 64 ? 2000 + 33 : 2000 + d.OW;       // stride 2: 2000 + W (8 / 16 / 32), 2033 = 32-pixel segments of wide outputs
     const int up = d.mode == VD_B_CONV3_UP ? 2 : 0;
     if (d.OW >= 64) return 4 * 32 + up + 1;
     const int cls = 4 * d.OW + up;
@@ -2441,7 +2455,7 @@ extern "C" int64_t vd_conv_wgrad_group_job_bytes(void) { return (int64_t)sizeof(
 extern "C" int vd_conv_wgrad_group_variant(int cls) {
     if (wgrad9_class(cls)) return 9;
     if (cls == 1000) return wgrad1x1_wide_enabled() ? 256 : 0;
-    if (cls != 1000 && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled()) return 32;
+    if (cls < 1000 && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled()) return 32;
     return 0;
 }
 
@@ -2601,6 +2615,10 @@ extern "C" int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls,
         case 4 * 8 + 2: VD_WG_K32(8, 2) break;
 #undef VD_WG_K32
         case 4 * 4 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<4, 0>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 2000 + 33: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 4, true>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 2000 + 32: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 4>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 2000 + 16: hipLaunchKernelGGL((wgrad_bx3_group_kernel<16, 4>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 2000 + 8: hipLaunchKernelGGL((wgrad_bx3_group_kernel<8, 4>), grid, dim3(NT), 0, st, jobs, n); break;
         default: vd_set_error("vd_conv_wgrad_group_launch: unknown kernel class %d", cls); return VD_EINVAL;
     }
     VD_LAUNCH_CHECK("vd_conv_wgrad_group_launch");

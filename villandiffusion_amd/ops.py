@@ -559,7 +559,9 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
     flops = sum(2.0 * d.M * d.C * d.T * d.nb * d.NP for d in descs)
     nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
     var = lib.vd_conv_wgrad_group_variant(ent["cls"])
-    if ent["cls"] == 1000:                                       # symbol names as rocprofv3 prints them
+    if ent["cls"] > 2000:                                        # stride-2 3x3 classes (2000 + output width; 2033: 32-pixel segments of wide outputs)
+        name = "wgrad_bx3_group_kernel<32, 4, true>(+group_reduce)" if ent["cls"] == 2033 else f"wgrad_bx3_group_kernel<{ent['cls'] - 2000}, 4, false>(+group_reduce)"
+    elif ent["cls"] == 1000:                                     # symbol names as rocprofv3 prints them
         name = "wgrad1x1_wide_group_kernel(+group_reduce)" if var == 256 else "wgrad1x1_bx3_group_kernel(+group_reduce)"
     elif var == 9:
         name = f"wgrad9_group_kernel<{ent['cls'] // 4}>(+group_reduce)"
@@ -605,12 +607,22 @@ def conv_wgrad(dy, x, dw2d, mode, ws: Optional[torch.Tensor], accumulate=False, 
     return dw2d
 
 
+def _wgrad_s2_split(OW) -> bool:
+    """Stride-2 weight gradients on the split-precision kernel (wgrad_bx3 MODE 4).  VILLAN_WGRAD_S2=none: the exact-f32 kernel; wide: only 32x32 outputs and
+    wider.  (The first version of the kernel measured neutral -- profiles/r04_wgrad_s2_ab.txt -- because a conditional store pattern kept its loader state in
+    scratch memory; fixed, it is 0.28 ms against 0.99 on config #4's two large layers and -0.03 ms per config-#2 step: profiles/r04_wgrad_s2_wide_ab.txt.)"""
+    sel = os.environ.get("VILLAN_WGRAD_S2", "all")
+    return sel == "all" or (sel != "none" and OW >= 32)
+
+
 def wgrad_bx3_eligible(M, Cc, OH, OW, mode) -> bool:
     """Problems the split-precision weight-gradient kernel takes (vd_wgrad_desc.math = 1)."""
     if mode == B_PLAIN:
         return (OH * OW) % 8 == 0 and M >= 64 and Cc >= 64
     if (mode == B_CONV3 and OW == 4 and OH == 4) or (mode in (B_CONV3, B_CONV3_UP) and OW >= 64 and OW % 32 == 0):
         return M >= 64 and Cc >= 64      # 4x4: two images per K-step; wide images: 32-pixel row segments
+    if mode == B_CONV3_S2:                   # round 4: the Downsample2D convolution (stride 2) at 8x8 .. 32x32 outputs and 32-pixel segments of wider ones
+        return OH == OW and (OW in (8, 16, 32) or (OW >= 64 and OW % 32 == 0)) and M >= 64 and Cc >= 64 and _wgrad_s2_split(OW)
     return mode in (B_CONV3, B_CONV3_UP) and OH == OW and OW in (8, 16, 32) and M >= 64 and Cc >= 64
 
 

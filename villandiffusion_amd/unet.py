@@ -1052,7 +1052,7 @@ class UNet2DModel(nn.Module):
                         for md in ((B_PLAIN,) if T == 1 else (B_CONV3, B_CONV3_UP, B_CONV3_S2)):
                             need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=md))
                         side = int(round(math.sqrt(hw)))
-                        for md in (B_CONV3, B_CONV3_UP):
+                        for md in (B_CONV3, B_CONV3_UP, B_CONV3_S2):
                             if T == 9 and ops.wgrad_bx3_eligible(M, Cc, side, side, md):
                                 need = max(need, ops.wgrad_ws_floats(M, Cc, T, B, hw, mode=md, math_mode=1))
                         if T == 1 and ops.wgrad_bx3_eligible(M, Cc, side, side, B_PLAIN):
