@@ -5,6 +5,7 @@
 // softmax over j per column i (this file),  out[c][i] = sum_j v[c][j] P[j][i].
 // Replaces torch.baddbmm/softmax/bmm of diffusers' AttentionBlock (UNet2DModel, reached from loss.py:993).
 #include "vd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -529,7 +530,11 @@ template <bool BWD>
 static int launch_attn_core(const attn_core_args& a, int nbh, hipStream_t st) {
     const dim3 grid(2 * nbh);
     const int d = a.d;
-    if (d % 256 == 0) hipLaunchKernelGGL((attn_core_kernel<8, BWD>), grid, dim3(256), 0, st, a);
+    // d = 256 k, backward: eight channel tiles of phase-2 accumulators beside the 128 + 128 score / staging registers spill 101 VGPRs (396 bytes of
+    // scratch per lane); two passes of four tiles (VD_ATTN_BWD_DT8=1: the one-pass form) re-stage k once more and spill 4
+    static const int bwd_dt8 = getenv("VD_ATTN_BWD_DT8") ? atoi(getenv("VD_ATTN_BWD_DT8")) : 0;
+    if (d % 256 == 0 && BWD && !bwd_dt8) hipLaunchKernelGGL((attn_core_kernel<4, BWD>), grid, dim3(256), 0, st, a);
+    else if (d % 256 == 0) hipLaunchKernelGGL((attn_core_kernel<8, BWD>), grid, dim3(256), 0, st, a);
     else if (d == 128) hipLaunchKernelGGL((attn_core_kernel<4, BWD>), grid, dim3(256), 0, st, a);
     else if (d == 64) hipLaunchKernelGGL((attn_core_kernel<2, BWD>), grid, dim3(256), 0, st, a);
     else if (d == 32) hipLaunchKernelGGL((attn_core_kernel<1, BWD>), grid, dim3(256), 0, st, a);
