@@ -139,14 +139,27 @@ __global__ __launch_bounds__(256) void softmax_col_bwd_kernel(const float* __res
 }
 
 // Whole attention for N <= 64 tokens: one workgroup per batch item (mid block: N = 16, C = 256; < 0.1 % of FLOPs).
+// STAGE (round 4): q, k, v (and dout in the backward) of the image are copied to LDS first (coalesced) when they fit 64 KB -- the mid block of config #2
+// (C = 256, N = 16): every thread's channel loop then reads LDS instead of issuing 2 x C strided global loads one after the other (56 / 85 us -> see
+// profiles/r04_attn_small.txt).
+template <bool STAGE>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              float* __restrict__ Pout, int C, int N, float scale,
                                                              int64_t qkv_bs, int64_t out_bs) {
     __shared__ float Ps[64 * 64];
+    __shared__ float stage[STAGE ? 12288 : 1];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* __restrict__ q = qkv + (int64_t)b * qkv_bs;
     const float* __restrict__ k = q + (int64_t)C * N;
     const float* __restrict__ v = k + (int64_t)C * N;
+    if (STAGE) {
+        const int CN = C * N;                             // 3 C N <= 12288
+        for (int e = tid; e < 3 * CN; e += 256) stage[e] = q[e];         // q | k | v are contiguous in qkv
+        __syncthreads();
+        q = stage;
+        k = stage + CN;
+        v = stage + 2 * CN;
+    }
     for (int e = tid; e < N * N; e += 256) {
         const int j = e / N, i = e - j * N;
         float s = 0.f;
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* __rest
     }
 }
 
+template <bool STAGE>
 __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                              const float* __restrict__ dout, float* __restrict__ dqkv, int C,
                                                              int N, float scale, int64_t qkv_bs, int64_t dout_bs,
@@ -186,11 +200,22 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
     __shared__ float Ps[64 * 64];
     __shared__ float dS[64 * 64];
     __shared__ float dots[64];
+    __shared__ float stage[STAGE ? 16384 : 1];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* __restrict__ q = qkv + (int64_t)b * qkv_bs;
     const float* __restrict__ k = q + (int64_t)C * N;
     const float* __restrict__ v = k + (int64_t)C * N;
     const float* __restrict__ dob = dout + (int64_t)b * dout_bs;
+    if (STAGE) {
+        const int CN = C * N;                             // 4 C N <= 16384
+        for (int e = tid; e < 3 * CN; e += 256) stage[e] = q[e];
+        for (int e = tid; e < CN; e += 256) stage[3 * CN + e] = dob[e];
+        __syncthreads();
+        q = stage;
+        k = stage + CN;
+        v = stage + 2 * CN;
+        dob = stage + 3 * CN;
+    }
     float* __restrict__ dq = dqkv + (int64_t)b * dqkv_bs;
     float* __restrict__ dk = dq + (int64_t)C * N;
     float* __restrict__ dv = dk + (int64_t)C * N;
@@ -568,8 +593,11 @@ extern "C" int vd_softmax_col_bwd(const float* P, float* dP, int nb, int N, floa
 extern "C" int vd_attn_small_fwd(const float* qkv, float* out, float* P, int B, int C, int N, float scale, int64_t qkv_bstride,
                                  int64_t out_bstride, void* stream) {
     VD_REQUIRE(qkv && out && B > 0 && C > 0 && N > 0 && N <= 64, "vd_attn_small_fwd: needs N <= 64 (N=%d)", N);
-    hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, out, P, C, N, scale, qkv_bstride,
-                       out_bstride);
+    static const int nostage = getenv("VD_ATTN_SMALL_NOSTAGE") ? atoi(getenv("VD_ATTN_SMALL_NOSTAGE")) : 0;
+    if (!nostage && 3 * C * N <= 12288)
+        hipLaunchKernelGGL(attn_small_fwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, out, P, C, N, scale, qkv_bstride, out_bstride);
+    else
+        hipLaunchKernelGGL(attn_small_fwd_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, out, P, C, N, scale, qkv_bstride, out_bstride);
     VD_LAUNCH_CHECK("vd_attn_small_fwd");
     return 0;
 }
@@ -577,8 +605,13 @@ extern "C" int vd_attn_small_fwd(const float* qkv, float* out, float* P, int B, 
 extern "C" int vd_attn_small_bwd(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int C, int N,
                                  float scale, int64_t qkv_bstride, int64_t dout_bstride, int64_t dqkv_bstride, void* stream) {
     VD_REQUIRE(qkv && P && dout && dqkv && B > 0 && C > 0 && N > 0 && N <= 64, "vd_attn_small_bwd: needs N <= 64 (N=%d)", N);
-    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, P, dout, dqkv, C, N, scale,
-                       qkv_bstride, dout_bstride, dqkv_bstride);
+    static const int nostage = getenv("VD_ATTN_SMALL_NOSTAGE") ? atoi(getenv("VD_ATTN_SMALL_NOSTAGE")) : 0;
+    if (!nostage && 4 * C * N <= 16384)
+        hipLaunchKernelGGL(attn_small_bwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, P, dout, dqkv, C, N, scale, qkv_bstride,
+                           dout_bstride, dqkv_bstride);
+    else
+        hipLaunchKernelGGL(attn_small_bwd_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, P, dout, dqkv, C, N, scale, qkv_bstride,
+                           dout_bstride, dqkv_bstride);
     VD_LAUNCH_CHECK("vd_attn_small_bwd");
     return 0;
 }
