@@ -189,7 +189,7 @@ __device__ __forceinline__ void gemm_epilogue(const vd_gemm_desc& d, f32x16 (&ac
 
 // ---- generic GEMM / conv forward / dgrad -------------------------------------------------------------------------
 template <int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(NT, 3) void gemm_kernel(const vd_gemm_desc d) {
+__global__ __launch_bounds__(NT, (WM * WN >= 4 ? 2 : 3)) void gemm_kernel(const vd_gemm_desc d) {      // (the 128 x 128 tile spilled 17-66 VGPRs at three workgroups per CU)
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA_ = BM + 1, LDB_ = BN + 1;
     constexpr int A_F4 = BM * KG / NT;  // float4 slots per thread for A
