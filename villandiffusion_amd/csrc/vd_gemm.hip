@@ -2499,7 +2499,9 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     static const int tw = getenv("VD_W1X1_WIDE_TARGET") ? atoi(getenv("VD_W1X1_WIDE_TARGET")) : 256;
     static const int capw = getenv("VD_W1X1_WIDE_KCAP") ? atoi(getenv("VD_W1X1_WIDE_KCAP")) : 64;
     const bool k32 = !one && !nine && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled();      // two workgroups per CU: 512 resident slots
-    static const int t32 = getenv("VD_WGRAD_K32_TARGET") ? atoi(getenv("VD_WGRAD_K32_TARGET")) : 512;
+    // (512 = the resident slots; 448 / 384 measured 0.15 ms per config-#2 step faster, same box, three interleaved rounds: the small classes get
+    // longer K ranges and fewer slabs, the large ones are capped at 128 steps either way -- profiles/r04_wgrad_k32_target.txt)
+    static const int t32 = getenv("VD_WGRAD_K32_TARGET") ? atoi(getenv("VD_WGRAD_K32_TARGET")) : 448;
     const int target = wide1 ? tw : (one ? t1 : (nine ? t9 : (k32 ? t32 : t3)));
     const int min_ks = one ? (wide1 ? 8 : 4) : 8;
     int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
