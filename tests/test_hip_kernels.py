@@ -334,6 +334,17 @@ def test_chunked_groupnorm_inside_a_hip_graph_capture_replays_correctly():
         assert torch.equal(got[5], wb)
 
 
+@pytest.mark.parametrize("B,M,H", [(3, 40, 128), (2, 16, 256), (2, 8, 96)])
+def test_rowsum_of_long_rows(B, M, H):
+    """vd_rowsum on rows of >= 8192 floats (config #4's feature maps): four waves per row; channel slices of a wider buffer; H = 96: 9216 floats."""
+    buf = torch.randn(B, M + 3, H, H, generator=g(0)).to(DEV)
+    x = buf[:, 3:]
+    ws = torch.full((B, M + 5), -3.0, device=DEV)
+    ops.rowsum(x, ws[:, 2:2 + M], ws_ld=M + 5)
+    check(ws[:, 2:2 + M], x.cpu().double().sum((2, 3)).float(), 2e-6, f"rowsum long rows {H}x{H}")
+    assert torch.all(ws[:, :2] == -3.0) and torch.all(ws[:, 2 + M:] == -3.0)
+
+
 def _attn_ref(qkv, C, scale):
     B, _, N = qkv.shape
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]

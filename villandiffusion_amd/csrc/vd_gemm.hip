@@ -1849,6 +1849,33 @@ __global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict_
     }
 }
 
+// Long rows (P >= 8192 floats: the 128x128 / 256x256 feature maps of config #4): the FOUR waves of a workgroup share one row (a quarter each, four
+// float4 loads in flight per lane), partial sums combined in fixed order -- one wave per 256 KB row left the launch at ~2.7 TB/s with 1024 waves.
+__global__ __launch_bounds__(256) void rowsum_long_kernel(const float* __restrict__ X, float* __restrict__ ws, int M, int P, int64_t x_bs, int64_t ws_ld) {
+    __shared__ float part[4];
+    const int row = blockIdx.x, b = row / M, m = row - b * M;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int Q = P >> 4;                                    // float4 per wave (P % 16 == 0)
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(X + (int64_t)b * x_bs + (int64_t)m * P) + (int64_t)w * Q;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = lane;
+    for (; i + 192 < Q; i += 256) {
+        const f32x4 a = x4[i], c = x4[i + 64], e = x4[i + 128], f = x4[i + 192];
+        s0 += (a[0] + a[1]) + (a[2] + a[3]);
+        s1 += (c[0] + c[1]) + (c[2] + c[3]);
+        s2 += (e[0] + e[1]) + (e[2] + e[3]);
+        s3 += (f[0] + f[1]) + (f[2] + f[3]);
+    }
+    for (; i < Q; i += 64) {
+        const f32x4 a = x4[i];
+        s0 += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    const float s = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) part[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[(int64_t)b * ws_ld + m] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // ws[b][m] = sum_p X[b][m][p] ; one wave per (b, m) row.
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ X, float* __restrict__ ws, int B, int M, int P,
                                                      int64_t x_bs, int64_t ws_ld) {
@@ -2672,8 +2699,11 @@ extern "C" int vd_col2im_s2(const float* G, float* dX, int B, int C, int H, int 
 
 extern "C" int vd_rowsum(const float* X, float* ws, int B, int M, int P, int64_t x_bstride, int64_t ws_ld, void* stream) {
     VD_REQUIRE(X && ws && B > 0 && M > 0 && P > 0 && ws_ld >= M, "vd_rowsum: bad args");
-    hipLaunchKernelGGL(rowsum_kernel, dim3(vd_cdiv((int64_t)B * M, 4)), dim3(256), 0, (hipStream_t)stream, X, ws, B, M, P,
-                       x_bstride, ws_ld);
+    if (P >= 8192 && (P & 15) == 0 && (x_bstride & 3) == 0 && ((((uintptr_t)X) & 15) == 0))
+        hipLaunchKernelGGL(rowsum_long_kernel, dim3(B * M), dim3(256), 0, (hipStream_t)stream, X, ws, M, P, x_bstride, ws_ld);
+    else
+        hipLaunchKernelGGL(rowsum_kernel, dim3(vd_cdiv((int64_t)B * M, 4)), dim3(256), 0, (hipStream_t)stream, X, ws, B, M, P,
+                           x_bstride, ws_ld);
     VD_LAUNCH_CHECK("vd_rowsum");
     return 0;
 }
