@@ -54,6 +54,12 @@ def parse():
     ap.add_argument("--cpu-true-1000", action="store_true",
                     help="CPU leg: also one TRUE 1000-step DDPM run of one image on the oracle and on the product with the same noise (about a minute of CPU)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-ddp-path", action="store_true",
+                    help="skip the extra leg that times the MULTI-RANK schedule on this one GPU (see --ddp-path)")
+    ap.add_argument("--ddp-path", action="store_true",
+                    help="(default at --gpus 1; the flag makes a failure fatal) also time the K steps on the schedule rank 0 of an N-GPU run executes: "
+                         "an RCCL communicator of size 1, gradient-bucket hooks fired from the explicit backward, graphed micro-step off -> "
+                         "ddp_path_ms_per_step beside ms_per_step")
     ap.add_argument("--graph-step", type=int, default=None, choices=(0, 1),
                     help="1: replay q-sample + forward + loss + backward of the training step as ONE HIP graph (trainer.GraphedMicroStep; single process only); "
                          "default: the library default (graphs only under gradient accumulation)")
@@ -172,8 +178,11 @@ def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=N
 
 
 # ---- roofline: per-launch HIP-event timing (on the launch stream) of one extra training step and of one denoising step ----
-def is_split(kname):     # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
-    return "bx3" in kname or "attn_core" in kname or "k32" in kname or "wgrad9" in kname or "wgrad1x1_wide" in kname
+def is_split(kname, kind="mfma"):     # split-precision kernels run on the bf16 MFMA (3 instructions per algorithmic product term)
+    from villandiffusion_amd.flops import SPLIT_PRECISION_FAMILIES, is_split_precision
+    if kind != "mfma":                # HBM-bound passes: no matrix peak is quoted for them
+        return any(f in kname for f in SPLIT_PRECISION_FAMILIES)
+    return is_split_precision(kname)  # raises for a matrix kernel nobody classified
 
 
 def peak_of(kname):
@@ -196,15 +205,15 @@ def summarise(rec):
     for k, v in agg.items():
         tf = v["flops"] / v["ms"] / 1e9 if v["ms"] > 0 else 0.0
         gbs = v["bytes"] / v["ms"] / 1e6 if v["ms"] > 0 else 0.0
-        split = is_split(k)
-        f_mfma = tf / peak_of(k) if v["kind"] == "mfma" else 0.0
+        split = is_split(k, v["kind"])
+        f_mfma = tf / (PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS) if v["kind"] == "mfma" else 0.0
         f_hbm = gbs / PEAK_HBM_GBS
         rows.append({"kernel": k, "launches": v["n"], "ms": round(v["ms"], 3), "avg_us": round(1e3 * v["ms"] / v["n"], 1),
                      "tflops": round(tf, 2), "gbs": round(gbs, 1), "gflop": round(v["flops"] / 1e9, 1), "mbytes": round(v["bytes"] / 1e6, 1),
                      "frac_mfma": round(f_mfma, 4), "frac_mfma_executed": round((3 if split else 1) * f_mfma, 4), "frac_hbm": round(f_hbm, 4),
                      "bound": "hbm" if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else "mfma",
                      "frac": round(f_hbm if round(f_hbm, 4) >= round((3 if split else 1) * f_mfma, 4) else f_mfma, 4),
-                     "mfma_peak": peak_of(k) if v["kind"] == "mfma" else None})
+                     "mfma_peak": (PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS) if v["kind"] == "mfma" else None})
     return sorted(rows, key=lambda r: -r["ms"])
 
 
@@ -344,16 +353,29 @@ def bench_secondary_config(args):
             mf = [k for k in kernels if k["mfma_peak"]]
             k0 = mf[0]
             sp = is_split(k0["kernel"])
+            # HBM bytes per launch of the dominant kernel from this configuration's committed PMC passes (tools/collect_profiles_r05.sh:
+            # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this same command; rocprofv3 cannot run inside this process)
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{'cfg4' if args.config == 'celebahq256' else 'cfg5'}.json")
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    traffic = json.load(f)["kernels"].get(k0["kernel"].split("(+")[0].split("@")[0], {}).get("traffic_bytes_per_launch")
+                traffic_src = os.path.relpath(pmc, ROOT) if traffic else None
             out["roofline"] = {"bound": k0["bound"], "kernel": k0["kernel"], "achieved": k0["tflops"] if k0["bound"] == "mfma" else k0["gbs"],
                                "peak": k0["mfma_peak"] if k0["bound"] == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if k0["bound"] == "mfma" else "GB/s",
                                "frac": k0["frac"], "frac_executed": k0["frac_mfma_executed"], "executed_tflops": round((3 if sp else 1) * k0["tflops"], 2),
-                               "traffic": None, "launches_per_step": k0["launches"], "avg_launch_us": k0["avg_us"], "ms_per_step": k0["ms"],
-                               "algorithmic_gflop_per_launch": round(k0["gflop"] / k0["launches"], 2)}
+                               "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": k0["launches"], "avg_launch_us": k0["avg_us"],
+                               "ms_per_step": k0["ms"], "algorithmic_gflop_per_launch": round(k0["gflop"] / k0["launches"], 2),
+                               "algorithmic_mbytes_per_launch": round(k0["mbytes"] / k0["launches"], 2)}
             out["top_kernels"] = [{"kernel": k["kernel"], "launches": k["launches"], "ms": k["ms"], "tflops": k["tflops"], "bound": k["bound"], "frac": k["frac"]}
                                   for k in kernels[:10]]
             out["profiled_kernels_ms"] = round(sum(k["ms"] for k in kernels), 2)
             for k in kernels[:14]:
                 log(f"{k['ms']:8.3f} ms {k['launches']:4d}x {k['avg_us']:8.1f} us  {k['tflops']:7.1f} TF {k['bound']:4s} frac {k['frac']:.3f}  {k['kernel']}")
+            path = os.environ.get("VD_BENCH_DETAIL")       # full per-kernel table (tools/update_profiles_r05.py joins it with the PMC passes)
+            if path:
+                with open(path, "w") as f:
+                    json.dump(dict(out, train_step_kernels=kernels), f)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -464,6 +486,7 @@ def main():
     host_submit_ms = host_sync_ms = None
     exact = None
     f16 = None
+    ddp_path = None
     if do_train:
         for i in range(args.warmup):
             one_step(i)
@@ -496,6 +519,41 @@ def main():
             sub.append((h1 - h0, time.perf_counter() - h0))
         host_submit_ms, host_sync_ms = 1e3 * min(a for a, _ in sub), 1e3 * min(b for _, b in sub)
         log(f"host: one step submitted in {host_submit_ms:.2f} ms, finished in {host_sync_ms:.2f} ms (drained queue)")
+
+        # ---- the MULTI-RANK schedule on this one GPU (reference VillanDiffusion.py:440, 1161-1166): what rank 0 of an 8-GPU run
+        #      executes minus the wire time -- a size-1 RCCL communicator, one all-reduce per gradient bucket fired from the backward pass ----
+        if world == 1 and not args.no_ddp_path:
+            try:
+                import socket
+                if not dist.is_initialized():
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        port = sk.getsockname()[1]
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", str(port))
+                    dist.init_process_group(os.environ.get("VD_BENCH_BACKEND", "nccl"), rank=0, world_size=1)
+                trainer.ddp_path, net.bucket_ready_hook = True, trainer._bucket_ready
+                for i in range(3):
+                    one_step(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    one_step(args.warmup + i)
+                torch.cuda.synchronize()
+                ddp_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+                ddp_path = {"ddp_path_ms_per_step": round(ddp_ms, 3), "vs_single_process": round(ddp_ms / (1e3 * dt / args.steps), 4),
+                            "what": "same K steps, process group of size 1 (backend %s), 4 bucket all-reduces fired from the explicit backward on the "
+                                    "weight-gradient side stream, graphed micro-step off" % dist.get_backend()}
+                log(f"ddp path: {ddp_ms:.2f} ms/step ({ddp_path['vs_single_process']:.3f} x the single-process step)")
+            except Exception as e:  # noqa: BLE001 -- a box without a usable RCCL must not cost the headline line
+                if args.ddp_path:
+                    raise
+                ddp_path = {"ddp_path_ms_per_step": None, "error": f"{type(e).__name__}: {e}"[:200]}
+            finally:
+                trainer.ddp_path, net.bucket_ready_hook = False, None
+                trainer._pending, trainer._sync_now = [], False
+                if dist.is_initialized():
+                    dist.destroy_process_group()
 
         # ---- the same K steps with every contraction on the exact-f32 MFMA (reported beside the headline, not as `value`) ----
         if net.conv_math != "f32" and not args.no_exact:
@@ -654,7 +712,7 @@ def main():
         net.sampler_graph = g0
         if rank == 0:
             sample_kernels = summarise(rec_s)
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
 
     def traffic_of(kname):      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
@@ -664,7 +722,7 @@ def main():
             return None
 
     def roof_entry(k, rule):
-        split = is_split(k["kernel"])
+        split = is_split(k["kernel"], "mfma" if k["mfma_peak"] else "hbm")
         tr = traffic_of(k["kernel"])
         if k["bound"] == "mfma":
             e = {"bound": "mfma", "kernel": k["kernel"], "achieved": k["tflops"], "peak": k["mfma_peak"], "unit": "TFLOP/s", "frac": k["frac_mfma"],
@@ -768,6 +826,8 @@ def main():
             "sample_tflops": None if sample_ips is None else round(sample_ips * FWD_GFLOP_PER_IMG * args.sample_steps / 1e3, 2),
             "final_loss": None if final_loss is None else round(final_loss, 5),
             "host_submit_ms_per_step": None if host_submit_ms is None else round(host_submit_ms, 3),
+            "ddp_path_ms_per_step": None if not ddp_path else ddp_path.get("ddp_path_ms_per_step"),
+            "ddp_path": None if not ddp_path else {k: v for k, v in ddp_path.items() if k in ("vs_single_process", "error")},
             "non_mfma_ms_per_step": non_mfma_ms,
             "roofline": slim_roof(roofline), "roofline_largest_flops": slim_roof(roofline_by_flops), "top_kernels": top,
             "cpu_baseline": cpu, "parity": parity, "process_group": pg,
@@ -782,7 +842,7 @@ def main():
         # communicator lines) goes to a side file and to stderr: the driver keeps only the tail of stdout, and the ONE line must survive it
         detail = dict(out)
         detail.update({"roofline": roofline, "roofline_largest_flops": roofline_by_flops, "train_step_kernels": kernels,
-                       "sampler_step_kernels": sample_kernels, "exact_f32_mode": exact, "f16_mode": f16, "sample_eager_launches": sample_eager,
+                       "sampler_step_kernels": sample_kernels, "exact_f32_mode": exact, "f16_mode": f16, "ddp_path": ddp_path, "sample_eager_launches": sample_eager,
                        "process_group": ranks_seen,
                        "dtype_note": ("f32 tensors and accumulation; 3x3 / 1x1 convolutions and the attention contractions (forward, input and weight "
                                       "gradients) as hi*hi + hi*lo + lo*hi over bf16 halves on the bf16 MFMA (~1e-5 of exact f32 per contraction; the "

@@ -28,13 +28,18 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 10
+#define VD_ABI_VERSION 11
 #define VD_EINVAL (-22)
+#define VD_ETIMEDOUT (-110) /* an EARLIER asynchronous launch reported a bounded-poll timeout (see vd_async_errors) */
 
 int vd_abi_version(void);
 const char* vd_last_error(void);
 /* 0 when a gfx950-capable device is visible to this process. */
 int vd_device_ok(void);
+/* Errors that kernels report asynchronously through a word of pinned host memory (today: poll timeouts of the one-launch chunked
+ * GroupNorm, whose statistics are then NaN).  Returns the count since the last clear without synchronising; while it is non-zero every
+ * vd_groupnorm_* call fails with VD_ETIMEDOUT (sticky).  clear != 0 resets it. */
+int vd_async_errors(int clear);
 
 /* ------------------------------------------------------------------------------------------
  * K2/K4/K5/K6/K7 -- implicit-GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32, exact f32).
@@ -71,8 +76,9 @@ typedef struct vd_gemm_desc {
     int32_t d_trans;         /* 1: D[n*ldd + m] (n-major store)                                 */
     int32_t accumulate;      /* 1: D += result                                                  */
     int32_t tile;            /* 0 auto, 1: 128x128, 2: 64x128, 3: 64x64                         */
-    int32_t debug;           /* 0 in production. Timing-only ablations (results invalid): 1 = no global loads
-                                after the first K-step, 2 = no epilogue, 4 = no MFMA                            */
+    int32_t debug;           /* MUST be 0: the release library fails with VD_EINVAL otherwise (ABI 11).  Only a diagnostic
+                                `make ABLATION=1` build honours timing-only ablation bits here (results invalid): 1 = no
+                                global loads after the first K-step, 2 = no epilogue, 4 = no MFMA, 8 = no LDS stores      */
     float alpha;
     int64_t lda, a_bstride;  /* a_bstride != 0: per-batch A (requires tile_n | NP)              */
     int64_t ldb, b_bstride;
@@ -335,9 +341,10 @@ int vd_loss_fwd_bwd(const float* pred, const float* y, const float* pscale, floa
  * ------------------------------------------------------------------------------------------ */
 int vd_l2norm_sq(const float* g, int64_t n, float* partial, float* out_sq, void* stream);
 /* clip = min(1, max_norm/(sqrt(*norm_sq)*inv_scale + 1e-6)); g' = g*inv_scale*clip; torch.optim.Adam update.  With norm_sq given and
- * *norm_sq not finite the kernel leaves p / m / v untouched (GradScaler.step's overflow skip, for the f16 mixed-precision mode). */
+ * *norm_sq not finite the kernel leaves p / m / v untouched (GradScaler.step's overflow skip) and adds 1 to *skipped (device word, may be
+ * NULL): the host reads that counter lazily and refuses to go on (default arithmetic) or halves its loss scale (f16 mode). */
 int vd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float max_norm,
-                 float inv_scale, float lr, float beta1, float beta2, float eps, int step, void* stream);
+                 float inv_scale, float lr, float beta1, float beta2, float eps, int step, unsigned* skipped, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K10 -- sampler steps (diffusers *Scheduler.step, via pipeline(...) VillanDiffusion.py:579).

@@ -5,6 +5,8 @@ import json
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 
@@ -195,3 +197,34 @@ def test_gpus_flag_launches_that_many_ranks():
 def test_gpus_flag_disagreeing_with_world_size_fails_loudly():
     r = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "VD_BENCH_RENDEZVOUS_ONLY": "1"})
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_no_split_precision_kernel_is_priced_against_the_f32_peak():
+    """Round-4 review: `attn_flash_kernel` (bf16 x 3) was priced against the 157.3 TFLOP/s f32 peak (0.79 printed, 0.05 true).  The classification is
+    now ONE table (villandiffusion_amd/flops.py) that raises for a matrix kernel nobody classified; every committed round-5 line must agree with it."""
+    import glob
+    from villandiffusion_amd.flops import is_split_precision
+    for name in ("attn_flash_kernel<0>", "attn_flash_kernel<1>+<2>", "attn_core_kernel<8, true>", "conv3_k32p_kernel<32, 1, true, true, false>",
+                 "gemm1x1_k32p_kernel<false>", "wgrad_k32_group_kernel<32, 0>(+group_reduce)", "wgrad1x1_wide_group_kernel(+group_reduce)",
+                 "gemm_bx3_kernel<256>", "gemm_bx3_act_kernel<1, 0>", "wgrad9_group_kernel<32>(+group_reduce)", "wgrad_presplit_group_kernel<32, 0>"):
+        assert is_split_precision(name), name
+    for name in ("gemm_kernel<128x128,ROW,PLAIN>", "gemm_plain_kernel<1>", "conv3_patch_kernel<32, 0, 2>", "wgrad_kernel<128x128,CONV3_S2>(+slab_reduce)",
+                 "wgrad_small_kernel<true>(+colsum)", "conv3_fewout_kernel<4>"):
+        assert not is_split_precision(name), name
+    with pytest.raises(KeyError):
+        is_split_precision("brand_new_matrix_kernel<3>")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    checked = 0
+    for f in sorted(glob.glob(os.path.join(root, "r05_bench_*.json"))):
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        rows = list(d.get("train_step_kernels") or []) + list(d.get("sampler_step_kernels") or [])
+        for r in rows:
+            if r.get("mfma_peak"):
+                assert r["mfma_peak"] == (2500.0 if is_split_precision(r["kernel"]) else 157.3), (f, r["kernel"], r["mfma_peak"])
+                checked += 1
+        for key in ("roofline", "roofline_largest_flops"):
+            r = d.get(key)
+            if r and r.get("bound") == "mfma":
+                assert r["peak"] == (2500.0 if is_split_precision(r["kernel"]) else 157.3), (f, key, r["kernel"], r["peak"])
+                checked += 1
+    print(f"[contract] {checked} priced kernel rows checked")

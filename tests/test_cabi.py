@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, s), f"{s} declared in villan_hip.h but not exported"
         assert s in lib.PROTOTYPES, f"{s} has no ctypes prototype in lib.py"
     assert set(lib.PROTOTYPES) == set(syms)
-    assert handle.vd_abi_version() == 10
+    assert handle.vd_abi_version() == 11
 
 
 def test_struct_layout_matches_c(tmp_path):

@@ -145,9 +145,32 @@ def test_f16_training_mode_tracks_the_default_arithmetic():
     tr.opt.step(lr=1e-4, grad_inv_scale=1.0 / tr.loss_scale, need_norm=True)
     torch.cuda.synchronize()
     assert torch.equal(net.flat_param, p_before)
-    tr.sched_step = tr.scale_check_every - 1 if False else tr.sched_step
-    tr.sched_step = tr.scale_check_every                       # force the lazy check
-    tr._check_scale()
+    steps_before, sched_before = tr.opt.step_count, tr.sched_step
+    tr.check_skipped(force=True)                               # the lazy check (every `scale_check_every` steps in a run)
     assert tr.loss_scale == 2048.0 and tr.overflow_steps_seen == 1
+    assert tr.opt.step_count == steps_before - 1               # the refused step does not count for the bias correction ...
+    assert tr.sched_step == max(0, sched_before - 1)           # ... nor for the LR schedule (GradScaler / accelerate skip both)
+    net.zero_grad()
+    # the NEXT step runs under the new scale (advisor r4: the scale used to be re-read once per epoch only) and moves the parameters
+    p_before = net.flat_param.detach().clone()
+    l2 = float(tr.train_step(batch, t))
+    assert lf.grad_scale == 2048.0 / tr.grad_accum and tr._step_scale == 2048.0
+    assert math.isfinite(l2) and not torch.equal(net.flat_param, p_before)
+    # the scale state survives a checkpoint
+    sd = tr.state_dict()
+    tr2 = Trainer(net, lf, lr=1e-4, total_steps=100, warmup_steps=0)
+    tr2.load_state_dict(sd)
+    assert tr2.loss_scale == 2048.0 and tr2.overflow_steps_seen == 1
     net.zero_grad()
     net.conv_math = "bf16x3"
+    # default arithmetic: there is no scale to lower -- a non-finite gradient norm is refused loudly at the check
+    tr3 = Trainer(net, lf, lr=1e-4, total_steps=100, warmup_steps=0)
+    p_before = net.flat_param.detach().clone()
+    net.flat_grad[7] = float("nan")
+    tr3.opt.step(lr=1e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(net.flat_param, p_before)
+    import pytest as _pytest
+    with _pytest.raises(FloatingPointError):
+        tr3.check_skipped(force=True)
+    net.zero_grad()

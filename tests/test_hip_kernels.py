@@ -297,6 +297,52 @@ def test_one_launch_chunked_groupnorm_matches_the_two_launch_form(tmp_path):
             check(u, v, 2e-6, f"one-launch vs two-launch GroupNorm backward: {what}")
 
 
+_GN_STICKY_PROBE = r"""
+import sys, torch
+from villandiffusion_amd import lib as L
+from villandiffusion_amd import ops
+dev = "cuda"
+B, C, H = 2, 128, 256
+x = torch.randn(B, C, H, H, device=dev)
+gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+y = torch.empty_like(x)
+mean, rstd = torch.empty(B * 32, device=dev), torch.empty(B * 32, device=dev)
+assert L.load().vd_async_errors(0) == 0
+ops.groupnorm_fwd(x, gamma, beta, y, mean, rstd, 32, 1e-6, True)           # VD_GN_POLL_MAX=0: every poll of the one-launch form times out
+torch.cuda.synchronize()
+mode = sys.argv[1]
+if mode == "capacity":                                                     # VD_GN_CHUNK1_CAPACITY=1: the two-launch form was taken, no polling at all
+    assert L.load().vd_async_errors(0) == 0 and bool(torch.isfinite(y).all())
+    print("GN capacity ok")
+    sys.exit(0)
+n = L.load().vd_async_errors(0)
+assert n > 0 and not bool(torch.isfinite(mean).all()), n                   # NaN statistics AND a reported error
+try:
+    ops.groupnorm_fwd(x, gamma, beta, y, mean, rstd, 32, 1e-6, True)       # sticky: the next call is refused with a message
+except L.VillanHipError as e:
+    assert "poll timeout" in str(e) and "-110" in str(e), str(e)
+else:
+    raise AssertionError("the sticky GroupNorm error did not fail the next call")
+assert L.load().vd_async_errors(1) == n and L.load().vd_async_errors(0) == 0
+print("GN sticky ok")
+"""
+
+
+def test_polling_groupnorm_timeout_is_a_sticky_error_and_small_devices_take_two_launches():
+    """Round-4 review: a poll timeout of the one-launch chunked GroupNorm used to publish NaN statistics and carry on.  Now the kernel also bumps a
+    word of pinned host memory: `vd_async_errors()` reports it without a sync and every later vd_groupnorm_* call fails with VD_ETIMEDOUT until it is
+    cleared.  (VD_GN_POLL_MAX=0 makes every poll time out.)  And a device whose resident-workgroup capacity is below 2 x S never polls: it takes the
+    two-launch form (VD_GN_CHUNK1_CAPACITY pretends one)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode, env in (("sticky", {"VD_GN_POLL_MAX": "0"}), ("capacity", {"VD_GN_POLL_MAX": "0", "VD_GN_CHUNK1_CAPACITY": "1"})):
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        r = subprocess.run([sys.executable, "-c", _GN_STICKY_PROBE, mode], capture_output=True, text=True, env=e, cwd=root, timeout=300)
+        assert r.returncode == 0 and f"GN {mode} ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_chunked_groupnorm_inside_a_hip_graph_capture_replays_correctly():
     """The one-launch chunked GroupNorm tags its exchange words with a per-launch epoch -- a HIP-graph capture would bake that epoch into the
     launch, so inside a capture the library takes the two-launch form (hipStreamIsCapturing).  Capture forward + backward of a 256x256 group once,

@@ -491,3 +491,49 @@ def test_gpu_list_spawns_one_rank_per_gpu():
     assert r1.returncode == 0, r1.stderr[-2000:]
     assert json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1]) == \
         {"rendezvous_only": True, "world_size": 1, "ranks_counted": 1, "visible": "4"}
+
+
+def test_rank_sharded_measure_chunks_own_disjoint_philox_ranges(monkeypatch):
+    """Advisor r4: two consecutive chunked sampling calls (clean set, then backdoor set -- what `measure()` does) on a world of 2 must give every
+    (call, chunk) its own Philox offset range whatever rank draws it, including a rank that owns only the short last chunk and a rank with no
+    chunk at all: the stride and the advance of the scheduler's offset come from the WHOLE job's chunk list, not from the rank's own."""
+    from types import SimpleNamespace
+    from villandiffusion_amd import pipelines as P
+    from villandiffusion_amd import sampling_io as SIO
+
+    steps, calls = 7, []
+
+    def fake_call(self, batch_size=None, init=None, num_inference_steps=None, return_tensor=False, **kw):
+        calls.append((self.rank, self.scheduler._rng_offset, init.numel()))
+        return init
+
+    monkeypatch.setattr(P.DiffusionPipeline, "__call__", fake_call)
+    monkeypatch.setattr(SIO, "save_imgs", lambda *a, **k: None)
+    monkeypatch.setattr(P, "_post", lambda x: x)
+
+    def job(n_images, batch, world):
+        calls.clear()
+        ranges, ends = [], []
+        for rank in range(world):
+            pipe = object.__new__(P.DiffusionPipeline)
+            pipe.rank, pipe.unet = rank, None                    # (no UNet2DModel: the chunks take the sequential walk)
+            pipe.scheduler = SimpleNamespace(device_rng_seed=5, _rng_offset=0, set_timesteps=lambda n: None, timesteps=list(range(steps)))
+            pipe.default_steps = steps
+            for _ in range(2):                                   # clean set, then backdoor set
+                init = torch.zeros(n_images, 3, 4, 4)
+                SIO.batch_sampling_save(n_images, pipe, "unused", init=init, max_batch_n=batch, num_inference_steps=steps, rank=rank, world=world)
+            ends.append(pipe.scheduler._rng_offset)
+        per_elem = 2 * steps                                     # draws per element a chunk may make (chunk_rng_offset's stride)
+        for _, off, numel in calls:
+            ranges.append((off, off + per_elem * ((numel + 3) // 4)))
+        return sorted(ranges), ends
+
+    for n_images, batch, world in ((384, 256, 2), (2048, 256, 2), (256, 256, 2), (1024, 128, 4)):
+        ranges, ends = job(n_images, batch, world)
+        n_chunks = -(-n_images // batch)
+        assert len(ranges) == 2 * n_chunks
+        for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+            assert a1 <= b0, (n_images, batch, world, ranges)     # no two (call, chunk) pairs share an offset
+        assert len(set(ends)) == 1                                # every rank (also one without chunks) ends at the same offset
+        ranges1, ends1 = job(n_images, batch, 1)
+        assert ranges1 == ranges and ends1[0] == ends[0]          # ... and the layout does not depend on the world size

@@ -27,6 +27,14 @@ void vd_set_error(const char* fmt, ...);
         }                                                                   \
     } while (0)
 
+// vd_gemm_desc.debug: timing-only ablation bits (wrong results) exist in `make ABLATION=1` builds only; the release library rejects a non-zero value
+// in vd_gemm() and compiles the bit tests away.
+#ifdef VD_ABLATION
+#define VD_DBG(d) ((d).debug)
+#else
+#define VD_DBG(d) 0
+#endif
+
 static inline int vd_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // 64-lane wave sum via DPP-free shuffles (wavefront = 64 on CDNA).

@@ -162,12 +162,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const float* __restrict__ norm_sq,
                                                    float max_norm, float inv_scale, float lr, float beta1, float beta2,
-                                                   float eps, float bc1, float bc2_sqrt) {
+                                                   float eps, float bc1, float bc2_sqrt, unsigned* __restrict__ skipped) {
     float gs = inv_scale;
     if (norm_sq) {
         // a non-finite gradient (f16 mixed-precision mode: an operand overflowed under the loss scale) skips the whole update, as
-        // torch.cuda.amp.GradScaler.step does (reference VillanDiffusion.py:260-264 -> accelerate); Trainer halves the scale when it sees it
-        if (!(*norm_sq <= 3.0e38f)) return;
+        // torch.cuda.amp.GradScaler.step does (reference VillanDiffusion.py:260-264 -> accelerate); the skip is COUNTED (one writer: thread 0 of
+        // block 0) so that the host sees every skipped step at its next lazy check, not only the one the check happens to land on
+        if (!(*norm_sq <= 3.0e38f)) {
+            if (skipped && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1u;
+            return;
+        }
         const float norm = sqrtf(*norm_sq) * inv_scale;
         gs *= fminf(1.0f, max_norm / (norm + 1e-6f));
     }
@@ -430,13 +434,13 @@ extern "C" int vd_l2norm_sq(const float* g, int64_t n, float* partial, float* ou
 }
 
 extern "C" int vd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float max_norm,
-                            float inv_scale, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+                            float inv_scale, float lr, float beta1, float beta2, float eps, int step, unsigned* skipped, void* stream) {
     VD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vd_adam_step: bad args");
     VD_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, "vd_adam_step: unaligned");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(egrid(n, 8)), dim3(256), 0, ST, p, g, m, v, n, norm_sq, max_norm, inv_scale, lr, beta1,
-                       beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       beta2, eps, (float)bc1, (float)sqrt(bc2), skipped);
     VD_LAUNCH_CHECK("vd_adam_step");
     return 0;
 }

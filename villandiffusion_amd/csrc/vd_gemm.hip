@@ -400,7 +400,7 @@ __global__ __launch_bounds__(NT, (WM * WN >= 4 ? 2 : 3)) void gemm_kernel(const 
     load_b(0);
     store_ab();
     __syncthreads();
-    if (d.debug == 0) {
+    if (VD_DBG(d) == 0) {
         for (int kt = 0; kt < ktiles; ++kt) {
             const bool more = kt + 1 < ktiles;
             if (more) {
@@ -415,16 +415,16 @@ __global__ __launch_bounds__(NT, (WM * WN >= 4 ? 2 : 3)) void gemm_kernel(const 
     } else {  // timing-only ablations (results are invalid)
         for (int kt = 0; kt < ktiles; ++kt) {
             const bool more = kt + 1 < ktiles;
-            if (more && !(d.debug & 1)) {
+            if (more && !(VD_DBG(d) & 1)) {
                 load_a((kt + 1) * BK);
                 load_b((kt + 1) * BK);
             }
-            if (!(d.debug & 4)) mma_stage<WM, WN, LDA_, LDB_>(As, Bs, arow, bcol, h, acc);
+            if (!(VD_DBG(d) & 4)) mma_stage<WM, WN, LDA_, LDB_>(As, Bs, arow, bcol, h, acc);
             __syncthreads();
-            if (more && !(d.debug & 8)) store_ab();
+            if (more && !(VD_DBG(d) & 8)) store_ab();
             __syncthreads();
         }
-        if (d.debug & 2) {
+        if (VD_DBG(d) & 2) {
             float s = 0.f;
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128 || MODE == 4) ? 2 : 3) voi
     __syncthreads();
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         const bool more = ks + 1 < ks_end;
-        if (more && !(d.debug & 1)) load_stage((ks + 1) * CKK);       // debug bits: timing-only ablations
+        if (more && !(VD_DBG(d) & 1)) load_stage((ks + 1) * CKK);       // debug bits: timing-only ablations
         // software-pipelined operand fetch: the ds_reads of MFMA step u+1 are issued before the MFMAs of step u
         // (hipcc otherwise places each read right in front of its use and waits lgkmcnt(0): LDS latency per 4 MFMAs)
         auto fetch = [&](int u, float (&a)[WM], float (&bb)[WN]) {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(NT, (WN == 4 || W >= 128 || MODE == 4) ? 2 : 3) voi
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
-        if (more && !(d.debug & 8)) store_stage((ks + 1) * CKK);
+        if (more && !(VD_DBG(d) & 8)) store_stage((ks + 1) * CKK);
         __syncthreads();
     }
     if (gridDim.y == 1) {
@@ -744,7 +744,7 @@ static bool patch_eligible(const vd_gemm_desc& d) {
     if (d.C % CK != 0 || d.OH * d.OW != d.NP || d.d_trans) return false;
     if (d.NP >= 128 ? (d.NP % 128 != 0) : (128 % d.NP != 0)) return false;
     if (d.K != d.C * 9 || (d.lda & 3) != 0 || (((uintptr_t)d.A) & 15) != 0) return false;
-    if ((d.debug & ~(16 | 1 | 8)) != 0 || (d.debug != 0 && !(d.debug & 16)) || d.tile != 0) return false;   // 16: ablations on this kernel
+    if ((VD_DBG(d) & ~(16 | 1 | 8)) != 0 || (VD_DBG(d) != 0 && !(VD_DBG(d) & 16)) || d.tile != 0) return false;   // 16: ablations on this kernel
     if (d.b_mode == VD_B_CONV3_UP && d.OW == 4) return false;
     return d.M >= 64;
 }
@@ -2186,6 +2186,9 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(desc != nullptr, "vd_gemm: null desc");
     vd_gemm_desc d = *desc;
     VD_REQUIRE(d.A && d.B && d.D, "vd_gemm: null operand");
+#ifndef VD_ABLATION
+    VD_REQUIRE(d.debug == 0, "vd_gemm: desc.debug = %d -- timing-only ablation bits exist in `make ABLATION=1` builds only", d.debug);
+#endif
     VD_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.NP > 0 && d.N % d.NP == 0, "vd_gemm: bad dims M=%d N=%d K=%d NP=%d", d.M,
                d.N, d.K, d.NP);
     if (d.b_mode >= VD_B_CONV3) {

@@ -804,13 +804,16 @@ __device__ __forceinline__ void gn_publish(unsigned long long* __restrict__ wa, 
 }
 
 // thread t < S: the pair of chunk t of this group, into LDS pa[t], pb[t] (NaN after a timeout); all threads leave through a barrier
-__device__ __forceinline__ void gn_gather(const unsigned long long* __restrict__ words, int S, unsigned epoch, float* __restrict__ pa, float* __restrict__ pb) {
+// A timeout is also REPORTED: `flag` is a word of pinned host memory (system-scope add), which the host reads without synchronising at the top of the
+// next vd_groupnorm_* call and through vd_async_errors() -- a sticky error instead of NaN that nobody sees (round-4 review).
+__device__ __forceinline__ void gn_gather(const unsigned long long* __restrict__ words, int S, unsigned epoch, float* __restrict__ pa, float* __restrict__ pb,
+                                          unsigned* __restrict__ flag, int poll_max) {
     const int t = threadIdx.x;
     if (t < S) {
         const unsigned long long* __restrict__ wa = words + 2 * t;
         unsigned long long a = 0, b = 0;
         bool ok = false;
-        for (int it = 0; it < GN_POLL_MAX; ++it) {
+        for (int it = 0; it < poll_max; ++it) {
             a = __hip_atomic_load(wa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             b = __hip_atomic_load(wa + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch;
@@ -819,6 +822,7 @@ __device__ __forceinline__ void gn_gather(const unsigned long long* __restrict__
         }
         pa[t] = ok ? __uint_as_float((unsigned)a) : __builtin_nanf("");
         pb[t] = ok ? __uint_as_float((unsigned)b) : __builtin_nanf("");
+        if (!ok && flag) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
 }
@@ -827,7 +831,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void gn_chunk1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             unsigned long long* __restrict__ words, int C, int HW, int G, int S, float eps, int apply_silu,
-                                                            int64_t x_bs, int64_t y_bs, unsigned epoch) {
+                                                            int64_t x_bs, int64_t y_bs, unsigned epoch, unsigned* __restrict__ flag, int poll_max) {
     __shared__ float red[8];
     __shared__ float pa[256], pb[256];
     const int bg = blockIdx.x / S, sc = blockIdx.x - bg * S;
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(256) void gn_chunk1_fwd_kernel(const float* __restr
         }
     q = block_sum_256(q, red + 4);
     if (tid == 0) gn_publish(words + 2 * (int64_t)blockIdx.x, words + 2 * (int64_t)blockIdx.x + 1, cmean, q, epoch);
-    gn_gather(words + 2 * (int64_t)bg * S, S, epoch, pa, pb);
+    gn_gather(words + 2 * (int64_t)bg * S, S, epoch, pa, pb, flag, poll_max);
     // the S partials in FIXED order (Chan et al.), as gn_combine
     float n = 0.f, mean = 0.f, m2 = 0.f;
     const float n_c = (float)(c4 * 4);
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(256) void gn_chunk1_bwd_kernel(const float* __restr
                                                             float* __restrict__ dgamma_ws, float* __restrict__ dbeta_ws,
                                                             unsigned long long* __restrict__ words, int C, int HW, int G, int S, int apply_silu,
                                                             int64_t dy_bs, int64_t x_bs, int64_t ex_bs, int64_t dx_bs, const float* __restrict__ extra2,
-                                                            int64_t e2_bs, float* __restrict__ rs_part, unsigned epoch) {
+                                                            int64_t e2_bs, float* __restrict__ rs_part, unsigned epoch, unsigned* __restrict__ flag, int poll_max) {
     __shared__ float red[8];
     __shared__ float pa[256], pb[256];
     __shared__ float ch_s1[64], ch_s2[64];
@@ -942,7 +946,7 @@ __global__ __launch_bounds__(256) void gn_chunk1_bwd_kernel(const float* __restr
     s1 = block_sum_256(s1, red);
     s2 = block_sum_256(s2, red + 4);
     if (tid == 0) gn_publish(words + 2 * (int64_t)blockIdx.x, words + 2 * (int64_t)blockIdx.x + 1, s1, s2, epoch);
-    gn_gather(words + 2 * (int64_t)bg * S, S, epoch, pa, pb);
+    gn_gather(words + 2 * (int64_t)bg * S, S, epoch, pa, pb, flag, poll_max);
     if (tid < cpg) {                                      // channel sums: the channel's chunks in fixed order
         float a1 = 0.f, a2 = 0.f;
         for (int k = 0; k < spc; ++k) {
@@ -996,10 +1000,42 @@ static unsigned gn_next_epoch() {                  // never 0: zero-filled works
     return v;
 }
 
+// Sticky asynchronous error word of the polling kernels: pinned, device-mapped host memory (allocated at the first one-launch call; never freed).
+static unsigned* g_gn_flag_host = nullptr;
+static unsigned* g_gn_flag_dev = nullptr;
+static unsigned* gn_flag_dev() {
+    static std::atomic<int> state{0};              // 0: not tried, 1: ready, -1: no pinned memory (kernels then only emit NaN, as before)
+    if (state.load() == 0) {
+        void* h = nullptr;
+        void* dptr = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&dptr, h, 0) == hipSuccess) {
+            *reinterpret_cast<volatile unsigned*>(h) = 0u;
+            g_gn_flag_host = reinterpret_cast<unsigned*>(h);
+            g_gn_flag_dev = reinterpret_cast<unsigned*>(dptr);
+            state.store(1);
+        } else {
+            (void)hipGetLastError();
+            state.store(-1);
+        }
+    }
+    return g_gn_flag_dev;
+}
+static int gn_poll_max() {                         // VD_GN_POLL_MAX=0: every poll times out at once (the sticky-error test)
+    static const int v = getenv("VD_GN_POLL_MAX") ? atoi(getenv("VD_GN_POLL_MAX")) : GN_POLL_MAX;
+    return v;
+}
+static unsigned gn_flag_read() { return g_gn_flag_host ? *reinterpret_cast<volatile unsigned*>(g_gn_flag_host) : 0u; }
+
+// Resident-workgroup capacity of the device for the one-launch kernels (occupancy x CU count, the smallest over the four instantiations).  A group's S
+// workgroups poll each other, so all S must be resident at once with room to spare for whatever else runs (the weight-gradient side stream, a
+// partitioned or CU-masked device): below 2 x S the two-launch form is taken.
+static int gn_chunk1_capacity();
+
 // the one-launch chunked kernels: not inside a HIP-graph capture (the epoch would be baked into the launch), not with VD_GN_CHUNK1_OFF=1
-static bool gn_chunk1_ok(hipStream_t st) {
+static bool gn_chunk1_ok(hipStream_t st, int S) {
     static const int off = getenv("VD_GN_CHUNK1_OFF") ? atoi(getenv("VD_GN_CHUNK1_OFF")) : 0;
     if (off) return false;
+    if (gn_chunk1_capacity() < 2 * S) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
         (void)hipGetLastError();
@@ -1031,7 +1067,47 @@ static int gn_chunks(int B, int C, int HW, int G, bool fwd = false) {
     return S;
 }
 
+static int gn_chunk1_capacity() {
+    static std::atomic<int> cap{-1};
+    int v = cap.load();
+    if (v >= 0) return v;
+    int dev = 0, cus = 0, best = 1 << 30;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        cap.store(0);
+        return 0;
+    }
+    const void* ks[4] = {reinterpret_cast<const void*>(&gn_chunk1_fwd_kernel<8>), reinterpret_cast<const void*>(&gn_chunk1_fwd_kernel<16>),
+                         reinterpret_cast<const void*>(&gn_chunk1_bwd_kernel<8>), reinterpret_cast<const void*>(&gn_chunk1_bwd_kernel<16>)};
+    for (int i = 0; i < 4; ++i) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ks[i], 256, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            nb = 0;
+        }
+        if (nb * cus < best) best = nb * cus;
+    }
+    if (const char* e = getenv("VD_GN_CHUNK1_CAPACITY")) best = atoi(e);       // tests: pretend a smaller device
+    cap.store(best);
+    return best;
+}
+
+// a timeout reported by an earlier polling launch fails every later GroupNorm call until vd_async_errors(1) clears it
+static int gn_sticky(const char* who) {
+    const unsigned n = gn_flag_read();
+    if (n == 0) return 0;
+    vd_set_error("%s: %u GroupNorm poll timeout(s) reported by an earlier one-launch chunked kernel (statistics were NaN); "
+                 "vd_async_errors(1) clears the flag, VD_GN_CHUNK1_OFF=1 selects the two-launch form", who, n);
+    return VD_ETIMEDOUT;
+}
+
 }  // namespace
+
+extern "C" int vd_async_errors(int clear) {
+    const unsigned n = gn_flag_read();
+    if (clear && g_gn_flag_host) *reinterpret_cast<volatile unsigned*>(g_gn_flag_host) = 0u;
+    return (int)(n > 0x7fffffffu ? 0x7fffffffu : n);
+}
 
 extern "C" int64_t vd_groupnorm_ws_floats(int B, int C, int HW, int G) {
     if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
@@ -1050,14 +1126,16 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
                     ((((uintptr_t)y) & 15) == 0);
     const bool reg_ok = al && slab <= GN_REG_MAX;
     const int S = (al && ws) ? gn_chunks(B, C, HW, G, true) : 0;
-    if (S && gn_chunk1_ok((hipStream_t)stream)) {       // one launch: the chunk stays in registers between statistics and apply
+    if (const int rc = gn_sticky("vd_groupnorm_fwd")) return rc;
+    if (S && gn_chunk1_ok((hipStream_t)stream, S)) {       // one launch: the chunk stays in registers between statistics and apply
         unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + 4 * (int64_t)B * G * S);
+        unsigned* flag = gn_flag_dev();
         if (slab / S > 8192)
             hipLaunchKernelGGL((gn_chunk1_fwd_kernel<16>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, words, C, HW,
-                               G, S, eps, apply_silu, x_bstride, y_bstride, gn_next_epoch());
+                               G, S, eps, apply_silu, x_bstride, y_bstride, gn_next_epoch(), flag, gn_poll_max());
         else
             hipLaunchKernelGGL((gn_chunk1_fwd_kernel<8>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, words, C, HW,
-                               G, S, eps, apply_silu, x_bstride, y_bstride, gn_next_epoch());
+                               G, S, eps, apply_silu, x_bstride, y_bstride, gn_next_epoch(), flag, gn_poll_max());
         VD_LAUNCH_CHECK("vd_groupnorm_fwd");
         return 0;
     }
@@ -1192,6 +1270,7 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
     VD_REQUIRE(dy && x && mean && rstd && gamma && beta && dx && dgamma_ws && dbeta_ws, "vd_groupnorm_bwd: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 64, "vd_groupnorm_bwd: bad dims");
     VD_REQUIRE(!rowsum || rowsum_ld >= C, "vd_groupnorm_bwd: rowsum_ld < C");
+    if (const int rc = gn_sticky("vd_groupnorm_bwd")) return rc;
     const int64_t slab = (int64_t)(C / G) * HW;
     const int L = HW / 4;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)extra) | ((uintptr_t)extra2)) & 15) == 0 &&
@@ -1224,17 +1303,18 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
         VD_LAUNCH_CHECK("vd_groupnorm_bwd");
         return 0;
     }
-    if (S && gn_chunk1_ok((hipStream_t)stream)) {
+    if (S && gn_chunk1_ok((hipStream_t)stream, S)) {
+        unsigned* flag = gn_flag_dev();
         float* rs_part = rowsum ? ws + 2 * (int64_t)B * G * S : nullptr;
         unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + 4 * (int64_t)B * G * S);
         if (slab / S > 8192)
             hipLaunchKernelGGL((gn_chunk1_bwd_kernel<16>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
                                dgamma_ws, dbeta_ws, words, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride, extra2,
-                               extra2_bstride, rs_part, gn_next_epoch());
+                               extra2_bstride, rs_part, gn_next_epoch(), flag, gn_poll_max());
         else
             hipLaunchKernelGGL((gn_chunk1_bwd_kernel<8>), dim3(B * G * S), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, extra, dx,
                                dgamma_ws, dbeta_ws, words, C, HW, G, S, apply_silu, dy_bstride, x_bstride, extra_bstride, dx_bstride, extra2,
-                               extra2_bstride, rs_part, gn_next_epoch());
+                               extra2_bstride, rs_part, gn_next_epoch(), flag, gn_poll_max());
         if (rowsum)
             hipLaunchKernelGGL(gn_chunk_rowsum_kernel, dim3(vd_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, rs_part, rowsum, B, C, G, S,
                                rowsum_ld);

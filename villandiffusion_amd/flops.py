@@ -47,3 +47,21 @@ def unet_forward_flops(net, breakdown: bool = False):
     f["conv_in_out"] += 2.0 * 9 * net._conv_out.cin * net.out_channels * S * S
     total = sum(f.values())
     return (total, f) if breakdown else total
+
+
+# ---- which matrix pipe a kernel symbol runs on (bench.py prices a kernel against the dense peak of the arithmetic it executes) ----
+# Split-precision kernels: every algorithmic product term is three bf16 MFMAs (hi*hi + hi*lo + lo*hi) -> 2500 TFLOP/s dense bf16 peak on
+# ALGORITHMIC FLOPs, x3 for the executed fraction.  Everything else that `ops` records with kind "mfma" runs on v_mfma_f32_32x32x2_f32 (157.3).
+SPLIT_PRECISION_FAMILIES = ("bx3", "attn_core", "attn_flash", "k32", "wgrad9", "wgrad1x1_wide", "presplit")
+EXACT_F32_FAMILIES = ("gemm_kernel<", "gemm_plain_kernel", "conv3_patch_kernel", "wgrad_patch_kernel", "wgrad_patch_gen_kernel", "wgrad_kernel<",
+                      "wgrad_small_kernel", "conv3_fewout_kernel", "conv3_smallm_kernel", "attn_small")
+
+
+def is_split_precision(kernel_name: str) -> bool:
+    """True for kernels of the split-precision (bf16 x 3) arithmetic; raises for a matrix kernel that is in neither list, so a new kernel cannot be
+    priced against the wrong peak silently (round 4 priced `attn_flash_kernel` against the f32 peak: 0.79 printed, 0.05 true)."""
+    if any(f in kernel_name for f in SPLIT_PRECISION_FAMILIES):
+        return True
+    if any(f in kernel_name for f in EXACT_F32_FAMILIES):
+        return False
+    raise KeyError(f"matrix kernel {kernel_name!r} is in neither SPLIT_PRECISION_FAMILIES nor EXACT_F32_FAMILIES (villandiffusion_amd/flops.py)")

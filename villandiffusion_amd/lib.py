@@ -46,6 +46,7 @@ class WgradDesc(C.Structure):
 PROTOTYPES = {
     "vd_abi_version": (_i32, []),
     "vd_last_error": (C.c_char_p, []),
+    "vd_async_errors": (_i32, [_i32]),
     "vd_device_ok": (_i32, []),
     "vd_gemm": (_i32, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_tile": (_i32, [C.POINTER(GemmDesc)]),
@@ -93,7 +94,7 @@ PROTOTYPES = {
     "vd_mse_fwd_bwd": (_i32, [_vp] * 6 + [_i32, _i64, _f32, _vp]),
     "vd_loss_fwd_bwd": (_i32, [_vp] * 6 + [_i32, _i64, _f32, _i32, _vp]),
     "vd_l2norm_sq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
-    "vd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "vd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "vd_sched_step": (_i32, [_vp] * 5 + [_i64] + [_f32] * 7 + [C.c_uint64, C.c_uint64, _vp]),
     "vd_batch_l2norm": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "vd_postprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
@@ -143,7 +144,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vd_abi_version() != 10:
+    if lib.vd_abi_version() != 11:
         raise VillanHipError("libvillan_hip.so ABI version mismatch")
     _lib = lib
     return lib

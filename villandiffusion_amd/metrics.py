@@ -64,9 +64,10 @@ def activation_statistics(act):
 
 def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
     """d^2 = |mu1 - mu2|^2 + Tr(S1 + S2 - 2 sqrt(S1 S2))  -- the FID of two Gaussian activation statistics
-    (fid_score.py:150-203, Sutherland's stable version).  The statistics themselves need InceptionV3 pool3 activations, i.e. the
-    pt_inception weights the reference downloads (fid_score.py:31-33): not available without a network, so measure() reports
-    FID = None; with activations from elsewhere this function finishes the job."""
+    (fid_score.py:150-203, Sutherland's stable version).  The statistics come from InceptionV3 pool3 activations computed on the HIP
+    kernels (`inception.py`, `fid_score.py`); `measure()` fills FID when the published pt_inception weight file is present locally
+    (`$VILLAN_FID_WEIGHTS`: the reference downloads it, fid_score.py:31-33, and the box has no network) and records None with the reason
+    otherwise."""
     import numpy as np
     from scipy import linalg
     mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)

@@ -906,12 +906,12 @@ def l2norm_sq(g, partial, out_sq):
     return out_sq
 
 
-def adam_step(p, g, m, v, norm_sq, max_norm, inv_scale, lr, beta1, beta2, eps, step):
+def adam_step(p, g, m, v, norm_sq, max_norm, inv_scale, lr, beta1, beta2, eps, step, skipped=None):
     global WEIGHTS_EPOCH
     WEIGHTS_EPOCH += 1
     _timed("adam_step (adam_kernel)", 28.0 * p.numel(), "hbm", lambda: L.check(      # p, g, m, v read; p, m, v written
         _lib().vd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm_sq), max_norm, inv_scale, lr, beta1, beta2,
-                            eps, step, _s()), "vd_adam_step"))
+                            eps, step, _p(skipped), _s()), "vd_adam_step"))
 
 
 # --------------------------------------------------------------------------------------------- samplers / data

@@ -169,7 +169,7 @@ class DiffusionPipeline:
 
     @torch.no_grad()
     def sample_concurrent(self, inits, num_inference_steps: Optional[int] = None, n_streams: int = 2, eta: Optional[float] = None,
-                          chunk_ids=None):
+                          chunk_ids=None, n_chunks_total: Optional[int] = None, max_numel: Optional[int] = None):
         """Throughput mode of the measure / sampling loops (reference VillanDiffusion.py:1062-1067 walks its chunks of `eval_max_batch` one after
         the other): the chunks of `inits` are denoised `n_streams` at a time, each on its own HIP stream with its own captured forward, its own
         split-K workspace and its own copy of the scheduler state, stepping in lock-step on the host.  A denoising step is ~250 kernels, a fifth
@@ -178,7 +178,10 @@ class DiffusionPipeline:
         must be set); chunk c owns the offset range starting at `chunk_rng_offset(c, ...)`, so a chunk's result does not depend on what runs beside
         it: it is bit-identical to a sequential `__call__` started at the same offset (`sample_sequential` does exactly that).  `chunk_ids`:
         GLOBAL index of every chunk in the caller's chunk list (rank-sharded measure jobs; default 0, 1, ...), so that two ranks never draw the
-        same noise and a chunk's images do not depend on the world size.  Returns the list of final states (device tensors)."""
+        same noise and a chunk's images do not depend on the world size; `n_chunks_total` / `max_numel`: chunk count and largest chunk of the
+        WHOLE job (all ranks) -- the stride of the offset ranges and the amount the scheduler's offset advances by are then the same on every
+        rank, including ranks that own only the short last chunk or none at all (defaults: this call's own list).  Returns the list of final
+        states (device tensors)."""
         import copy
         unet, dev = self.unet, self.device
         n = num_inference_steps if num_inference_steps is not None else self.default_steps
@@ -197,8 +200,7 @@ class DiffusionPipeline:
             # refreshes on whichever stream is current and marks the version fresh, so a refresh left to chunk 0's stream would race with the
             # replays of chunks 1.. on their own streams (they would skip it and read the buffer while it is being rewritten).
             unet.refresh_packed(False)
-        numel = max(c.numel() for c in inits)
-        chunk_ids = list(range(len(inits))) if chunk_ids is None else [int(c) for c in chunk_ids]
+        numel, chunk_ids, n_total = self._chunk_plan(inits, chunk_ids, n_chunks_total, max_numel)
         for first in range(0, len(inits), n_streams):
             group = list(range(first, min(first + n_streams, len(inits))))
             states = []
@@ -230,27 +232,38 @@ class DiffusionPipeline:
                 main.wait_stream(streams[k])
                 outs[ci] = states[k][1]
         if hasattr(base, "_rng_offset"):
-            base._rng_offset = off0 + self.chunk_rng_offset(max(chunk_ids) + 1, len(ts), numel)
+            base._rng_offset = off0 + self.chunk_rng_offset(n_total, len(ts), numel)
         return outs
 
+    @staticmethod
+    def _chunk_plan(inits, chunk_ids, n_chunks_total, max_numel):
+        """(stride numel, global chunk ids, global chunk count) of a chunked sampling call; see `sample_concurrent`."""
+        chunk_ids = list(range(len(inits))) if chunk_ids is None else [int(c) for c in chunk_ids]
+        own = max((c.numel() for c in inits), default=0)
+        numel = own if max_numel is None else int(max_numel)
+        n_total = (max(chunk_ids) + 1 if chunk_ids else 0) if n_chunks_total is None else int(n_chunks_total)
+        if numel < own or any(c >= n_total for c in chunk_ids):
+            raise ValueError("chunk plan: max_numel / n_chunks_total smaller than this call's own chunks")
+        return numel, chunk_ids, n_total
+
     @torch.no_grad()
-    def sample_sequential(self, inits, num_inference_steps: Optional[int] = None, eta: Optional[float] = None, chunk_ids=None):
+    def sample_sequential(self, inits, num_inference_steps: Optional[int] = None, eta: Optional[float] = None, chunk_ids=None,
+                          n_chunks_total: Optional[int] = None, max_numel: Optional[int] = None):
         """The chunks of `inits` one after the other with the SAME per-chunk Philox offsets as `sample_concurrent`: seeded stochastic samplers
         then give identical images whatever VILLAN_SAMPLER_STREAMS / the world size is.  Returns the list of final states (device tensors)."""
         base = self.scheduler
         n = num_inference_steps if num_inference_steps is not None else self.default_steps
         base.set_timesteps(n)
         off0 = getattr(base, "_rng_offset", 0)
-        numel = max(c.numel() for c in inits)
+        numel, chunk_ids, n_total = self._chunk_plan(inits, chunk_ids, n_chunks_total, max_numel)
         outs = []
         kw = {} if eta is None else {"eta": eta}
-        chunk_ids = list(range(len(inits))) if chunk_ids is None else [int(c) for c in chunk_ids]
         for ci, c in enumerate(inits):
             if hasattr(base, "_rng_offset"):
                 base._rng_offset = off0 + self.chunk_rng_offset(chunk_ids[ci], n, numel)
             outs.append(self(batch_size=len(c), init=c, num_inference_steps=n, return_tensor=True, **kw))
         if hasattr(base, "_rng_offset"):
-            base._rng_offset = off0 + self.chunk_rng_offset(max(chunk_ids) + 1, n, numel)
+            base._rng_offset = off0 + self.chunk_rng_offset(n_total, n, numel)
         return outs
 
     @staticmethod

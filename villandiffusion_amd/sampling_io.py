@@ -51,6 +51,12 @@ def _concurrent_ok(pipeline, chunks, eta) -> bool:
     return seeded or not stochastic
 
 
+def _seeded_scheduler(pipeline) -> bool:
+    from .pipelines import DiffusionPipeline
+    return (type(pipeline).__call__ is DiffusionPipeline.__call__ and hasattr(pipeline, "sample_sequential")
+            and getattr(pipeline.scheduler, "device_rng_seed", None) is not None)
+
+
 def _seeded_chunks(pipeline, chunks) -> bool:
     """Explicit inits + in-kernel noise on a plain pipeline: the per-chunk Philox offsets of pipelines.chunk_rng_offset apply."""
     from .pipelines import DiffusionPipeline
@@ -64,15 +70,24 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
                         rank: int = 0, world: int = 1):
     """model.py:504-527; with `world` > 1 each rank samples its own slice of the chunk list (replicas only).  A rank's chunks are denoised
     sampler_streams() at a time on their own streams where that gives the same images (see _concurrent_ok), else one after the other."""
-    cnt, mine = 0, []
+    cnt, mine, n_total, max_numel = 0, [], 0, 0
     for k, (c, n) in enumerate(_chunks(sample_n, init, max_batch_n)):
         if k % world == rank:
             mine.append((c, n, cnt, k))
         cnt += n
+        n_total += 1
+        if c is not None:
+            max_numel = max(max_numel, c.numel())
+    # the Philox offset ranges of the chunks are laid out over the WHOLE job (every rank's chunks, the largest chunk's size): rank-local values
+    # made consecutive calls (clean set, then backdoor set) overlap between ranks
+    plan = dict(n_chunks_total=n_total, max_numel=max_numel)
     from .pipelines import _post
+    if not mine and n_total and max_numel and _seeded_scheduler(pipeline):
+        pipeline.sample_sequential([], num_inference_steps=num_inference_steps, eta=eta, chunk_ids=[], **plan)   # no chunk here: advance the offset only
+        return None
     if _concurrent_ok(pipeline, [(c, n) for c, n, _, _ in mine], eta):
         xs = pipeline.sample_concurrent([c for c, _, _, _ in mine], num_inference_steps=num_inference_steps, n_streams=sampler_streams(), eta=eta,
-                                        chunk_ids=[k for _, _, _, k in mine])
+                                        chunk_ids=[k for _, _, _, k in mine], **plan)
         for (c, n, start, _), x in zip(mine, xs):
             save_imgs(_post(x), path, start_cnt=start)
         return None
@@ -80,7 +95,7 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
         # in-kernel noise, one chunk at a time: the same per-chunk Philox ranges as the concurrent walk, so the images (and every score computed
         # from them) do not depend on VILLAN_SAMPLER_STREAMS or on the number of ranks
         xs = pipeline.sample_sequential([c for c, _, _, _ in mine], num_inference_steps=num_inference_steps, eta=eta,
-                                        chunk_ids=[k for _, _, _, k in mine])
+                                        chunk_ids=[k for _, _, _, k in mine], **plan)
         for (c, n, start, _), x in zip(mine, xs):
             save_imgs(_post(x), path, start_cnt=start)
         return None

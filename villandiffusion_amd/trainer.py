@@ -33,6 +33,8 @@ class FusedAdam:
         self.step_count = 0
         self._partial = torch.empty(1024, device=model.flat_param.device, dtype=torch.float32)
         self.grad_norm_sq = torch.zeros(1, device=model.flat_param.device, dtype=torch.float32)
+        # steps the Adam kernel skipped because the gradient norm was not finite (device word, bumped by the kernel; read lazily by Trainer)
+        self.skipped = torch.zeros(1, device=model.flat_param.device, dtype=torch.int32)
 
     def step(self, lr: Optional[float] = None, grad_inv_scale: float = 1.0, need_norm: bool = False):
         m = self.model
@@ -43,7 +45,7 @@ class FusedAdam:
             nsq = self.grad_norm_sq
         ops.adam_step(m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, nsq,
                       float(self.max_grad_norm if self.max_grad_norm is not None else 3.0e38), grad_inv_scale, self.lr if lr is None else lr, self.betas[0],
-                      self.betas[1], self.eps, self.step_count)
+                      self.betas[1], self.eps, self.step_count, skipped=self.skipped if nsq is not None else None)
 
     def grad_norm(self, grad_inv_scale: float = 1.0) -> float:
         """Global L2 norm of the (averaged) gradient of the last step -- synchronises; for logging/tests only."""
@@ -59,10 +61,10 @@ class FusedAdam:
         self.lr = float(sd.get("lr", self.lr))
 
 
-def allreduce_flat_grad(flat_grad: torch.Tensor, n_buckets: int = 4):
+def allreduce_flat_grad(flat_grad: torch.Tensor, n_buckets: int = 4, even_alone: bool = False):
     """SUM all-reduce of the flat gradient in a few large buckets (RCCL over xGMI: ring all-reduce is per-link bound,
     so few large messages; backend "nccl" IS RCCL on ROCm, "gloo" in the CPU tests)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not even_alone):
         return
     n = flat_grad.numel()
     per = (n + n_buckets - 1) // n_buckets
@@ -174,7 +176,8 @@ class GraphedMicroStep:
 
 class Trainer:
     def __init__(self, model, loss_fn, lr: float, total_steps: int, warmup_steps: int = 500, grad_accum: int = 1,
-                 max_grad_norm: Optional[float] = 1.0, n_allreduce_buckets: int = 4, graph_micro_step: Optional[bool] = None):
+                 max_grad_norm: Optional[float] = 1.0, n_allreduce_buckets: int = 4, graph_micro_step: Optional[bool] = None,
+                 force_ddp_path: bool = False):
         self.model, self.loss_fn = model, loss_fn
         self.base_lr = lr
         self.opt = FusedAdam(model, lr, max_grad_norm=max_grad_norm)
@@ -192,13 +195,17 @@ class Trainer:
         self.scale_check_every, self.scale_growth_every = 100, 2000
         self._since_growth = 0
         self.overflow_steps_seen = 0
+        self._skipped_seen = 0                    # value of opt.skipped at the last lazy check
         self.loss_fn.grad_scale = self._scale() / self.grad_accum
         self._pending = []                        # async all-reduce handles of the current optimiser step
         self._sync_now = False
         # HIP-graph replay of the micro-step: on by default where a step is launch-bound (gradient accumulation = small micro-batches), single process
         self.graph_micro_step = (self.grad_accum > 1) if graph_micro_step is None else bool(graph_micro_step)
         self._graphs: Dict = {}
-        if self.world > 1 and hasattr(model, "grad_buckets"):
+        # force_ddp_path: the schedule of a multi-rank step (bucket hooks fired from the explicit backward, eager micro-step, one all-reduce per
+        # bucket) on a process group of ANY size, including 1 -- what rank 0 of an 8-GPU run executes minus the wire time (bench.py --ddp-path)
+        self.ddp_path = (self.world > 1 or (force_ddp_path and dist.is_available() and dist.is_initialized())) and hasattr(model, "grad_buckets")
+        if self.ddp_path:
             model.bucket_ready_hook = self._bucket_ready      # overlap the all-reduce with the rest of backward
         model.zero_grad()
 
@@ -212,18 +219,38 @@ class Trainer:
     def _scale(self) -> float:
         return self.loss_scale if getattr(self.model, "conv_math", None) == "f16" else 1.0
 
-    def _check_scale(self):
-        """Lazy GradScaler: read the last gradient norm back once in a while; halve the scale after an overflow, double it after a clean stretch."""
+    def check_skipped(self, force: bool = False):
+        """Lazy finite-gradient check, every arithmetic: the Adam kernel leaves the parameters alone when the gradient norm is not finite and
+        counts the step on the device; that counter is read back every `scale_check_every` optimiser steps (and from `state_dict`).
+
+        * f16 mode (GradScaler semantics, reference VillanDiffusion.py:260-264 -> accelerate): ANY skipped step since the last check halves the
+          loss scale and restarts the growth interval; skipped steps are taken back out of Adam's bias-correction count and the LR schedule
+          (GradScaler / accelerate skip both), at the check rather than at the step -- the price of not synchronising every step;
+        * every other arithmetic has no scale to lower: a non-finite gradient norm is a broken run (NaN statistics out of a GroupNorm poll
+          timeout, a diverged model, ...) and raises instead of training on silently."""
         self._since_growth += 1
-        if self._scale() == 1.0 or self.sched_step % self.scale_check_every:
+        if not force and self.sched_step % self.scale_check_every:
             return
-        if not math.isfinite(float(self.opt.grad_norm_sq)):
+        if self.opt.max_grad_norm is None and self._scale() == 1.0:
+            return                                   # no norm kernel in this configuration: nothing was counted
+        skipped = int(self.opt.skipped)
+        new = skipped - self._skipped_seen
+        self._skipped_seen = skipped
+        if new > 0 and self._scale() == 1.0:
+            raise FloatingPointError(f"{new} optimiser step(s) had a non-finite gradient norm and were skipped by the Adam kernel "
+                                     f"(arithmetic {getattr(self.model, 'conv_math', '?')!r}; asynchronous kernel errors, e.g. GroupNorm poll "
+                                     f"timeouts: {ops.L.load().vd_async_errors(0)}; last library error: {ops.L.last_error()!r})")
+        if new > 0:
             self.loss_scale = max(1.0, self.loss_scale * 0.5)
-            self.overflow_steps_seen += 1
+            self.overflow_steps_seen += new
             self._since_growth = 0
-        elif self._since_growth >= self.scale_growth_every:
+            self.opt.step_count = max(0, self.opt.step_count - new)
+            self.sched_step = max(0, self.sched_step - new)
+        elif self._scale() != 1.0 and self._since_growth >= self.scale_growth_every:
             self.loss_scale = min(float(2 ** 24), self.loss_scale * 2.0)
             self._since_growth = 0
+
+    _check_scale = check_skipped
 
     @property
     def lr(self) -> float:
@@ -234,7 +261,7 @@ class Trainer:
         """One micro-step; returns the (un-divided) loss tensor of this micro-batch."""
         sync = (self.micro + 1) % self.grad_accum == 0 or last_batch   # accelerate: sync on every G-th and on the last batch
         self._sync_now = sync and self.model.bucket_ready_hook is not None
-        if self.micro == 0:                                            # (the scale never changes inside an accumulation window)
+        if self.micro % self.grad_accum == 0:                          # first micro-step of an accumulation window (the scale never changes inside one)
             self._step_scale = self._scale()
         self.loss_fn.grad_scale = self._step_scale / self.grad_accum
         loss = self._graphed(batch, timesteps, noise, target_key, poison_key)
@@ -250,7 +277,7 @@ class Trainer:
                     w.wait()
                 self._pending = []
             else:
-                allreduce_flat_grad(self.model.flat_grad, self.n_buckets)
+                allreduce_flat_grad(self.model.flat_grad, self.n_buckets, even_alone=self.ddp_path)
             self._sync_now = False
             self.opt.step(lr=self.lr, grad_inv_scale=1.0 / (self.world * self._step_scale), need_norm=self._step_scale != 1.0)
             self.sched_step += 1
@@ -261,7 +288,7 @@ class Trainer:
     def _graphed(self, batch, timesteps, noise, target_key, poison_key):
         """The micro-step as a HIP-graph replay, or None when this step has to run eagerly."""
         m, lf = self.model, self.loss_fn
-        if not self.graph_micro_step or self.world > 1 or not hasattr(m, "_run_backward") or getattr(lf, "_sde", None) == "SDE-VE":
+        if not self.graph_micro_step or self.ddp_path or not hasattr(m, "_run_backward") or getattr(lf, "_sde", None) == "SDE-VE":
             return None
         x0, R = batch[target_key], batch[poison_key]
         if len(x0) == 0 or getattr(m, "device", torch.device("cpu")).type != "cuda" or not hasattr(m, "_packed"):
@@ -279,8 +306,15 @@ class Trainer:
         return g(x0, R, noise.to(dev), timesteps.to(dev))
 
     def state_dict(self) -> Dict:
-        return {"optimizer": self.opt.state_dict(), "micro": self.micro, "sched_step": self.sched_step}
+        if getattr(self.model, "device", torch.device("cpu")).type == "cuda":
+            self.check_skipped(force=True)            # a checkpoint never records steps the kernel refused
+        return {"optimizer": self.opt.state_dict(), "micro": self.micro, "sched_step": self.sched_step,
+                "loss_scale": self.loss_scale, "since_growth": self._since_growth, "overflow_steps_seen": self.overflow_steps_seen}
 
     def load_state_dict(self, sd: Dict):
         self.opt.load_state_dict(sd["optimizer"])
         self.micro, self.sched_step = int(sd["micro"]), int(sd["sched_step"])
+        self.loss_scale = float(sd.get("loss_scale", self.loss_scale))          # (absent from checkpoints written before round 5)
+        self._since_growth = int(sd.get("since_growth", 0))
+        self.overflow_steps_seen = int(sd.get("overflow_steps_seen", 0))
+        self._skipped_seen = int(self.opt.skipped)

@@ -47,7 +47,7 @@ def _ensure_path(root: nn.Module, parts: Sequence[str]) -> nn.Module:
 # ----------------------------------------------------------------------------------------------------------- layers
 CONV_MATH_DEFAULT = os.environ.get("VILLAN_CONV_MATH", "bf16x3")
 if CONV_MATH_DEFAULT not in ("bf16x3", "f32", "f16"):
-    raise ValueError(f"VILLAN_CONV_MATH must be 'bf16x3' or 'f32', got {CONV_MATH_DEFAULT!r}")
+    raise ValueError(f"VILLAN_CONV_MATH must be 'bf16x3', 'f32' or 'f16', got {CONV_MATH_DEFAULT!r}")
 
 
 class _PackedConvWeights:
@@ -999,9 +999,33 @@ class UNet2DModel(nn.Module):
             torch.cuda.current_stream(self._dev).wait_stream(self._wg_side)
             self._wg_keep = []
 
+    def _bucket_boundary(self, i: int, hook):
+        """Gradient bucket `i` is complete once the weight gradients queued so far have run: hand it to the all-reduce WITHOUT stalling the
+        input-gradient chain.  Round 4 joined the side stream into the main stream here (`_cs_flush`), so the backward chain of the next
+        bucket waited for every weight gradient of this one -- a schedule the single-process step never had, and one nobody had timed
+        (round-4 review).  Now the bucket's segmented column sums and the hook (torch.distributed's all-reduce, which orders its
+        communication stream after the CURRENT stream) are issued on the weight-gradient side stream: the collective waits for exactly the
+        kernels that produce the bucket, the main stream never waits.  Operands stay referenced until the join at the end of the pass.
+        `VILLAN_BUCKET_JOIN=1` (or no side stream) restores the joining form."""
+        if not self.wgrad_stream or os.environ.get("VILLAN_BUCKET_JOIN", "0") == "1":
+            self._cs_flush()
+            hook(i)
+            return
+        if self._wg_side is None:
+            self._wg_side = torch.cuda.Stream(device=self._dev)
+        self._wg_flush()
+        self._wg_side.wait_stream(torch.cuda.current_stream(self._dev))      # the row-sum partials the column sums read were written on main
+        with torch.cuda.stream(self._wg_side):
+            self._cs_launch()
+            hook(i)
+        self._wg_keep.append(("bucket", i))                                  # the end-of-pass join must happen even with no job queued
+
     def _cs_flush(self):
         self._wg_flush()
         self._wg_join()
+        self._cs_launch()
+
+    def _cs_launch(self):
         jobs = self._cs_jobs
         if not jobs:
             return
@@ -1243,11 +1267,9 @@ class UNet2DModel(nn.Module):
         while sv:
             if hook is not None:                                  # gradient buckets complete in the order up|out, mid, down
                 if len(sv) == st.marks["mid_end"]:
-                    self._cs_flush()
-                    hook(0)
+                    self._bucket_boundary(0, hook)
                 elif len(sv) == st.marks["down_end"]:
-                    self._cs_flush()
-                    hook(1)
+                    self._bucket_boundary(1, hook)
             rec = sv.pop()
             kind = rec[0]
             if kind in ("res", "attn"):
