@@ -523,6 +523,16 @@ def main():
         # ---- the MULTI-RANK schedule on this one GPU (reference VillanDiffusion.py:440, 1161-1166): what rank 0 of an 8-GPU run
         #      executes minus the wire time -- a size-1 RCCL communicator, one all-reduce per gradient bucket fired from the backward pass ----
         if world == 1 and not args.no_ddp_path:
+            # RCCL prints its version banner / INFO lines through C stdio: they must not land on the stdout that carries the ONE JSON line.
+            # Its debug file takes what honours NCCL_DEBUG_FILE; fd 1 points at stderr for the length of the leg and C stdio is flushed before it
+            # is restored (the banner sat in libc's buffer until exit and came out AFTER the JSON line on the first run of this leg).
+            import ctypes
+            import tempfile
+            if "NCCL_DEBUG_FILE" not in os.environ:
+                os.environ["NCCL_DEBUG_FILE"] = os.path.join(tempfile.gettempdir(), "vd_bench_rccl_ddp_path.%h.%p.log")
+            sys.stdout.flush()
+            saved_fd1 = os.dup(1)
+            os.dup2(2, 1)
             try:
                 import socket
                 if not dist.is_initialized():
@@ -554,6 +564,12 @@ def main():
                 trainer._pending, trainer._sync_now = [], False
                 if dist.is_initialized():
                     dist.destroy_process_group()
+                try:
+                    ctypes.CDLL(None).fflush(None)
+                except OSError:
+                    pass
+                os.dup2(saved_fd1, 1)
+                os.close(saved_fd1)
 
         # ---- the same K steps with every contraction on the exact-f32 MFMA (reported beside the headline, not as `value`) ----
         if net.conv_math != "f32" and not args.no_exact:

@@ -128,6 +128,11 @@ typedef struct vd_gemm_desc {
                                 ([nb][C][H][W], batch stride act_bstride) by the workgroups of the first channel tile.  The TRAINING forward
                                 saves it for the weight gradient instead of running a separate GroupNorm + SiLU pass (round 4).           */
     int64_t act_bstride;
+    int32_t b_presplit;      /* ABI 11.  1: B is a PRE-SPLIT image (vd_presplit_* below: bf16 (hi, lo) pairs, 8 channels of a pixel per 16-byte
+                                unit) instead of f32 NCHW -- same bytes, same batch stride, same channel-octet offsets.  Only the persistent
+                                16x16x32 convolution (vd_gemm_tile() == 18) with a_packed, math 0, VD_B_CONV3 / VD_B_CONV3_T and no gn_ss takes
+                                it: the patch loader then moves (hi, lo) units without converting.  Anything else: VD_EINVAL.      */
+    int32_t reserved_;
 } vd_gemm_desc;
 
 int vd_gemm(const vd_gemm_desc* desc, void* stream);
@@ -161,6 +166,11 @@ typedef struct vd_wgrad_desc {
                                  ~1e-5 relative): VD_B_CONV3 / VD_B_CONV3_UP with 8x8 / 16x16 / 32x32 outputs, either of them on images whose
                                  width is a multiple of 32 from 64 up, VD_B_CONV3 at 4x4, or VD_B_PLAIN (1x1) with
                                  NP % 8 == 0; M >= 64, C >= 64; otherwise VD_EINVAL */
+    int32_t presplit;         /* ABI 11, math == 1 only.  Bit 0: X, bit 1: dY is a PRE-SPLIT image (vd_presplit_* below) instead of f32 NCHW.
+                                 3 (both): the kernel fetches both operands by LDS-DMA and reads them through ds_read_b64_tr_b16 -- no
+                                 conversion, no staging registers (VD_B_CONV3 at 8x8 / 16x16 / 32x32 outputs, M % 8 == C % 8 == 0, grouped
+                                 launches only).  Any other non-zero value, or a problem outside that set: VD_EINVAL.               */
+    int32_t reserved_;
 } vd_wgrad_desc;
 
 int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);
@@ -168,6 +178,31 @@ int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream);
 int64_t vd_conv_wgrad_ws_floats(const vd_wgrad_desc* desc);
 /* Tile and split count vd_conv_wgrad will use (profiling / tests). */
 int vd_conv_wgrad_plan(const vd_wgrad_desc* desc, int* tile, int* splits);
+
+/* ------------------------------------------------------------------------------------------
+ * PRE-SPLIT activation images (round 5, ABI 11) -- csrc/vd_presplit.hip.
+ * The split-precision kernels contract f32 operands as bf16 (hi, lo) pairs; a pre-split image holds those pairs as its PRODUCER
+ * wrote them, so that no consumer converts: unit (o, p, part) = 16 bytes = channels 8o .. 8o+7 of pixel p as bf16 (part 0 = hi =
+ * bf16(x), part 1 = lo = bf16(x - hi)) at byte ((o * HW + p) * 2 + part) * 16 of the image.  Same bytes, batch stride and
+ * channel-octet offsets as the f32 [C][HW] image it replaces; C % 8 == 0.  Consumers: vd_gemm_desc.b_presplit (3x3 convolution
+ * forward / input gradient), vd_wgrad_desc.presplit (grouped 3x3 weight gradient: LDS-DMA + transposed LDS reads).
+ * Replaces the F.group_norm + F.silu -> F.conv2d hand-over inside diffusers ResnetBlock2D (reference loss.py:993).
+ * ------------------------------------------------------------------------------------------ */
+/* f32 NCHW -> pre-split image and back (x = hi + lo: 16 significant bits); strides in floats. */
+int vd_presplit_pack(const float* x, void* y, int B, int C, int HW, int64_t x_bstride, int64_t y_bstride, void* stream);
+int vd_presplit_unpack(const void* y, float* x, int B, int C, int HW, int64_t y_bstride, int64_t x_bstride, void* stream);
+/* GroupNorm (+ SiLU) forward whose output IS the pre-split image (one read of x, one write of the pairs; mean / rstd as
+ * vd_groupnorm_fwd).  _ok: 1 when a kernel exists for (C, HW, G) -- the 16x16 / 32x32 levels with 4 .. 16 channels per group. */
+int vd_groupnorm_fwd_presplit_ok(int C, int HW, int G);
+int vd_groupnorm_fwd_presplit(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int B, int C, int HW, int G,
+                              float eps, int apply_silu, int64_t x_bstride, int64_t y_bstride, void* stream);
+/* GroupNorm (+ SiLU) backward (same shapes) as vd_groupnorm_bwd_fused -- dgamma_ws / dbeta_ws rows per (image, channel), residual gradients extra /
+ * extra2 added into dx, rowsum[b][c] = sum_p dx -- with dx written as f32 (dx), as the pre-split image (dx_ps: the operand of the producing
+ * convolution's input AND weight gradient), or both; at least one of the two must be given. */
+int vd_groupnorm_bwd_presplit(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              const float* extra, const float* extra2, float* dx, void* dx_ps, float* dgamma_ws, float* dbeta_ws, float* rowsum,
+                              int B, int C, int HW, int G, int apply_silu, int64_t dy_bstride, int64_t x_bstride, int64_t extra_bstride,
+                              int64_t extra2_bstride, int64_t dx_bstride, int64_t ps_bstride, int64_t rowsum_ld, void* stream);
 
 /* GROUPED weight gradients: several split-precision (math = 1) weight gradients of one kernel class in ONE launch pair (compute +
  * fixed-order slab reduction).  A weight gradient has a small output and a huge reduction length (K = batch * pixels), so a launch

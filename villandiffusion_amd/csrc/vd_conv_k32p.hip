@@ -58,8 +58,12 @@ struct k32p_args {
 
 // F16 (math = 2): the operands are single f16 planes -- packed weights [chunk][tap][q][Mpad] (vd_conv3_pack_weights_f16), patch planes [c2][q] --
 // and a product term is ONE v_mfma_f32_16x16x32_f16.  NPART = planes per operand (2: bf16 hi / lo, 1: f16); every index below is written in it.
-template <int TW, int MODE, bool DMA, bool PIPE, bool F16>   // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP, 3: CONV3 of silu(GroupNorm(x))
+// PS (round 5, vd_gemm_desc.b_presplit): the input is a PRE-SPLIT image (vd_presplit.hip: unit (octet, pixel, part) = the 8 channels of a pixel as bf16
+// hi / lo, 16 bytes, at ((octet * HW + pixel) * 2 + part) * 16) written by its producer -- a patch item is then two 16-byte loads that go to LDS as they
+// are: no conversion (24 VALU instructions per item), 2 instead of 8 loads per item.  Same values, same LDS image, same MFMA order: same bits.
+template <int TW, int MODE, bool DMA, bool PIPE, bool F16, bool PS = false>   // MODE 0: CONV3, 1: CONV3_T (flipped taps), 2: CONV3_UP, 3: CONV3 of silu(GroupNorm(x))
 __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
+    static_assert(!PS || (!F16 && MODE != 3), "pre-split inputs: split-precision arithmetic, no folded GroupNorm");
     const vd_gemm_desc& d = a.d;
     constexpr int BM = 128, NPIX = 256, NTH = 512;
     constexpr int NPART = F16 ? 1 : 2;
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     constexpr int A_UNITS = 2 * A_HALF;                           // 3072 units = 48 KB per buffer (f16: 24 KB)
     constexpr int A_IT = A_UNITS / NTH;                           // 6 (3)
     constexpr int P_IT = (PIMG + 127) / 128;                      // 3
+    constexpr int P_LOADS = PS ? 2 * P_IT : 8 * P_IT;             // vector-memory loads of one patch per thread (counted vmcnt waits below)
     constexpr int RED_UNITS = 8 * 64 * 2 * 4 / 16;                // gn_part scratch: [wave][64 channels][2] floats = 4 KB
     // ONE LDS object (a second __shared__ array beside an LDS-DMA target makes hipcc wait vmcnt(0) before every ds_read: guide §5 item 4a)
     __shared__ u32x4 lds[2 * A_UNITS + 4 * NPART * PLANE + RED_UNITS];
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
         pdst[i] = ((cq >> 1) * 2 * NPART + (cq & 1)) * PLANE + rem;      // Ps[c2][part = 0][q][pixel]; the lo part sits 2 * PLANE further
     }
     unsigned poff[P_IT];
+    unsigned poff_lo[PS ? P_IT : 1];                              // PS: the lo unit's offset (a masked item must stay out of range: 0xFFFFFFFF + 16 would wrap)
     unsigned pmask = 0;
     __amdgpu_buffer_rsrc_t xrs;
     __amdgpu_buffer_rsrc_t ors;                                  // MODE 3, d.act_out: the normalised activation's image of the tile's batch item
@@ -153,7 +159,12 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                 iy >>= 1;
                 ix >>= 1;
             }
-            poff[i] = ok ? 4u * (unsigned)(cq * 8 * HWs + iy * d.W + ix) : 0xFFFFFFFFu;
+            if constexpr (PS) {
+                poff[i] = ok ? 32u * (unsigned)(cq * HWs + iy * d.W + ix) : 0xFFFFFFFFu;
+                poff_lo[i] = ok ? poff[i] + 16u : 0xFFFFFFFFu;
+            } else {
+                poff[i] = ok ? 4u * (unsigned)(cq * 8 * HWs + iy * d.W + ix) : 0xFFFFFFFFu;
+            }
             pmask |= (ok ? 1u : 0u) << i;
         }
         act_store = MODE == 3 && d.act_out != nullptr && m0_ == 0;      // every element once: the workgroups of the first channel tile
@@ -171,7 +182,8 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     };
 
     u32x4 ra[DMA ? 1 : A_IT];
-    float rp[P_IT][8];
+    float rp[PS ? 1 : P_IT][8];
+    u32x4 cph[P_IT], cpl[P_IT];
     unsigned aoff[6];             // (A_IT <= 6; sized by a constant: with `aoff[A_IT]`, A_IT depending on F16, hipcc 7.2 emits no host stubs for this template)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -199,6 +211,15 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
         }
     };
     auto load_p = [&](int cp) {
+        if constexpr (PS) {                                       // the (hi, lo) units of the item, as they will sit in LDS
+            const unsigned so = 32u * (unsigned)(cp * 4 * HWs);                                  // wave-uniform: chunk pair = 4 octets
+#pragma unroll
+            for (int i = 0; i < P_IT; ++i) {
+                cph[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, poff[i], so, 0));
+                cpl[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, poff_lo[i], so, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned so = 4u * (unsigned)((cp * 32 + j) * HWs);                           // wave-uniform
@@ -206,8 +227,8 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
             for (int i = 0; i < P_IT; ++i) rp[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, poff[i], so, 0));
         }
     };
-    u32x4 cph[P_IT], cpl[P_IT];
     auto convert_p = [&](int cp) {
+        if constexpr (PS) return;
         float ss[16];
         if (MODE == 3) {
 #pragma unroll
@@ -489,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     set_patch_tile(b0, y0, x0, m0);
     load_a(m0, 0, 0, 0);
     load_p(0);
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * P_IT) : "memory");        // the DMA stage (issued first) has landed
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LOADS) : "memory");        // the DMA stage (issued first) has landed
     store_a(0);
     convert_p(0);
     write_p();
@@ -549,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                 }
                 if constexpr (DMA) {
                     // this stage's DMAs (issued before any patch load of this stage) must have landed before the barrier that releases M(s+1)
-                    if (r == 1 && pnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * P_IT) : "memory");
+                    if (r == 1 && pnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LOADS) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
@@ -622,6 +643,7 @@ extern "C" int vd_conv3_pack_weights_f16_multi(const int64_t* table, int n_jobs,
 bool vd_conv3_k32p_eligible(const vd_gemm_desc& d) {
     static const int off = env_int("VD_K32P_OFF", 0);
     if (off || d.C % 32 != 0 || d.bias_on_n || d.d_trans || d.nb2 > 1) return false;
+    if (d.b_presplit && (d.b_presplit != 1 || d.gn_ss || d.math == 2 || (d.b_bstride & 3) || (((uintptr_t)d.B) & 15))) return false;
     const int TW = d.OW == 16 ? 16 : 32, TR = 256 / TW;
     if (d.OW % TW != 0 || d.OH % TR != 0 || d.OH * d.OW != d.NP) return false;
     if (d.OW == 16 && d.OH != 16) return false;
@@ -684,6 +706,14 @@ int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st) {
         return 0;                                                                                                    \
     }
 #endif
+#define VD_K32P_PS(WW, MD)                                                                                           \
+    if (d.b_presplit && TW == WW && mode == MD) {                                                                    \
+        hipLaunchKernelGGL((conv3_k32p_kernel<WW, MD, true, true, false, true>), dim3(grid), dim3(512), 0, st, a);   \
+        return 0;                                                                                                    \
+    }
+    VD_K32P_PS(32, 0) VD_K32P_PS(32, 1) VD_K32P_PS(32, 2) VD_K32P_PS(16, 0) VD_K32P_PS(16, 1) VD_K32P_PS(16, 2)
+#undef VD_K32P_PS
+    if (d.b_presplit) return -1;
     VD_K32P_CASE(32, 0) VD_K32P_CASE(32, 1) VD_K32P_CASE(32, 2) VD_K32P_CASE(32, 3)
     VD_K32P_CASE(16, 0) VD_K32P_CASE(16, 1) VD_K32P_CASE(16, 2) VD_K32P_CASE(16, 3)
 #undef VD_K32P_CASE

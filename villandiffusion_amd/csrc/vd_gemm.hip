@@ -19,6 +19,8 @@
 // vd_conv_k32p.hip: the persistent 16x16x32 split-precision 3x3 convolution (its own translation unit)
 bool vd_conv3_k32p_eligible(const vd_gemm_desc& d);
 int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st);
+// vd_presplit.hip: the grouped 3x3 weight gradient with both operands pre-split (LDS-DMA + transposed reads)
+int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int blocks, hipStream_t st);
 // vd_gemm_k32p.hip: the persistent 16x16x32 split-precision 1x1 convolution / plain product
 bool vd_gemm1x1_k32p_pick(const vd_gemm_desc& d);
 int vd_launch_gemm1x1_k32p(const vd_gemm_desc& d, hipStream_t st);
@@ -2186,6 +2188,9 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
     VD_REQUIRE(desc != nullptr, "vd_gemm: null desc");
     vd_gemm_desc d = *desc;
     VD_REQUIRE(d.A && d.B && d.D, "vd_gemm: null operand");
+    VD_REQUIRE(d.b_presplit == 0 || (d.b_presplit == 1 && vd_gemm_tile(&d) == 18),
+               "vd_gemm: a pre-split B operand (b_presplit = %d) is read by the persistent 16x16x32 convolution only (vd_gemm_tile() == 18; this problem: %d)",
+               d.b_presplit, d.b_presplit == 1 ? vd_gemm_tile(&d) : 0);
 #ifndef VD_ABLATION
     VD_REQUIRE(d.debug == 0, "vd_gemm: desc.debug = %d -- timing-only ablation bits exist in `make ABLATION=1` builds only", d.debug);
 #endif
@@ -2340,6 +2345,7 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
     VD_REQUIRE(desc != nullptr, "vd_conv_wgrad: null desc");
     vd_wgrad_desc d = *desc;
     VD_REQUIRE(d.dY && d.X && d.dW, "vd_conv_wgrad: null operand");
+    VD_REQUIRE(d.presplit == 0, "vd_conv_wgrad: pre-split operands (presplit = %d) are taken by the grouped launches only (vd_conv_wgrad_group_*)", d.presplit);
     VD_REQUIRE(d.T == 9 || d.T == 1, "vd_conv_wgrad: T must be 1 or 9");
     VD_REQUIRE((d.T == 1) == (d.mode == VD_B_PLAIN), "vd_conv_wgrad: T/mode mismatch");
     VD_REQUIRE(d.NP == d.OH * d.OW && d.NP % 4 == 0 && d.OW % 4 == 0, "vd_conv_wgrad: NP/OW must be multiples of 4");
@@ -2463,8 +2469,16 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
 // ---- grouped weight gradients -----------------------------------------------------------------------------------------------
 // Class of a split-precision weight gradient = the kernel instantiation it runs on; only jobs of one class share a launch.
 //   3x3: 4 * W + 2 * (CONV3_UP) + (wide image)   (W = 32 / 16 / 8 / 4),   stride-2 3x3: 2000 + W (W = 16 / 8),   1x1: 1000,   0: not groupable
+//   both operands PRE-SPLIT (d.presplit == 3, round 5): 3000 + 4 * W (plain 3x3 at 8x8 / 16x16 / 32x32)
 static int wgrad_group_class(const vd_wgrad_desc& d) {
     if (d.math != 1 || d.splits != 0 || d.tile != 0) return 0;
+    if (d.presplit != 0) {
+        if (d.presplit != 3 || d.T != 9 || d.mode != VD_B_CONV3 || (d.OW != 8 && d.OW != 16 && d.OW != 32) || d.OH != d.OW || d.H != d.OH || d.W != d.OW ||
+            (d.M & 7) || (d.C & 7) || d.M < 64 || d.C < 64 || (d.dy_bstride & 3) || (d.x_bstride & 3) || ((((uintptr_t)d.dY) | ((uintptr_t)d.X)) & 15) ||
+            (int64_t)d.M * d.NP * 4 >= (1ll << 32) || (int64_t)d.C * d.NP * 4 >= (1ll << 32))
+            return 0;
+        return 3000 + 4 * d.OW;
+    }
     if (wgrad1x1_bx3_eligible(d)) return 1000;
     if (d.T != 9 || wgrad_patch_kind(d) != 4) return 0;
     if (d.mode == VD_B_CONV3_S2) return d.OW >= 64 ? 2000 + 33 : 2000 + d.OW;       // stride 2: 2000 + W (8 / 16 / 32), 2033 = 32-pixel segments of wide outputs
@@ -2483,6 +2497,7 @@ extern "C" int64_t vd_conv_wgrad_group_job_bytes(void) { return (int64_t)sizeof(
 // Which kernel vd_conv_wgrad_group_launch runs for a class: 9 = wgrad9_group_kernel (all nine taps per workgroup), 32 = wgrad_k32_group_kernel
 // (16x16x32 one-tap-row kernel, the default where it applies), 0 = wgrad_bx3_group_kernel / wgrad1x1_bx3_group_kernel (profiling names, tests).
 extern "C" int vd_conv_wgrad_group_variant(int cls) {
+    if (cls >= 3000) return 3000;                   // wgrad_ps_group_kernel (pre-split operands)
     if (wgrad9_class(cls)) return 9;
     if (cls == 1000) return wgrad1x1_wide_enabled() ? 256 : 0;
     if (cls < 1000 && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled()) return 32;
@@ -2498,7 +2513,7 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     VD_REQUIRE(cls != 0, "vd_conv_wgrad_group_plan: job 0 is not a split-precision (math = 1) 3x3 / 1x1 weight gradient");
     vd_wgrad_job* jobs = reinterpret_cast<vd_wgrad_job*>(table_out);
     const bool one = cls == 1000;
-    const bool nine = wgrad9_class(cls);                         // one workgroup (512 threads, one per CU) per tile produces all nine taps
+    const bool nine = cls < 3000 && wgrad9_class(cls);           // one workgroup (512 threads, one per CU) per tile produces all nine taps
     const bool wide1 = one && wgrad1x1_wide_enabled();           // 1x1: BM x 256 tiles, 32-pixel K-steps, one 512-thread workgroup per CU
     auto job_base = [&](const vd_wgrad_desc& d) -> int64_t {
         if (wide1) return (int64_t)vd_cdiv(d.M, wgrad1x1_wide_bm(d)) * vd_cdiv(d.C, 256);
@@ -2528,7 +2543,7 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     static const int cap9 = getenv("VD_WGRAD9_KCAP") ? atoi(getenv("VD_WGRAD9_KCAP")) : 128;
     static const int tw = getenv("VD_W1X1_WIDE_TARGET") ? atoi(getenv("VD_W1X1_WIDE_TARGET")) : 256;
     static const int capw = getenv("VD_W1X1_WIDE_KCAP") ? atoi(getenv("VD_W1X1_WIDE_KCAP")) : 64;
-    const bool k32 = !one && !nine && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled();      // two workgroups per CU: 512 resident slots
+    const bool k32 = cls >= 3000 || (!one && !nine && cls != 4 * 4 + 0 && !(cls & 1) && wgrad_k32_enabled());      // two workgroups per CU: 512 resident slots
     // (512 = the resident slots; 448 / 384 measured 0.15 ms per config-#2 step faster, same box, three interleaved rounds: the small classes get
     // longer K ranges and fewer slabs, the large ones are capped at 128 steps either way -- profiles/r04_wgrad_k32_target.txt)
     static const int t32 = getenv("VD_WGRAD_K32_TARGET") ? atoi(getenv("VD_WGRAD_K32_TARGET")) : 448;
@@ -2647,6 +2662,9 @@ extern "C" int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls,
         case 4 * 8 + 2: VD_WG_K32(8, 2) break;
 #undef VD_WG_K32
         case 4 * 4 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<4, 0>), grid, dim3(NT), 0, st, jobs, n); break;
+        case 3000 + 4 * 32: case 3000 + 4 * 16: case 3000 + 4 * 8:
+            VD_REQUIRE(vd_launch_wgrad_ps_group(dev_table, n, (cls - 3000) / 4, blocks, st) == 0, "vd_conv_wgrad_group_launch: no pre-split kernel for class %d", cls);
+            break;
         case 2000 + 33: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 4, true>), grid, dim3(NT), 0, st, jobs, n); break;
         case 2000 + 32: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 4>), grid, dim3(NT), 0, st, jobs, n); break;
         case 2000 + 16: hipLaunchKernelGGL((wgrad_bx3_group_kernel<16, 4>), grid, dim3(NT), 0, st, jobs, n); break;

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
                 ("ldd", _i64), ("d_bstride", _i64), ("res_bstride", _i64), ("rowadd_bstride", _i64), ("ws", _vp), ("pad", _i32), ("nb2", _i32),
                 ("a_b2stride", _i64), ("b_b2stride", _i64), ("d_b2stride", _i64), ("gn_ss", _vp), ("a_packed", _vp), ("a_packed_mpad", _i32), ("math", _i32), ("pool2", _i32),
                 ("kh", _i32), ("kw", _i32), ("conv_stride", _i32), ("pad_h", _i32), ("pad_w", _i32), ("act", _i32),
-                ("gn_part", _vp), ("act_out", _vp), ("act_bstride", _i64)]
+                ("gn_part", _vp), ("act_out", _vp), ("act_bstride", _i64), ("b_presplit", _i32), ("reserved_", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -39,7 +39,7 @@ class WgradDesc(C.Structure):
                 ("M", _i32), ("C", _i32), ("T", _i32), ("nb", _i32), ("NP", _i32),
                 ("H", _i32), ("W", _i32), ("OH", _i32), ("OW", _i32),
                 ("mode", _i32), ("splits", _i32), ("accumulate", _i32), ("tile", _i32),
-                ("dy_bstride", _i64), ("x_bstride", _i64), ("pad", _i32), ("math", _i32)]
+                ("dy_bstride", _i64), ("x_bstride", _i64), ("pad", _i32), ("math", _i32), ("presplit", _i32), ("reserved_", _i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/villan_hip.h
@@ -54,6 +54,11 @@ PROTOTYPES = {
     "vd_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "vd_conv_wgrad_plan": (_i32, [C.POINTER(WgradDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "vd_conv_wgrad_ws_floats": (_i64, [C.POINTER(WgradDesc)]),
+    "vd_presplit_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
+    "vd_presplit_unpack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp]),
+    "vd_groupnorm_fwd_presplit_ok": (_i32, [_i32, _i32, _i32]),
+    "vd_groupnorm_fwd_presplit": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i64, _i64, _vp]),
+    "vd_groupnorm_bwd_presplit": (_i32, [_vp] * 12 + [_vp, _i32, _i32, _i32, _i32, _i32] + [_i64] * 7 + [_vp]),
     "vd_conv_wgrad_group_class": (_i32, [C.POINTER(WgradDesc)]),
     "vd_conv_wgrad_group_job_bytes": (_i64, []),
     "vd_conv_wgrad_group_variant": (_i32, [_i32]),

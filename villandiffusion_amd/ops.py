@@ -73,6 +73,133 @@ def _img(t: torch.Tensor):
     return B, Cc, H, W, (st[0] if B > 1 else Cc * H * W)
 
 
+# --------------------------------------------------------------------------------------------- pre-split activation images
+class PreSplit:
+    """A [B, C, H, W] activation held as its PRE-SPLIT image (include/villan_hip.h "PRE-SPLIT activation images": per pixel and channel octet the
+    bf16 hi / lo halves the split-precision kernels contract, written once by the producer).  `t` is the float32 tensor whose storage carries the
+    image: same shape, bytes, batch stride and channel-octet offsets as the f32 tensor it replaces -- only the meaning of the bytes differs, so
+    nothing but a kernel that declares a pre-split operand may read it."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        assert t.dtype == torch.float32 and t.dim() == 4 and t.shape[1] % 8 == 0, (t.dtype, t.shape)
+        self.t = t
+
+    shape = property(lambda self: self.t.shape)
+    device = property(lambda self: self.t.device)
+
+    def stride(self, *a):
+        return self.t.stride(*a)
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def channels(self, lo: int, hi: int) -> "PreSplit":
+        """The channel slice [lo, hi) (whole octets): an O8 image of a channel range is the same bytes as the f32 slice."""
+        assert lo % 8 == 0 and hi % 8 == 0
+        return PreSplit(self.t[:, lo:hi])
+
+
+def _unwrap(x):
+    """(tensor, is_presplit)"""
+    return (x.t, True) if isinstance(x, PreSplit) else (x, False)
+
+
+def presplit_empty(shape, device) -> PreSplit:
+    return PreSplit(torch.empty(shape, device=device, dtype=torch.float32))
+
+
+def presplit_pack(x: torch.Tensor, out: Optional[PreSplit] = None) -> PreSplit:
+    Bn, Cc, H, W, xbs = _img(x)
+    out = presplit_empty(x.shape, x.device) if out is None else out
+    assert tuple(out.shape) == tuple(x.shape)
+    _timed("presplit_pack (presplit_pack_kernel)", 8.0 * x.numel(), "hbm", lambda: L.check(
+        _lib().vd_presplit_pack(_p(x), _p(out.t), Bn, Cc, H * W, xbs, _img(out.t)[4], _s()), "vd_presplit_pack"))
+    return out
+
+
+def presplit_unpack(y: PreSplit, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    Bn, Cc, H, W, ybs = _img(y.t)
+    out = torch.empty(y.shape, device=y.device, dtype=torch.float32) if out is None else out
+    L.check(_lib().vd_presplit_unpack(_p(y.t), _p(out), Bn, Cc, H * W, ybs, _img(out)[4], _s()), "vd_presplit_unpack")
+    return out
+
+
+def groupnorm_presplit_ok(Cc: int, HW: int, G: int) -> bool:
+    return bool(_lib().vd_groupnorm_fwd_presplit_ok(Cc, HW, G))
+
+
+def groupnorm_fwd_presplit(x, gamma, beta, y: PreSplit, mean, rstd, G, eps, silu) -> PreSplit:
+    """y = the pre-split image of silu?(GroupNorm(x)); mean / rstd as groupnorm_fwd."""
+    Bn, Cc, H, W, xbs = _img(x)
+    assert tuple(y.shape) == tuple(x.shape) and mean.numel() >= Bn * G and rstd.numel() >= Bn * G
+    _timed("groupnorm_fwd_presplit (gn_fwd_ps_kernel<*>)", 8.0 * x.numel(), "hbm", lambda: L.check(
+        _lib().vd_groupnorm_fwd_presplit(_p(x), _p(gamma), _p(beta), _p(y.t), _p(mean), _p(rstd), Bn, Cc, H * W, G, eps, int(silu), xbs,
+                                         _img(y.t)[4], _s()), "vd_groupnorm_fwd_presplit"))
+    return y
+
+
+_PS_CONV_OK = {}
+
+
+def conv_presplit_ok(Bn: int, Cin: int, Cout: int, OH: int, OW: int, mode: int) -> bool:
+    """Would conv3x3(PreSplit input [Bn, Cin, ..] -> [Bn, Cout, OH, OW], mode, a_packed=...) be taken by the persistent 16x16x32 kernel, the only
+    reader of pre-split images?  (vd_gemm_tile() == 18 with b_presplit = 1; asked once per shape.)"""
+    key = (Bn, Cin, Cout, OH, OW, mode)
+    ok = _PS_CONV_OK.get(key)
+    if ok is None:
+        H, W = (OH // 2, OW // 2) if mode == B_CONV3_UP else (OH, OW)
+        d = GemmDesc()
+        d.A = d.B = d.D = d.a_packed = 64                  # (non-null placeholders: vd_gemm_tile() only looks at shapes, strides and alignment)
+        d.a_packed_mpad = (Cout + 127) // 128 * 128
+        d.M, d.N, d.K = Cout, Bn * OH * OW, Cin * 9
+        d.a_mode, d.b_mode, d.NP = A_ROW, mode, OH * OW
+        d.C, d.H, d.W, d.OH, d.OW = Cin, H, W, OH, OW
+        d.alpha = 1.0
+        d.lda, d.b_bstride, d.ldd, d.d_bstride = Cin * 9, Cin * H * W, OH * OW, Cout * OH * OW
+        d.b_presplit = 1
+        ok = _PS_CONV_OK[key] = int(_lib().vd_gemm_tile(C.byref(d))) == 18
+    return ok
+
+
+def wgrad_presplit_ok(Bn: int, Cin: int, Cout: int, S: int) -> bool:
+    """Is there a grouped pre-split weight-gradient kernel for a plain 3x3 convolution Cin -> Cout on S x S images?"""
+    d = WgradDesc()
+    d.dY = d.X = d.dW = 64
+    d.M, d.C, d.T, d.nb, d.NP = Cout, Cin, 9, Bn, S * S
+    d.H = d.W = d.OH = d.OW = S
+    d.mode, d.accumulate, d.math, d.presplit = B_CONV3, 1, 1, 3
+    d.dy_bstride, d.x_bstride = Cout * S * S, Cin * S * S
+    return int(_lib().vd_conv_wgrad_group_class(C.byref(d))) >= 3000
+
+
+def groupnorm_bwd_presplit(dy, x, mean, rstd, gamma, beta, dx, dx_ps, dgamma_ws, dbeta_ws, G, silu, extra=None, extra2=None, rowsum=None,
+                           rowsum_ld=None):
+    """groupnorm_bwd whose dx goes out as f32 (`dx`, may be None), as a pre-split image (`dx_ps`: PreSplit, may be None) or both."""
+    Bn, Cc, H, W, xbs = _img(x)
+    dbs = _img(dy)[4]
+    assert dx is not None or dx_ps is not None
+    dxbs = _img(dx)[4] if dx is not None else 0
+    psbs = _img(dx_ps.t)[4] if dx_ps is not None else 0
+    assert dx is None or dx.shape == x.shape
+    assert dx_ps is None or tuple(dx_ps.shape) == tuple(x.shape)
+    ebs = _img(extra)[4] if extra is not None else 0
+    e2bs = _img(extra2)[4] if extra2 is not None else 0
+    assert dgamma_ws.numel() >= Bn * Cc and dbeta_ws.numel() >= Bn * Cc
+    assert (extra is None or extra.shape == x.shape) and (extra2 is None or extra2.shape == x.shape)
+    rld = 0
+    if rowsum is not None:
+        rld = Cc if rowsum_ld is None else rowsum_ld
+        assert rld >= Cc
+    nbytes = (8.0 + (4.0 if dx is not None else 0.0) + (4.0 if dx_ps is not None else 0.0) + (4.0 if extra is not None else 0.0)
+              + (4.0 if extra2 is not None else 0.0)) * x.numel()
+    _timed("groupnorm_bwd_presplit (gn_bwd_ps_kernel<*>)", nbytes, "hbm", lambda: L.check(
+        _lib().vd_groupnorm_bwd_presplit(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(extra), _p(extra2), _p(dx),
+                                         _p(dx_ps.t) if dx_ps is not None else None, _p(dgamma_ws), _p(dbeta_ws), _p(rowsum), Bn, Cc, H * W, G,
+                                         int(silu), dbs, xbs, ebs, e2bs, dxbs, psbs, rld, _s()), "vd_groupnorm_bwd_presplit"))
+    return dx_ps if dx_ps is not None else dx
+
+
 # --------------------------------------------------------------------------------------------- GEMM family
 _GEMM_WS = {}
 _WS_SLOT = 0
@@ -114,12 +241,14 @@ def _gemm_ws(n_floats: int, device):
 def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bstride=0, ldb=0, b_bstride=0,
          ldd=0, d_bstride=0, bias=None, bias_on_n=False, rowadd=None, rowadd_bstride=0, residual=None,
          res_bstride=0, conv=None, alpha=1.0, d_trans=False, accumulate=False, tile=0, debug=0, pad=0, nb2=0, a_b2stride=0,
-         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False, convg=None, act=0, gn_part=None, act_out=None):
+         b_b2stride=0, d_b2stride=0, gn_ss=None, a_packed=None, math_mode=0, pool2=False, convg=None, act=0, gn_part=None, act_out=None,
+         b_presplit=False):
     """gn_part: optional [B, NP // 256, M, 2] buffer for the per-tile channel sums of the result (vd_gemm_desc.gn_part); it is filled only when the
     launch goes to the 16x16x32 split-precision convolution -- ops.GN_PART_WRITTEN tells the caller right after the call."""
     global GN_PART_WRITTEN
     d = GemmDesc()
     d.act = act
+    d.b_presplit = int(b_presplit)
     if convg is not None:
         d.kh, d.kw, d.conv_stride, d.pad_h, d.pad_w = convg
     d.pad = pad
@@ -203,7 +332,8 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = f"conv3_k32_kernel<{d.OW}, {md}>"
     elif tl == 18:          # the persistent kernel: template width 16 (16x16 images) or 32 (8-row x 32-column segments of any image); image width beside it
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else 2)
-        name = f"conv3_k32p_kernel<{16 if d.OW == 16 else 32}, {md}, true, true, {'true' if d.math == 2 else 'false'}>" + (f"@{d.OW}" if d.OW > 32 else "")
+        name = (f"conv3_k32p_kernel<{16 if d.OW == 16 else 32}, {md}, true, true, {'true' if d.math == 2 else 'false'}, {'true' if d.b_presplit else 'false'}>"
+                + (f"@{d.OW}" if d.OW > 32 else ""))
     elif tl in (8, 12, 15, 16):
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
         name = f"conv3_bx3_kernel<{d.OW if d.OW <= 64 else 128}, {md}, {4 if tl == 15 else 2}, {256 if tl == 8 else 512}, 2>"
@@ -302,6 +432,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
     """out[b] = W (*) gather_mode(x[b]) + bias (+ rowadd[b,:,None,None]) (+ residual).  w2d: [M, C*9].
     pad: stride-2 mode only (0: zero pad (0,1,0,1); 1: symmetric padding 1).
     pool2 (B_CONV3_T with a_packed only): `out` has HALF the resolution and receives the 2x2 block sums of the result."""
+    x, ps = _unwrap(x)                          # a PreSplit input: the persistent 16x16x32 kernel copies its (hi, lo) units (vd_gemm_desc.b_presplit)
     Bn, Cc, H, W, xbs = _img(x)
     M = w2d.shape[0]
     assert w2d.shape[1] == Cc * 9 and w2d.is_contiguous()
@@ -319,7 +450,7 @@ def conv3x3(x, w2d, bias, out, mode=B_CONV3, rowadd=None, rowadd_bstride=0, resi
     return gemm(w2d, x, out, M=M, N=Bn * OH * OW, K=Cc * 9, b_mode=mode, NP=OH * OW, lda=Cc * 9, b_bstride=xbs,
                 ldd=OHo * OWo, d_bstride=obs, bias=bias, rowadd=rowadd, rowadd_bstride=rowadd_bstride,
                 residual=residual, res_bstride=rbs, conv=(Cc, H, W, OH, OW), accumulate=accumulate, tile=tile, debug=debug,
-                pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2, gn_part=gn_part, act_out=act_out)
+                pad=pad, gn_ss=gn_ss, a_packed=a_packed, pool2=pool2, gn_part=gn_part, act_out=act_out, b_presplit=ps)
 
 
 def conv2d_general(x, w2d, bias, out, kh, kw, stride=1, pad_h=0, pad_w=0, relu=False):
@@ -449,6 +580,8 @@ def linear_wgrad(dy, x, dw, accumulate=False):
 
 
 def wgrad_desc(dy, x, dw2d, mode, ws=None, accumulate=False, splits=0, tile=0, pad=0, math_mode=0) -> WgradDesc:
+    dy, dy_ps = _unwrap(dy)                     # PreSplit operands: vd_wgrad_desc.presplit (bit 0: x, bit 1: dy)
+    x, x_ps = _unwrap(x)
     Bn, M, OH, OW, dbs = _img(dy)
     Bx, Cc, H, W, xbs = _img(x)
     assert Bx == Bn
@@ -462,6 +595,7 @@ def wgrad_desc(dy, x, dw2d, mode, ws=None, accumulate=False, splits=0, tile=0, p
     d.dy_bstride, d.x_bstride = dbs, xbs
     d.pad = pad
     d.math = math_mode
+    d.presplit = int(x_ps) | (int(dy_ps) << 1)
     return d
 
 
@@ -532,7 +666,7 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
     table is planned by the library and uploaded once per distinct set of operand addresses (steady-state training repeats them)."""
     lib = _lib()
     n = len(descs)
-    key = tuple((d.dY, d.X, d.dW, d.M, d.C, d.T, d.nb, d.NP, d.H, d.W, d.OH, d.OW, d.mode, d.accumulate, d.dy_bstride, d.x_bstride)
+    key = tuple((d.dY, d.X, d.dW, d.M, d.C, d.T, d.nb, d.NP, d.H, d.W, d.OH, d.OW, d.mode, d.accumulate, d.dy_bstride, d.x_bstride, d.presplit)
                 for d in descs)
     ent = _WG_CACHE.get(key)
     ws = _WG_WS.get(device)
@@ -559,7 +693,9 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
     flops = sum(2.0 * d.M * d.C * d.T * d.nb * d.NP for d in descs)
     nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
     var = lib.vd_conv_wgrad_group_variant(ent["cls"])
-    if ent["cls"] > 2000:                                        # stride-2 3x3 classes (2000 + output width; 2033: 32-pixel segments of wide outputs)
+    if ent["cls"] >= 3000:                                       # both operands pre-split: LDS-DMA + transposed reads (vd_presplit.hip)
+        name = f"wgrad_ps_group_kernel<{(ent['cls'] - 3000) // 4}>(+group_reduce)"
+    elif ent["cls"] > 2000:                                      # stride-2 3x3 classes (2000 + output width; 2033: 32-pixel segments of wide outputs)
         name = "wgrad_bx3_group_kernel<32, 4, true>(+group_reduce)" if ent["cls"] == 2033 else f"wgrad_bx3_group_kernel<{ent['cls'] - 2000}, 4, false>(+group_reduce)"
     elif ent["cls"] == 1000:                                     # symbol names as rocprofv3 prints them
         name = "wgrad1x1_wide_group_kernel(+group_reduce)" if var == 256 else "wgrad1x1_bx3_group_kernel(+group_reduce)"

@@ -185,12 +185,21 @@ class _Conv:
         return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
                            rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk, gn_part=gn_part, act_out=act_out)
 
-    def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False):
-        """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient."""
+    def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False, dout_ps=None):
+        """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient.  x a PreSplit image (round 5): the weight gradient
+        then wants dY pre-split too -- `dout_ps` when the producer of dout wrote one (dout itself may then be None), else a pack pass queued on the
+        weight-gradient stream -- and the input gradient reads `dout_ps` when it is there."""
         net = self.net
-        bx3 = _split(net) and ops.wgrad_bx3_eligible(self.cout, self.cin, dout.shape[2], dout.shape[3],
-                                                                                       self.mode) and x.stride(0) % 4 == 0
-        net.wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=int(bx3))
+        if isinstance(x, ops.PreSplit):
+            dy_ps = dout_ps if dout_ps is not None else net.pack_later(dout)
+            net.wgrad(dy_ps, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=1)
+            if dout_ps is not None:
+                dout = dout_ps                                # the input gradient copies (hi, lo) units too
+        else:
+            assert dout is not None
+            bx3 = _split(net) and ops.wgrad_bx3_eligible(self.cout, self.cin, dout.shape[2], dout.shape[3],
+                                                                                           self.mode) and x.stride(0) % 4 == 0
+            net.wgrad(dout, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=int(bx3))
         if not skip_bias:
             B = dout.shape[0]
             ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
@@ -237,6 +246,19 @@ class _Norm:
                           net.eps, self.silu)
         return mean, rstd
 
+    def fwd_ps(self, x):
+        """y = silu?(gn(x)) as a PRE-SPLIT image (ops.PreSplit): what the 3x3 convolution and its weight gradient read without converting."""
+        net = self.net
+        B = x.shape[0]
+        mean = torch.empty(B * self.groups, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        y = ops.presplit_empty(x.shape, x.device)
+        ops.groupnorm_fwd_presplit(x, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], y, mean, rstd, self.groups, net.eps, self.silu)
+        return y, mean, rstd
+
+    def ps_ok(self, HW: int) -> bool:
+        return ops.groupnorm_presplit_ok(self.ch, HW, self.groups)
+
     def stats(self, x, full=False):
         """Statistics-only pass: [B, C, 2] scale / shift pairs consumed by _Conv.fwd(gn_ss=...) (inference path; round 4: the training forward
         too).  full: also the (mean, rstd) the backward pass needs."""
@@ -272,15 +294,21 @@ class _Norm:
                                           self.groups, net.eps)
         return (ss, mean, rstd) if full else ss
 
-    def bwd(self, dy, x, mean, rstd, dx, extra=None, extra2=None, rowsum=None):
+    def bwd(self, dy, x, mean, rstd, dx, extra=None, extra2=None, rowsum=None, dx_ps=None):
         """extra / extra2: residual gradients added into dx; rowsum ([B, C] view, row stride free): per-image channel sums of the dx
-        written, i.e. the bias-gradient rows of the layer that produced x, from the same pass."""
+        written, i.e. the bias-gradient rows of the layer that produced x, from the same pass.  dx_ps (ops.PreSplit): dx ALSO (dx given) or ONLY
+        (dx None) as a pre-split image -- the operand of the producing convolution's input and weight gradients (needs ps_ok(HW))."""
         net = self.net
         B = x.shape[0]
         wg, wb = net.scratch_bc(B, self.ch, 1), net.scratch_bc(B, self.ch, 2)
-        ops.groupnorm_bwd(dy, x, mean, rstd, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], dx, wg, wb,
-                          self.groups, self.silu, extra=extra, extra2=extra2, rowsum=rowsum,
-                          rowsum_ld=(rowsum.stride(0) if rowsum is not None else None))
+        if dx_ps is not None:
+            ops.groupnorm_bwd_presplit(dy, x, mean, rstd, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], dx, dx_ps, wg, wb,
+                                       self.groups, self.silu, extra=extra, extra2=extra2, rowsum=rowsum,
+                                       rowsum_ld=(rowsum.stride(0) if rowsum is not None else None))
+        else:
+            ops.groupnorm_bwd(dy, x, mean, rstd, net.P[self.prefix + ".weight"], net.P[self.prefix + ".bias"], dx, wg, wb,
+                              self.groups, self.silu, extra=extra, extra2=extra2, rowsum=rowsum,
+                              rowsum_ld=(rowsum.stride(0) if rowsum is not None else None))
         net.colsum_later(wg, net.G[self.prefix + ".weight"], B, self.ch)
         net.colsum_later(wb, net.G[self.prefix + ".bias"], B, self.ch)
         return dx
@@ -297,9 +325,28 @@ class _Resnet:
         self.norm2 = _Norm(net, prefix + ".norm2", cout, True)
         self.conv2 = _Conv(net, prefix + ".conv2", cout, cout)
         self.has_sc = cin != cout
+        self._ps_cache = {}
         if self.has_sc:
             net._decl(prefix + ".conv_shortcut.weight", (cout, cin, 1, 1), fan_in=cin)
             net._decl(prefix + ".conv_shortcut.bias", (cout,), fan_in=cin, is_bias=True)
+
+    def ps_plan(self, B, H, W) -> bool:
+        """Pre-split operands for this block's two 3x3 convolutions in a TRAINING pass (round 5): both GroupNorms have a pre-split producer kernel,
+        all four convolution launches (conv1 / conv2 forward and input gradient) go to the persistent 16x16x32 kernel -- the only reader of
+        pre-split images -- and both weight gradients have a pre-split grouped kernel.  Decided per (block, batch, image size), cached."""
+        net = self.net
+        if not getattr(net, "presplit", False) or net.conv_math != "bf16x3" or not net.group_wgrad or H != W:
+            return False
+        key = (B, H, W)
+        ok = self._ps_cache.get(key)
+        if ok is None:
+            ci, co = self.cin, self.cout
+            ok = (self.norm1.ps_ok(H * W) and self.norm2.ps_ok(H * W)
+                  and ops.conv_presplit_ok(B, ci, co, H, W, B_CONV3) and ops.conv_presplit_ok(B, co, co, H, W, B_CONV3)
+                  and ops.conv_presplit_ok(B, co, ci, H, W, B_CONV3_T) and ops.conv_presplit_ok(B, co, co, H, W, B_CONV3_T)
+                  and ops.wgrad_presplit_ok(B, ci, co, H) and ops.wgrad_presplit_ok(B, co, co, H))
+            self._ps_cache[key] = ok
+        return ok
 
     def fwd(self, x, out, st, save):
         net = self.net
@@ -378,12 +425,19 @@ class _Resnet:
             else:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
             return (x, None, m1, r1, h1, None, m2, r2)
-        a1 = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
-        m1, r1 = self.norm1.fwd(x, a1)
+        ps = save and self.ps_plan(B, H, W)
+        if ps:                                                # silu(gn(.)) written as the pre-split image its two consumers (convolution, weight gradient) read
+            a1, m1, r1 = self.norm1.fwd_ps(x)
+        else:
+            a1 = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+            m1, r1 = self.norm1.fwd(x, a1)
         h1 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
         self.conv1.fwd(a1, h1, rowadd=st.temb_all[:, self.temb_off:], rowadd_bstride=st.temb_all.stride(0))
-        a2 = torch.empty_like(h1)
-        m2, r2 = self.norm2.fwd(h1, a2)
+        if ps:
+            a2, m2, r2 = self.norm2.fwd_ps(h1)
+        else:
+            a2 = torch.empty_like(h1)
+            m2, r2 = self.norm2.fwd(h1, a2)
         if self.has_sc:
             ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
                         net.P[self.prefix + ".conv_shortcut.bias"], out,
@@ -395,13 +449,17 @@ class _Resnet:
             return (x, a1, m1, r1, h1, a2, m2, r2)
         return None
 
-    def bwd(self, saved, dout, dx, st, dout_rs=None, extra2=None, dx_rs=None):
+    def bwd(self, saved, dout, dx, st, dout_rs=None, extra2=None, dx_rs=None, dout_ps=None, dx_ps=None):
         """dout_rs: [B, cout] per-image channel sums of dout when its producer already made them (else a rowsum launch); extra2: a skip
-        connection's gradient to add into dx; dx_rs: [B, cin] view to receive the sums of dx (both ride in the last GroupNorm backward)."""
+        connection's gradient to add into dx; dx_rs: [B, cin] view to receive the sums of dx (both ride in the last GroupNorm backward).
+        dout_ps: dout as a pre-split image when its producer wrote one too; dx_ps: receives dx as a pre-split image as well (the consumer of dx
+        is another pre-split block's conv2)."""
         net = self.net
         x, a1, m1, r1, h1, a2, m2, r2 = saved
         B, _, H, W = x.shape
         dev = x.device
+        if isinstance(a2, ops.PreSplit):
+            return self._bwd_ps(saved, dout, dx, st, dout_rs, extra2, dx_rs, dout_ps, dx_ps)
         if a2 is None:                                        # folded-GroupNorm forward: the weight gradients' operands are made on their side stream
             a2 = self.norm2.fwd_later(h1)
             a1 = self.norm1.fwd_later(x)
@@ -435,7 +493,42 @@ class _Resnet:
                      a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc, extra2=extra2, rowsum=dx_rs)
         else:
-            self.norm1.bwd(da1, x, m1, r1, dx, extra=dout, extra2=extra2, rowsum=dx_rs)
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dout, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
+        return dx
+
+    def _bwd_ps(self, saved, dout, dx, st, dout_rs, extra2, dx_rs, dout_ps, dx_ps):
+        """The same backward with pre-split operands (ps_plan): a1 / a2 are pre-split images from the forward pass, norm2's backward writes dh1 ONLY as a
+        pre-split image (its two consumers are conv1's input and weight gradients), dout arrives pre-split from its producer or is packed on the
+        weight-gradient stream, and norm1's backward can hand dx on pre-split as well."""
+        net = self.net
+        x, a1, m1, r1, h1, a2, m2, r2 = saved
+        B, _, H, W = x.shape
+        dev = x.device
+        if dout_rs is None:
+            bias_ws = net.scratch_bc(B, self.cout).view(B, self.cout)
+            net.rowsum(dout, bias_ws)
+        else:
+            bias_ws = dout_rs
+        da2 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
+        self.conv2.bwd(dout, a2, da2, bias_ws=bias_ws, dout_ps=dout_ps)
+        dh1 = ops.presplit_empty((B, self.cout, H, W), dev)
+        dt = st.d_temb_all[:, self.temb_off:self.temb_off + self.cout]      # temb projection gradient rows + conv1 bias share rowsum(dh1)
+        self.norm2.bwd(da2, h1, m2, r2, None, rowsum=dt, dx_ps=dh1)
+        da1 = da2 if self.cin == self.cout else torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+        self.conv1.bwd(None, a1, da1, bias_ws=dt, dout_ps=dh1)
+        if self.has_sc:
+            wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
+            net.wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
+                      math_mode=_wgrad1x1_math(net, dout, x))
+            net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout, ld=bias_ws.stride(0))
+            dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+            HW = H * W
+            ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
+                     ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
+                     a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
+        else:
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dout, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
         return dx
 
 
@@ -510,7 +603,8 @@ class _Attn:
             return (x, mean, rstd, g, qkv, P, o)
         return None
 
-    def bwd(self, saved, dout, dx, st, dout_rs=None, extra2=None, dx_rs=None):
+    def bwd(self, saved, dout, dx, st, dout_rs=None, extra2=None, dx_rs=None, dout_ps=None, dx_ps=None):
+        """(dout_ps is not used: the 1x1 products read f32; dx_ps: dx also as a pre-split image for a pre-split ResnetBlock that consumes it.)"""
         net, Cc = self.net, self.ch
         x, mean, rstd, g, qkv, P, o = saved
         B, _, H, W = x.shape
@@ -589,7 +683,7 @@ class _Attn:
         dg = torch.empty((B, Cc, H, W), device=dev, dtype=torch.float32)
         ops.gemm(net.Pq[self.qkv_w], dqkv, dg, M=Cc, N=B * N, K=3 * Cc, a_mode=A_COL, b_mode=B_PLAIN, NP=N, lda=Cc, ldb=N,
                  b_bstride=3 * Cc * N, ldd=N, d_bstride=Cc * N, a_packed=_bx3_packed_1x1(net, self.prefix + "::qkv", True, Cc, 3 * Cc, N, B))
-        self.norm.bwd(dg, x, mean, rstd, dx, extra=dout, extra2=extra2, rowsum=dx_rs)
+        self.norm.bwd(dg, x, mean, rstd, dx, extra=dout, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
         return dx
 
 
@@ -806,6 +900,9 @@ class UNet2DModel(nn.Module):
         # bias-gradient row sums and skip-connection gradient adds ride in the GroupNorm backward that writes the tensor they read
         # (vd_groupnorm_bwd_fused) instead of ~50 rowsum + 12 add_strided launches per step; False: the separate launches
         self.fuse_gn_bwd = os.environ.get("VILLAN_FUSE_GN_BWD", "1") != "0"
+        # round 5: GroupNorm forward / backward write PRE-SPLIT bf16 (hi, lo) images for the 3x3 convolutions and their weight gradients
+        # (csrc/vd_presplit.hip; _Resnet.ps_plan decides per block); VILLAN_PRESPLIT=0: round 4's converting kernels
+        self.presplit = os.environ.get("VILLAN_PRESPLIT", "1") != "0"
         # no-grad forward: the statistics of a ResnetBlock2D's second GroupNorm are summed in the first convolution's epilogue
         # (vd_gemm_desc.gn_part) instead of a read of its output; False: the statistics pass
         self.gn_stats_in_epilogue = os.environ.get("VILLAN_GN_STATS_IN_EPILOGUE", "1") != "0"
@@ -819,6 +916,7 @@ class UNet2DModel(nn.Module):
         # silu(gn(x)) as a side output, norm2's statistics come from conv1's epilogue.  Opt-in: measured +0.2 ms / step (profiles/r04_gn_actout_ab.txt)
         self.fold_gn_train = os.environ.get("VILLAN_FOLD_GN_TRAIN", "0") != "0"
         self._gn_jobs = []
+        self._pk_jobs = []
         # "bf16x3": eligible 3x3 convolutions (forward and stride-1 input gradient at 8x8 / 16x16 / 32x32) run on the bf16 matrix
         # cores as hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of the exact result); "f32": everything on the exact f32 MFMA.
         self.conv_math = CONV_MATH_DEFAULT
@@ -947,6 +1045,16 @@ class UNet2DModel(nn.Module):
             self._gn_jobs = []
         ops.conv_wgrad(dy, x, dw2d, mode, self.wgrad_ws, accumulate=True, pad=pad, math_mode=math_mode)
 
+    def pack_later(self, t):
+        """The pre-split image of `t` (a dY whose producer wrote f32 only) for a queued pre-split weight gradient: packed on the weight-gradient
+        stream right before the grouped launch that reads it (off the critical path), or now when there is no such stream."""
+        out = ops.presplit_empty(t.shape, t.device)
+        if self.wgrad_stream and self.group_wgrad:
+            self._pk_jobs.append((t, out))
+        else:
+            ops.presplit_pack(t, out=out)
+        return out
+
     def gn_later(self, norm, x, y):
         """y = norm(x) (+SiLU) before the next grouped weight-gradient launch, on its stream (see _Norm.fwd_later)."""
         if self.wgrad_stream and self.group_wgrad:
@@ -963,7 +1071,7 @@ class UNet2DModel(nn.Module):
             ops.rowsum(x, ws, ws_ld=ws_ld)
 
     def _wg_flush(self):
-        if not any(self._wg_jobs.values()) and not self._rs_jobs and not self._gn_jobs:
+        if not any(self._wg_jobs.values()) and not self._rs_jobs and not self._gn_jobs and not self._pk_jobs:
             return
         if self.wgrad_stream:
             # Weight gradients are off the critical path of the backward pass: run the grouped launches on a SIDE stream so that they
@@ -975,6 +1083,8 @@ class UNet2DModel(nn.Module):
             main = torch.cuda.current_stream(self._dev)
             self._wg_side.wait_stream(main)
             with torch.cuda.stream(self._wg_side):
+                for t, out in self._pk_jobs:                   # dY operands whose producer wrote f32 only -> pre-split images
+                    ops.presplit_pack(t, out=out)
                 for norm, x, y in self._gn_jobs:               # operands of the queued weight gradients (folded-GroupNorm forward)
                     norm._fwd_now(x, y)
                 for x, ws, ld in self._rs_jobs:
@@ -982,12 +1092,14 @@ class UNet2DModel(nn.Module):
                 for cls, jobs in self._wg_jobs.items():
                     if jobs:
                         ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
-            self._wg_keep.append((self._wg_jobs, self._rs_jobs, self._gn_jobs))
-            self._rs_jobs, self._gn_jobs = [], []
+            self._wg_keep.append((self._wg_jobs, self._rs_jobs, self._gn_jobs, self._pk_jobs))
+            self._rs_jobs, self._gn_jobs, self._pk_jobs = [], [], []
         else:
+            for t, out in self._pk_jobs:
+                ops.presplit_pack(t, out=out)
             for norm, x, y in self._gn_jobs:
                 norm._fwd_now(x, y)
-            self._gn_jobs = []
+            self._gn_jobs, self._pk_jobs = [], []
             for cls, jobs in self._wg_jobs.items():
                 if jobs:
                     ops.conv_wgrad_group([j[0] for j in jobs], self._dev)
@@ -1062,7 +1174,7 @@ class UNet2DModel(nn.Module):
         # a backward pass that raised midway leaves queued weight-gradient / row-sum jobs behind: they must never run in THIS pass
         if self._wg_keep:
             self._wg_join()
-        self._wg_jobs, self._rs_jobs, self._gn_jobs = {}, [], []
+        self._wg_jobs, self._rs_jobs, self._gn_jobs, self._pk_jobs = {}, [], [], []
         if self._wt_buf is None:
             self._wt_buf = torch.empty(self._wt_total, device=self._dev, dtype=torch.float32)
         self._wt_fresh = set()
@@ -1260,7 +1372,17 @@ class UNet2DModel(nn.Module):
         fuse = self.fuse_gn_bwd
         # g_rs: per-image channel sums of g ([B, C] view) when the kernel that wrote g also summed it (vd_groupnorm_bwd_fused), else None
         g_rs = self.scratch_bc(B, final.shape[1]).view(B, final.shape[1]) if fuse else None
-        self.norm_out.bwd(da, final, mo, ro, g, rowsum=g_rs)
+
+        def wants_ps(norm, shape):
+            """Is the next record on the tape (the consumer of the gradient about to be produced) a pre-split ResnetBlock, and can `norm`'s backward
+            kernel write its dx as a pre-split image too?  Then the gradient is handed on in both forms (g, g_ps)."""
+            if not sv or sv[-1][0] != "res" or not isinstance(sv[-1][2][5], ops.PreSplit):
+                return None
+            return ops.presplit_empty(shape, dev) if norm.ps_ok(shape[2] * shape[3]) else None
+
+        # g_ps: g as a pre-split image when its producer wrote one (consumed by a pre-split block's conv2 gradients), else None
+        g_ps = wants_ps(self.norm_out, final.shape)
+        self.norm_out.bwd(da, final, mo, ro, g, rowsum=g_rs, dx_ps=g_ps)
         # `g` is the gradient wrt the output of the most recent forward op; walk the tape backwards.
         slot = n_skip
         hook = self.bucket_ready_hook
@@ -1278,29 +1400,31 @@ class UNet2DModel(nn.Module):
                 is_cat_input = kind == "res" and any(x.data_ptr() == c.data_ptr() and x.shape == c.shape for c in st.cats)
                 dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
                 rs = self.scratch_bc(B, x.shape[1]).view(B, x.shape[1]) if fuse else None
+                dxp = wants_ps(layer.norm1 if kind == "res" else layer.norm, x.shape) if fuse else None
                 if is_cat_input:
                     slot -= 1
                     dcats[slot] = dx
-                    layer.bwd(saved, g, dx, st, dout_rs=g_rs, dx_rs=rs)
+                    layer.bwd(saved, g, dx, st, dout_rs=g_rs, dx_rs=rs, dout_ps=g_ps, dx_ps=dxp)
                     g = dx[:, :up_slots[slot][0]]
                     g_rs = rs[:, :up_slots[slot][0]] if fuse else None
+                    g_ps = dxp.channels(0, up_slots[slot][0]) if dxp is not None and up_slots[slot][0] % 8 == 0 else None
                 elif fuse:                                        # the skip connection's gradient rides in the block's last GroupNorm backward
-                    layer.bwd(saved, g, dx, st, dout_rs=g_rs, extra2=self._skip_grad(x, st, dcats), dx_rs=rs)
-                    g, g_rs = dx, rs
+                    layer.bwd(saved, g, dx, st, dout_rs=g_rs, extra2=self._skip_grad(x, st, dcats), dx_rs=rs, dout_ps=g_ps, dx_ps=dxp)
+                    g, g_rs, g_ps = dx, rs, dxp
                 else:
-                    layer.bwd(saved, g, dx, st)
-                    g = dx
+                    layer.bwd(saved, g, dx, st, dout_ps=g_ps)
+                    g, g_ps = dx, None
                     g = self._add_skip_grad(g, x, st, dcats)
             elif kind == "us":
                 layer, x = rec[1], rec[2]
                 dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
                 layer.bwd(g, x, dx, bias_ws=g_rs)
-                g, g_rs = dx, None
+                g, g_rs, g_ps = dx, None, None
             elif kind == "ds":
                 layer, x = rec[1], rec[2]
                 dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
                 layer.bwd(g, x, dx, bias_ws=g_rs)
-                g, g_rs = self._add_skip_grad(dx, x, st, dcats), None
+                g, g_rs, g_ps = self._add_skip_grad(dx, x, st, dcats), None, None
             elif kind == "conv_in":
                 self._conv_in.bwd(g, rec[1], None, bias_ws=g_rs)
             else:
