@@ -168,8 +168,8 @@ typedef struct vd_wgrad_desc {
                                  NP % 8 == 0; M >= 64, C >= 64; otherwise VD_EINVAL */
     int32_t presplit;         /* ABI 11, math == 1 only.  Bit 0: X, bit 1: dY is a PRE-SPLIT image (vd_presplit_* below) instead of f32 NCHW.
                                  3 (both): the kernel fetches both operands by LDS-DMA and reads them through ds_read_b64_tr_b16 -- no
-                                 conversion, no staging registers (VD_B_CONV3 at 8x8 / 16x16 / 32x32 outputs, M % 8 == C % 8 == 0, grouped
-                                 launches only).  Any other non-zero value, or a problem outside that set: VD_EINVAL.               */
+                                 conversion, no staging registers (VD_B_CONV3 / VD_B_CONV3_UP at 8x8 / 16x16 / 32x32 outputs, M % 8 == C % 8 == 0,
+                                 grouped launches only).  Any other non-zero value, or a problem outside that set: VD_EINVAL.               */
     int32_t reserved_;
 } vd_wgrad_desc;
 

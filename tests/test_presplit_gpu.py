@@ -64,7 +64,7 @@ def test_pack_unpack_follow_the_format_definition():
         ops.PreSplit(torch.zeros(1, 12, 4, 4, device=DEV))          # whole channel octets only
 
 
-GN_SHAPES = [(4, 128, 32), (4, 256, 32), (3, 384, 32), (5, 256, 16), (4, 512, 16), (3, 384, 16)]      # (B, C, side): 4 / 8 / 12 / 8 / 16 / 12 channels per group
+GN_SHAPES = [(4, 128, 32), (4, 256, 32), (3, 384, 32), (5, 256, 16), (4, 512, 16), (3, 384, 16), (6, 128, 16)]      # (B, C, side): 4 / 8 / 12 / 8 / 16 / 12 / 4 channels per group
 
 
 @pytest.mark.parametrize("B,C,S", GN_SHAPES)
@@ -185,37 +185,43 @@ def test_presplit_operand_outside_the_persistent_kernel_fails_loudly():
 
 
 WGRAD_PS = [
-    # side, [(B, Cin, Cout), ...]: one grouped launch per row
-    (32, [(8, 128, 128), (8, 384, 128), (3, 192, 64)]),
-    (16, [(16, 256, 256), (16, 512, 256), (5, 64, 200), (16, 128, 96)]),
-    (8, [(32, 256, 256), (6, 256, 128), (1, 64, 64)]),
-    (32, [(128, 128, 128), (128, 384, 128), (128, 256, 128)]),       # the headline batch: K = 131 072 pixels, 3-12 K ranges per layer
-    (16, [(128, 256, 256), (128, 512, 256), (128, 128, 256)]),
+    # side of the OUTPUT, mode, [(B, Cin, Cout), ...]: one grouped launch per row
+    (32, B_CONV3, [(8, 128, 128), (8, 384, 128), (3, 192, 64)]),
+    (16, B_CONV3, [(16, 256, 256), (16, 512, 256), (5, 64, 200), (16, 128, 96)]),
+    (8, B_CONV3, [(32, 256, 256), (6, 256, 128), (1, 64, 64)]),
+    (32, B_CONV3, [(128, 128, 128), (128, 384, 128), (128, 256, 128)]),       # the headline batch: K = 131 072 pixels, 3-12 K ranges per layer
+    (16, B_CONV3, [(128, 256, 256), (128, 512, 256), (128, 128, 256)]),
+    # the convolution behind Upsample2D: X is the half-resolution source, the doubling and the tap shift live in the transposed reads' row addresses
+    (32, B_CONV3_UP, [(16, 256, 256), (3, 64, 72)]),
+    (16, B_CONV3_UP, [(32, 256, 256), (5, 128, 64)]),
+    (8, B_CONV3_UP, [(64, 256, 256), (7, 64, 128)]),
 ]
 
 
-@pytest.mark.parametrize("S,jobs", WGRAD_PS)
-def test_grouped_weight_gradient_on_presplit_operands(S, jobs):
+@pytest.mark.parametrize("S,mode,jobs", WGRAD_PS)
+def test_grouped_weight_gradient_on_presplit_operands(S, mode, jobs):
     """wgrad_ps_group_kernel: both operands fetched by LDS-DMA, fragments through ds_read_b64_tr_b16 -- against torch's fp32 weight gradient and
     BIT-IDENTICAL to the converting kernel (wgrad_k32_group_kernel) on the same grouped plan."""
     d_ps, d_f, keep, refs, out_ps, out_f = [], [], [], [], [], []
+    up = 2 if mode == B_CONV3_UP else 0
+    Sx = S // 2 if up else S
     for k, (B, Cin, Cout) in enumerate(jobs):
-        x = torch.randn(B, Cin, S, S, generator=g(20 * k))
+        x = torch.randn(B, Cin, Sx, Sx, generator=g(20 * k))
         w = (torch.randn(Cout, Cin, 3, 3, generator=g(20 * k + 1)) / math.sqrt(Cin * 9)).requires_grad_()
-        y = F.conv2d(x, w, None, padding=1)
+        y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x, w, None, padding=1)
         dy = torch.randn(y.shape, generator=g(20 * k + 2))
         y.backward(dy)
-        xbuf = torch.zeros(B, Cin + 8, S, S, device=DEV)             # operands that are channel slices of wider buffers (skip concatenation)
+        xbuf = torch.zeros(B, Cin + 8, Sx, Sx, device=DEV)           # operands that are channel slices of wider buffers (skip concatenation)
         xbuf[:, 8:] = x.to(DEV)
         dyd = dy.to(DEV)
-        xp_buf = torch.zeros(B, Cin + 8, S, S, device=DEV)
+        xp_buf = torch.zeros(B, Cin + 8, Sx, Sx, device=DEV)
         xp = ops.presplit_pack(xbuf[:, 8:], out=ops.PreSplit(xp_buf[:, 8:]))
         dyp = ops.presplit_pack(dyd)
         dw_p = torch.full((Cout, Cin * 9), 0.25, device=DEV)
         dw_f = torch.full((Cout, Cin * 9), 0.25, device=DEV)
-        dp = ops.wgrad_desc(dyp, xp, dw_p, B_CONV3, None, accumulate=True, math_mode=1)
-        df = ops.wgrad_desc(dyd, xbuf[:, 8:], dw_f, B_CONV3, None, accumulate=True, math_mode=1)
-        assert ops.wgrad_group_class(dp) == 3000 + 4 * S and ops.wgrad_group_class(df) == 4 * S, (ops.wgrad_group_class(dp), ops.wgrad_group_class(df))
+        dp = ops.wgrad_desc(dyp, xp, dw_p, mode, None, accumulate=True, math_mode=1)
+        df = ops.wgrad_desc(dyd, xbuf[:, 8:], dw_f, mode, None, accumulate=True, math_mode=1)
+        assert ops.wgrad_group_class(dp) == 3000 + 4 * S + up and ops.wgrad_group_class(df) == 4 * S + up, (ops.wgrad_group_class(dp), ops.wgrad_group_class(df))
         d_ps.append(dp)
         d_f.append(df)
         keep.append((xbuf, dyd, xp_buf, xp, dyp))
@@ -227,7 +233,7 @@ def test_grouped_weight_gradient_on_presplit_operands(S, jobs):
     torch.cuda.synchronize()
     for k, (dp, df, ref) in enumerate(zip(out_ps, out_f, refs)):
         e = rel_err(dp - 0.25, ref)
-        print(f"[parity] pre-split grouped wgrad job {k} {jobs[k]}@{S}: rel_err={e:.3e} vs torch; max |ps - converting| = {float((dp - df).abs().max()):.3e}")
+        print(f"[parity] pre-split grouped wgrad (mode {mode}) job {k} {jobs[k]}@{S}: rel_err={e:.3e} vs torch; max |ps - converting| = {float((dp - df).abs().max()):.3e}")
         assert e <= 1e-4, (k, e)
         assert torch.equal(dp, df), (k, float((dp - df).abs().max()))
     snap = [o.clone() for o in out_ps]
@@ -270,7 +276,8 @@ def test_network_step_with_presplit_operands_matches_the_converting_path():
     used = [n for n in n1 if "_ps_" in n or "presplit" in n or n.endswith("true>")]
     print(f"[parity] pre-split vs converting step at B=128: loss {abs(l1 - l0) / abs(l0):.2e}, gradient (L2) {float((g1 - g0).norm() / g0.norm()):.2e}, "
           f"worst element {float((g1 - g0).abs().max() / g0.abs().max()):.2e}; pre-split kernels: {sorted(used)}")
-    assert any("wgrad_ps_group_kernel<32>" in n for n in n1) and any("wgrad_ps_group_kernel<16>" in n for n in n1)
+    assert any("wgrad_ps_group_kernel<32, 0>" in n for n in n1) and any("wgrad_ps_group_kernel<16, 0>" in n for n in n1)
+    assert any("wgrad_ps_group_kernel<32, 2>" in n for n in n1)                 # the Upsample2D convolution (operands packed on the side stream)
     assert any("gn_fwd_ps_kernel" in n for n in n1) and any("gn_bwd_ps_kernel" in n for n in n1)
     assert any(n.startswith("conv3_k32p_kernel<32, 0") and n.endswith("true>") for n in n1) and any(n.startswith("conv3_k32p_kernel<16, 1") and n.endswith("true>") for n in n1)
     assert not any("_ps_" in n for n in n0)

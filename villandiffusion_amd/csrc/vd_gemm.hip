@@ -20,7 +20,7 @@
 bool vd_conv3_k32p_eligible(const vd_gemm_desc& d);
 int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st);
 // vd_presplit.hip: the grouped 3x3 weight gradient with both operands pre-split (LDS-DMA + transposed reads)
-int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int blocks, hipStream_t st);
+int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int up, int blocks, hipStream_t st);
 // vd_gemm_k32p.hip: the persistent 16x16x32 split-precision 1x1 convolution / plain product
 bool vd_gemm1x1_k32p_pick(const vd_gemm_desc& d);
 int vd_launch_gemm1x1_k32p(const vd_gemm_desc& d, hipStream_t st);
@@ -2469,15 +2469,17 @@ extern "C" int vd_conv_wgrad(const vd_wgrad_desc* desc, void* stream) {
 // ---- grouped weight gradients -----------------------------------------------------------------------------------------------
 // Class of a split-precision weight gradient = the kernel instantiation it runs on; only jobs of one class share a launch.
 //   3x3: 4 * W + 2 * (CONV3_UP) + (wide image)   (W = 32 / 16 / 8 / 4),   stride-2 3x3: 2000 + W (W = 16 / 8),   1x1: 1000,   0: not groupable
-//   both operands PRE-SPLIT (d.presplit == 3, round 5): 3000 + 4 * W (plain 3x3 at 8x8 / 16x16 / 32x32)
+//   both operands PRE-SPLIT (d.presplit == 3, round 5): 3000 + 4 * W + 2 * (CONV3_UP)   (3x3 at 8x8 / 16x16 / 32x32 outputs)
 static int wgrad_group_class(const vd_wgrad_desc& d) {
     if (d.math != 1 || d.splits != 0 || d.tile != 0) return 0;
     if (d.presplit != 0) {
-        if (d.presplit != 3 || d.T != 9 || d.mode != VD_B_CONV3 || (d.OW != 8 && d.OW != 16 && d.OW != 32) || d.OH != d.OW || d.H != d.OH || d.W != d.OW ||
+        const bool up = d.mode == VD_B_CONV3_UP;
+        if (d.presplit != 3 || d.T != 9 || (d.mode != VD_B_CONV3 && !up) || (d.OW != 8 && d.OW != 16 && d.OW != 32) || d.OH != d.OW ||
+            d.H * (up ? 2 : 1) != d.OH || d.W * (up ? 2 : 1) != d.OW ||
             (d.M & 7) || (d.C & 7) || d.M < 64 || d.C < 64 || (d.dy_bstride & 3) || (d.x_bstride & 3) || ((((uintptr_t)d.dY) | ((uintptr_t)d.X)) & 15) ||
             (int64_t)d.M * d.NP * 4 >= (1ll << 32) || (int64_t)d.C * d.NP * 4 >= (1ll << 32))
             return 0;
-        return 3000 + 4 * d.OW;
+        return 3000 + 4 * d.OW + (up ? 2 : 0);
     }
     if (wgrad1x1_bx3_eligible(d)) return 1000;
     if (d.T != 9 || wgrad_patch_kind(d) != 4) return 0;
@@ -2662,8 +2664,9 @@ extern "C" int vd_conv_wgrad_group_launch(const void* dev_table, int n, int cls,
         case 4 * 8 + 2: VD_WG_K32(8, 2) break;
 #undef VD_WG_K32
         case 4 * 4 + 0: hipLaunchKernelGGL((wgrad_bx3_group_kernel<4, 0>), grid, dim3(NT), 0, st, jobs, n); break;
-        case 3000 + 4 * 32: case 3000 + 4 * 16: case 3000 + 4 * 8:
-            VD_REQUIRE(vd_launch_wgrad_ps_group(dev_table, n, (cls - 3000) / 4, blocks, st) == 0, "vd_conv_wgrad_group_launch: no pre-split kernel for class %d", cls);
+        case 3000 + 4 * 32: case 3000 + 4 * 16: case 3000 + 4 * 8: case 3000 + 4 * 32 + 2: case 3000 + 4 * 16 + 2: case 3000 + 4 * 8 + 2:
+            VD_REQUIRE(vd_launch_wgrad_ps_group(dev_table, n, (cls - 3000) / 4, (cls - 3000) & 2, blocks, st) == 0,
+                       "vd_conv_wgrad_group_launch: no pre-split kernel for class %d", cls);
             break;
         case 2000 + 33: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 4, true>), grid, dim3(NT), 0, st, jobs, n); break;
         case 2000 + 32: hipLaunchKernelGGL((wgrad_bx3_group_kernel<32, 4>), grid, dim3(NT), 0, st, jobs, n); break;

@@ -51,15 +51,20 @@ struct g32p_args {
 
 // F16 (vd_gemm_desc.math = 2, opt-in mixed precision): single f16 planes for both operands (packed weights: vd_conv3_pack_weights_f16_multi), one
 // v_mfma_f32_16x16x32_f16 per product term.  NPART = planes per operand.
-template <bool F16>
+// BM (round 5): 128 output channels x 256 pixels, or 256 x 128 -- the same 32 K accumulators, LDS bytes and MFMAs per stage, but HALF the activation
+// items to load, split and store per MFMA (the weights, which arrive by LDS-DMA and cost no VALU, double instead).  The kernel is bound by the
+// VALU issue of that split, repeated for every m-tile of a pixel tile (6 x for the 256 -> 768 projection); with BM = 256 it is repeated 3 x, and
+// layers of 256 output channels convert every activation exactly once.  Taken when M % 256 == 0.
+template <bool F16, int BM = 128>
 __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a) {
     const vd_gemm_desc& d = a.d;
-    constexpr int BM = 128, NPIX = 256, NTH = 512;
+    constexpr int NPIX = 128 * 256 / BM, NTH = 512;
+    constexpr int WN = NPIX / 64;                                 // waves along the pixels (4 | 2); 8 / WN along the channels
     constexpr int NPART = F16 ? 1 : 2;
-    constexpr int A_UNITS = 2 * NPART * 2 * BM;                   // 1024 units = 16 KB per stage: [c2][part][q][m] (f16: 8 KB)
-    constexpr int A_IT = A_UNITS / NTH;                           // 2 (1)
-    constexpr int P_UNITS = 4 * NPART * NPIX;                     // 2048 units = 32 KB per stage: [c2][part][q][pixel] (f16: 16 KB)
-    constexpr int P_IT = 2;                                       // (k-octet, pixel) items per thread: 4 octets x 256 pixels / 512 threads
+    constexpr int A_UNITS = 2 * NPART * 2 * BM;                   // 1024 units = 16 KB per stage: [c2][part][q][m] (f16: 8 KB; BM = 256: 32 KB)
+    constexpr int A_IT = A_UNITS / NTH;                           // 2 (1; BM = 256: 4)
+    constexpr int P_UNITS = 4 * NPART * NPIX;                     // 2048 units = 32 KB per stage: [c2][part][q][pixel] (f16: 16 KB; BM = 256: 16 KB)
+    constexpr int P_IT = 4 * NPIX / NTH;                          // (k-octet, pixel) items per thread: 4 octets x NPIX pixels / 512 threads = 2 | 1
     __shared__ u32x4 lds[2 * A_UNITS + 2 * P_UNITS];              // ONE LDS object (see vd_conv_k32p.hip)
     u32x4* const As = lds;
     u32x4* const Ps = lds + 2 * A_UNITS;
@@ -81,9 +86,9 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     const unsigned ldb4 = 4u * (unsigned)d.ldb;
 
     // weights: unit u = tid + i * 512 of a stage: run = u >> 7 = c2 * 4 + part * 2 + q, m = u & 127; global unit (cp * 8 + run) * Mpad + m0 + m
-    unsigned aoff[2];             // (A_IT <= 2; a constant size: see vd_conv_k32p.hip)
+    unsigned aoff[4];             // (A_IT <= 4; a constant size: see vd_conv_k32p.hip)
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) aoff[i] = 16u * (unsigned)(((tid + i * NTH) >> 7) * Mpad + (tid & 127));
+    for (int i = 0; i < A_IT; ++i) aoff[i] = 16u * (unsigned)(((tid + i * NTH) / BM) * Mpad + ((tid + i * NTH) % BM));
     auto dma_a = [&](int m0_, int cp, int buf) {
         const unsigned so = 16u * (unsigned)(cp * 4 * NPART * Mpad + m0_);                    // wave-uniform
 #pragma unroll
@@ -126,11 +131,19 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     };
     auto wait_p = [&](float (&r)[P_IT][8], auto LEFT) {          // all but the LEFT youngest vector-memory operations have completed
         constexpr int left = decltype(LEFT)::value;
-        asm volatile("s_waitcnt vmcnt(%16)"
-                     : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7]),
-                       "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]), "+v"(r[1][3]), "+v"(r[1][4]), "+v"(r[1][5]), "+v"(r[1][6]), "+v"(r[1][7])
-                     : "n"(left)
-                     : "memory");
+        if constexpr (P_IT == 2) {
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7]),
+                           "+v"(r[P_IT - 1][0]), "+v"(r[P_IT - 1][1]), "+v"(r[P_IT - 1][2]), "+v"(r[P_IT - 1][3]), "+v"(r[P_IT - 1][4]), "+v"(r[P_IT - 1][5]),
+                           "+v"(r[P_IT - 1][6]), "+v"(r[P_IT - 1][7])
+                         : "n"(left)
+                         : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7])
+                         : "n"(left)
+                         : "memory");
+        }
     };
     auto write_p = [&](int buf, const float (&r)[P_IT][8]) {
 #pragma unroll
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     };
 
     f32x4 acc[4][4];                                              // [pixel tile ni][channel tile mi]
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int c2 = g >> 1, q = g & 1;
     const u32x4* __restrict__ a_base = As + (c2 * 2 * NPART + q) * BM + wm * 64 + l15;
     const u32x4* __restrict__ p_base = Ps + (c2 * 2 * NPART + q) * NPIX + wn * 64 + l15;
@@ -333,7 +346,7 @@ bool vd_gemm1x1_k32p_pick(const vd_gemm_desc& d) {
     if (d.residual && ((d.res_bstride & 3) || (((uintptr_t)d.residual) & 15))) return false;
     const int64_t nb = d.N / d.NP;
     if (nb * d.b_bstride * 4 >= (1ll << 32) || (int64_t)d.K * d.ldb * 4 >= (1ll << 32)) return false;      // 32-bit buffer offsets
-    const int nt = vd_cdiv(d.M, 128) * (d.N / 256);
+    const int nt = vd_cdiv(d.M, 128) * (d.N / 256);               // (the 256 x 128 tiles of M % 256 == 0 problems: the same count)
     const int rounds = vd_cdiv(nt, 256);
     static const int min_tiles = env_int("VD_G32P_MIN_TILES", 192);
     if (nt < min_tiles) return false;
@@ -350,12 +363,15 @@ int vd_launch_gemm1x1_k32p(const vd_gemm_desc& d, hipStream_t st) {
         n_cu &= ~7;
         if (n_cu < 8) n_cu = 8;
     }
+    static const int bm256 = env_int("VD_G32P_BM256", 1);         // A/B switch: 0 = the 128 x 256 tile everywhere (round 4)
+    const bool big_m = bm256 && d.math != 2 && d.M % 256 == 0 && d.N % 128 == 0;
     g32p_args a;
     a.d = d;
-    a.tiles_m = vd_cdiv(d.M, 128);
-    a.n_tiles = a.tiles_m * (d.N / 256);
+    a.tiles_m = vd_cdiv(d.M, big_m ? 256 : 128);
+    a.n_tiles = a.tiles_m * (d.N / (big_m ? 128 : 256));
     const int grid = a.n_tiles < n_cu ? ((a.n_tiles + 7) & ~7) : n_cu;
-    if (d.math == 2) hipLaunchKernelGGL(gemm1x1_k32p_kernel<true>, dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(gemm1x1_k32p_kernel<false>, dim3(grid), dim3(512), 0, st, a);
+    if (d.math == 2) hipLaunchKernelGGL((gemm1x1_k32p_kernel<true, 128>), dim3(grid), dim3(512), 0, st, a);
+    else if (big_m) hipLaunchKernelGGL((gemm1x1_k32p_kernel<false, 256>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm1x1_k32p_kernel<false, 128>), dim3(grid), dim3(512), 0, st, a);
     return 0;
 }

@@ -347,11 +347,15 @@ __global__ __launch_bounds__(NTH) void gn_bwd_ps_kernel(const float* __restrict_
 //     rows above / below the image are out-of-range DMA sources (zeros).  All read addresses are loop-invariant VGPRs + immediates (the K loop is
 //     unrolled over the three stage buffers).
 // No VALU beside the MFMAs except the per-step DMA offsets; 2 workgroups per CU (76 KB of LDS each).
+// MODE 2 (the convolution behind Upsample2D: X is the HALF-resolution source of the nearest-2x upsample): a K-step's 32 upsampled pixels read 16
+// source pixels per octet (image row (y0 + rr + r - 1) >> 1, pixel (x + s - 1) >> 1), so the X stage is [8 octets][2 parts][16 slots] = 4 KB, ONE
+// DMA instruction per wave, and the tap shift / the doubling live in the row addresses of the transposed reads.
 constexpr int PS_NST = 3;
-constexpr int PS_A_U = 16 * 64, PS_B_U = 8 * 64;                // 16-byte units per stage: dY [16 octets][2 parts][32 slots], X [8 octets][2][32]
-constexpr int PS_ST_U = PS_A_U + PS_B_U;                        // 1536 units = 24 KB
+constexpr int PS_A_U = 16 * 64;                                 // 16-byte units per stage: dY [16 octets][2 parts][32 slots]
+constexpr int ps_b_units(int mode) { return mode == 2 ? 8 * 32 : 8 * 64; }      // X [8 octets][2 parts][32 | 16 slots]
+constexpr int ps_stage_units(int mode) { return PS_A_U + ps_b_units(mode); }     // 1536 units = 24 KB (MODE 2: 1280 = 20 KB)
 constexpr int PS_Z_U = 256;                                     // zero region: 4 KB (every (octet pair, part, channel tile) immediate of a padding lane lands in it)
-constexpr int PS_LDS_U = PS_NST * PS_ST_U + PS_Z_U;
+constexpr int ps_lds_units(int mode) { return PS_NST * ps_stage_units(mode) + PS_Z_U; }
 
 // The transposed reads are INLINE ASM with hand-counted lgkmcnt waits: hipcc's waitcnt pass treats an LDS read that may alias a pending LDS-DMA as
 // dependent on it and puts s_waitcnt vmcnt(0) in front of the first ds_read of a step -- i.e. it waits for the DMAs issued a moment ago for the step
@@ -369,9 +373,14 @@ __device__ __forceinline__ bf16x8 cat8(const s16x4& lo4, const s16x4& hi4) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int W>   // W: 8 | 16 | 32 (output width = pixels per image row); plain 3x3 convolution (VD_B_CONV3)
+template <int W, int MODE>   // W: 8 | 16 | 32 (output width = pixels per image row); MODE 0: VD_B_CONV3, 2: VD_B_CONV3_UP
 __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps_per_split, int gx, int gy, int lin, u32x4* lds) {
     constexpr int ROWS = 32 / W, OPR = W / 8, CT = 64;
+    constexpr int PS_ST_U = ps_stage_units(MODE);
+    constexpr int NDMA = MODE == 2 ? 5 : 6;          // LDS-DMA instructions per wave and stage (the counted vmcnt waits)
+    constexpr int SLOTS = MODE == 2 ? 16 : 32;       // X slots per (octet, part) plane
+    constexpr int B_CT = 2 * 2 * SLOTS * 16;         // bytes between the X fragments of channel tiles ct = 0 / 1 (two octets)
+    constexpr int B_PART = SLOTS * 16;               // bytes between the hi and lo planes of an X octet
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_m = (d.M + 127) / 128;
@@ -392,7 +401,7 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
     const int ks_total = d.nb * steps_per_img;
     const int ks_begin = by * ksteps_per_split;
     const int ks_end = min(ks_total, ks_begin + ksteps_per_split);
-    const int HWs = d.H * d.W;                       // == NP (plain convolution)
+    const int HWs = d.H * d.W;                       // source plane of X (MODE 2: the half-resolution image)
 
     // zero region (padding lanes of the shifted taps read it); nobody else ever writes it
     for (int i = tid; i < PS_Z_U; i += 256) lds[PS_NST * PS_ST_U + i] = u32x4{0u, 0u, 0u, 0u};
@@ -409,13 +418,22 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
         const bool ok = m0 + oa * 8 < d.M;
         a_voff[i] = ok ? 16u * (unsigned)((((m0 >> 3) + oa) * d.NP + px) * 2 + part) : 0xFFFFFFFFu;
     }
+    if constexpr (MODE == 2) {                        // ONE instruction per wave: octets 2 w, 2 w + 1; lane = [octet][part][16 slots]
+        const int ob = 2 * wave + (lane >> 5), pt = (lane >> 4) & 1;
+        const int ls = (lane & 15) ^ (8 * (ob & 1));         // logical slot rr * (W / 2) + sx held by this lane's LDS slot (XOR: see the reads)
+        b_oct_ok[0] = c0 + ob * 8 < d.C;
+        b_rr[0] = ls / (W / 2);
+        b_fix[0] = 16u * (unsigned)((((c0 >> 3) + ob) * HWs + (ls % (W / 2))) * 2 + pt);
+        b_oct_ok[1] = false, b_rr[1] = 0, b_fix[1] = 0u;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ob = wave + 4 * i;
-        const int px = slot ^ (4 * (ob & 1));
-        b_oct_ok[i] = c0 + ob * 8 < d.C;
-        b_rr[i] = px / W;                            // image row of this lane's pixel inside the K-step
-        b_fix[i] = 16u * (unsigned)((((c0 >> 3) + ob) * HWs + px) * 2 + part);
+        for (int i = 0; i < 2; ++i) {
+            const int ob = wave + 4 * i;
+            const int px = slot ^ (4 * (ob & 1));
+            b_oct_ok[i] = c0 + ob * 8 < d.C;
+            b_rr[i] = px / W;                            // image row of this lane's pixel inside the K-step
+            b_fix[i] = 16u * (unsigned)((((c0 >> 3) + ob) * HWs + px) * 2 + part);
+        }
     }
     auto dma_stage = [&](int ks, int sb) {
         const int b = ks / steps_per_img;
@@ -429,12 +447,20 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, dst, 16, a_voff[i], a_so, 0, 0);
         }
         const int yb = y0 + r - 1;                                               // first input row of the step (may be -1)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool ok = b_oct_ok[i] && (unsigned)(yb + b_rr[i]) < (unsigned)d.H;
-            const unsigned v = ok ? b_fix[i] + (unsigned)(32 * yb * W) : 0xFFFFFFFFu;     // a row outside the image is out of range: the DMA writes zeros
-            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(lds + sb * PS_ST_U + PS_A_U + (wave + 4 * i) * 64);
+        if constexpr (MODE == 2) {
+            const int uy = yb + b_rr[0];                                         // row of the (virtual) upsampled image -> source row uy >> 1
+            const bool ok = b_oct_ok[0] && (unsigned)uy < (unsigned)(2 * d.H);
+            const unsigned v = ok ? b_fix[0] + (unsigned)(32 * (uy >> 1) * d.W) : 0xFFFFFFFFu;
+            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(lds + sb * PS_ST_U + PS_A_U + wave * 64);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, v, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = b_oct_ok[i] && (unsigned)(yb + b_rr[i]) < (unsigned)d.H;
+                const unsigned v = ok ? b_fix[i] + (unsigned)(32 * yb * W) : 0xFFFFFFFFu;     // a row outside the image is out of range: the DMA writes zeros
+                __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(lds + sb * PS_ST_U + PS_A_U + (wave + 4 * i) * 64);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, v, 0, 0, 0);
+            }
         }
     };
 
@@ -453,9 +479,16 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
             const int pxs = px + s - 1;
             const bool pad = (s == 0 && (g % OPR) == 0 && h == 0 && q == 0) || (s == 2 && (g % OPR) == OPR - 1 && h == 1 && q == 3);
             const int octb = wc * 4 + (p >> 1);
-            const unsigned in_img = 16u * (unsigned)(PS_A_U + octb * 64 + ((pxs & 31) ^ (4 * (p >> 1)))) + 8u * (unsigned)(p & 1);
+            unsigned in_img;
+            if constexpr (MODE == 2) {                // upsampled pixel (row rr, column ux) reads source slot rr * (W / 2) + (ux >> 1); two octets 8 slots apart
+                const int rr = px / W, ux = (px % W) + s - 1;
+                const int ls = rr * (W / 2) + ((ux < 0 ? 0 : ux) >> 1);
+                in_img = 16u * (unsigned)(PS_A_U + octb * 32 + ((ls & 15) ^ (8 * (p >> 1)))) + 8u * (unsigned)(p & 1);
+            } else {
+                in_img = 16u * (unsigned)(PS_A_U + octb * 64 + ((pxs & 31) ^ (4 * (p >> 1)))) + 8u * (unsigned)(p & 1);
+            }
             // padding lanes: the zero region minus the stage offset the immediates add (the region is addressed from stage 0 for every stage)
-            const unsigned zero = 16u * (unsigned)(PS_NST * PS_ST_U) + 16u * 64u * (unsigned)(p >> 1) + 8u * (unsigned)(p & 1);
+            const unsigned zero = 16u * (unsigned)(PS_NST * PS_ST_U) + 16u * (unsigned)(2 * SLOTS) * (unsigned)(p >> 1) + 8u * (unsigned)(p & 1);
             b_addr[s][h] = lds0 + (pad ? zero : in_img);
         }
     }
@@ -499,10 +532,10 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
             const int sx = o == 0 ? 1 : (o == 1 ? 0 : 2);
             if (ct == 0) {
                 tr_read<0>(dst[0][0], b_st[SB][sx][0]); tr_read<0>(dst[0][1], b_st[SB][sx][1]);
-                tr_read<512>(dst[1][0], b_st[SB][sx][0]); tr_read<512>(dst[1][1], b_st[SB][sx][1]);
+                tr_read<B_PART>(dst[1][0], b_st[SB][sx][0]); tr_read<B_PART>(dst[1][1], b_st[SB][sx][1]);
             } else {
-                tr_read<2048>(dst[0][0], b_st[SB][sx][0]); tr_read<2048>(dst[0][1], b_st[SB][sx][1]);
-                tr_read<2048 + 512>(dst[1][0], b_st[SB][sx][0]); tr_read<2048 + 512>(dst[1][1], b_st[SB][sx][1]);
+                tr_read<B_CT>(dst[0][0], b_st[SB][sx][0]); tr_read<B_CT>(dst[0][1], b_st[SB][sx][1]);
+                tr_read<B_CT + B_PART>(dst[1][0], b_st[SB][sx][0]); tr_read<B_CT + B_PART>(dst[1][1], b_st[SB][sx][1]);
             }
         };
         b_reads(0, br[0]);
@@ -544,7 +577,7 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
         __builtin_amdgcn_sched_barrier(0);
         compute(SBc);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
@@ -553,7 +586,7 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
         const int ks_last = ks_end - 1;
         dma_stage(ks_begin, 0);
         dma_stage(min(ks_begin + 1, ks_last), 1);
-        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // stage 0 (and the zero region's stores) done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");      // stage 0 (and the zero region's stores) done
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         int ks = ks_begin;
@@ -592,14 +625,14 @@ __device__ __forceinline__ void wgrad_ps_body(const vd_wgrad_desc& d, int ksteps
     }
 }
 
-template <int W>
+template <int W, int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_ps_group_kernel(const vd_wgrad_job* __restrict__ jobs, int n_jobs) {
-    __shared__ u32x4 lds[PS_LDS_U];                 // ONE LDS object (a second one beside an LDS-DMA target makes hipcc wait vmcnt(0) before every ds_read)
+    __shared__ u32x4 lds[ps_lds_units(MODE)];       // ONE LDS object (a second one beside an LDS-DMA target makes hipcc wait vmcnt(0) before every ds_read)
     const vd_wgrad_job* __restrict__ jb = jobs + wgrad_find_job(jobs, n_jobs, blockIdx.x, false);
     const int lin = blockIdx.x - jb->first_block;
     if (lin >= jb->gx * jb->gy) return;            // padding blocks between jobs
     const vd_wgrad_desc d = jb->d;
-    wgrad_ps_body<W>(d, jb->ks_per, jb->gx, jb->gy, lin, lds);
+    wgrad_ps_body<W, MODE>(d, jb->ks_per, jb->gx, jb->gy, lin, lds);
 }
 
 }  // namespace
@@ -628,7 +661,7 @@ extern "C" int vd_groupnorm_fwd_presplit_ok(int C, int HW, int G) {
     if (C <= 0 || G <= 0 || C % G || C % 8) return 0;
     const int cpg = C / G;
     if (HW == 1024) return (cpg == 4 || cpg == 8 || cpg == 12) ? 1 : 0;
-    if (HW == 256) return (cpg == 8 || cpg == 12 || cpg == 16) ? 1 : 0;
+    if (HW == 256) return (cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) ? 1 : 0;
     return 0;
 }
 
@@ -648,7 +681,8 @@ extern "C" int vd_groupnorm_fwd_presplit(const float* x, const float* gamma, con
         else if (cpg == 8) VD_GN_PS(8, 1, 4, 256);
         else VD_GN_PS(12, 3, 2, 512);
     } else {
-        if (cpg == 8) VD_GN_PS(8, 1, 1, 256);
+        if (cpg == 4) VD_GN_PS(4, 1, 1, 256);
+        else if (cpg == 8) VD_GN_PS(8, 1, 1, 256);
         else if (cpg == 12) VD_GN_PS(12, 3, 1, 256);
         else VD_GN_PS(16, 2, 1, 256);
     }
@@ -679,7 +713,8 @@ extern "C" int vd_groupnorm_bwd_presplit(const float* dy, const float* x, const 
         else if (cpg == 8) VD_GNB_PS(8, 1, 4, 256);
         else VD_GNB_PS(12, 3, 2, 512);
     } else {
-        if (cpg == 8) VD_GNB_PS(8, 1, 1, 256);
+        if (cpg == 4) VD_GNB_PS(4, 1, 1, 256);
+        else if (cpg == 8) VD_GNB_PS(8, 1, 1, 256);
         else if (cpg == 12) VD_GNB_PS(12, 3, 1, 256);
         else VD_GNB_PS(16, 2, 1, 256);
     }
@@ -688,13 +723,17 @@ extern "C" int vd_groupnorm_bwd_presplit(const float* dy, const float* x, const 
     return 0;
 }
 
-// vd_gemm.hip's grouped launch (class 3000 + 4 W): both operands pre-split
-int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int blocks, hipStream_t st) {
+// vd_gemm.hip's grouped launch (class 3000 + 4 W + 2 * upsample-fused): both operands pre-split
+int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int up, int blocks, hipStream_t st) {
     const vd_wgrad_job* jb = reinterpret_cast<const vd_wgrad_job*>(jobs);
+#define VD_WG_PS(WW)                                                                                                \
+    case WW:                                                                                                        \
+        if (up) hipLaunchKernelGGL((wgrad_ps_group_kernel<WW, 2>), dim3(blocks), dim3(256), 0, st, jb, n);          \
+        else hipLaunchKernelGGL((wgrad_ps_group_kernel<WW, 0>), dim3(blocks), dim3(256), 0, st, jb, n);             \
+        return 0;
     switch (W) {
-        case 32: hipLaunchKernelGGL((wgrad_ps_group_kernel<32>), dim3(blocks), dim3(256), 0, st, jb, n); return 0;
-        case 16: hipLaunchKernelGGL((wgrad_ps_group_kernel<16>), dim3(blocks), dim3(256), 0, st, jb, n); return 0;
-        case 8: hipLaunchKernelGGL((wgrad_ps_group_kernel<8>), dim3(blocks), dim3(256), 0, st, jb, n); return 0;
+        VD_WG_PS(32) VD_WG_PS(16) VD_WG_PS(8)
         default: return -1;
     }
+#undef VD_WG_PS
 }

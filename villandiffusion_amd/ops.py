@@ -162,14 +162,15 @@ def conv_presplit_ok(Bn: int, Cin: int, Cout: int, OH: int, OW: int, mode: int) 
     return ok
 
 
-def wgrad_presplit_ok(Bn: int, Cin: int, Cout: int, S: int) -> bool:
-    """Is there a grouped pre-split weight-gradient kernel for a plain 3x3 convolution Cin -> Cout on S x S images?"""
+def wgrad_presplit_ok(Bn: int, Cin: int, Cout: int, S: int, mode: int = B_CONV3) -> bool:
+    """Is there a grouped pre-split weight-gradient kernel for a 3x3 convolution Cin -> Cout with S x S OUTPUTS (mode B_CONV3 or B_CONV3_UP)?"""
     d = WgradDesc()
     d.dY = d.X = d.dW = 64
     d.M, d.C, d.T, d.nb, d.NP = Cout, Cin, 9, Bn, S * S
-    d.H = d.W = d.OH = d.OW = S
-    d.mode, d.accumulate, d.math, d.presplit = B_CONV3, 1, 1, 3
-    d.dy_bstride, d.x_bstride = Cout * S * S, Cin * S * S
+    d.OH = d.OW = S
+    d.H = d.W = S // 2 if mode == B_CONV3_UP else S
+    d.mode, d.accumulate, d.math, d.presplit = mode, 1, 1, 3
+    d.dy_bstride, d.x_bstride = Cout * S * S, Cin * d.H * d.W
     return int(_lib().vd_conv_wgrad_group_class(C.byref(d))) >= 3000
 
 
@@ -694,7 +695,7 @@ def conv_wgrad_group(descs: Sequence[WgradDesc], device):
     nbytes = sum(4.0 * (d.nb * d.M * d.NP + d.nb * d.C * d.H * d.W + d.M * d.C * d.T) for d in descs)
     var = lib.vd_conv_wgrad_group_variant(ent["cls"])
     if ent["cls"] >= 3000:                                       # both operands pre-split: LDS-DMA + transposed reads (vd_presplit.hip)
-        name = f"wgrad_ps_group_kernel<{(ent['cls'] - 3000) // 4}>(+group_reduce)"
+        name = f"wgrad_ps_group_kernel<{(ent['cls'] - 3000) // 4}, {(ent['cls'] - 3000) & 2}>(+group_reduce)"
     elif ent["cls"] > 2000:                                      # stride-2 3x3 classes (2000 + output width; 2033: 32-pixel segments of wide outputs)
         name = "wgrad_bx3_group_kernel<32, 4, true>(+group_reduce)" if ent["cls"] == 2033 else f"wgrad_bx3_group_kernel<{ent['cls'] - 2000}, 4, false>(+group_reduce)"
     elif ent["cls"] == 1000:                                     # symbol names as rocprofv3 prints them

@@ -195,6 +195,12 @@ class _Conv:
             net.wgrad(dy_ps, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=1)
             if dout_ps is not None:
                 dout = dout_ps                                # the input gradient copies (hi, lo) units too
+        elif (self.mode == B_CONV3_UP and getattr(net, "presplit", False) and net.conv_math == "bf16x3" and net.group_wgrad
+              and dout.shape[2] == dout.shape[3] and ops.wgrad_presplit_ok(dout.shape[0], self.cin, self.cout, dout.shape[3], B_CONV3_UP)):
+            # Upsample2D's convolution: its input is a block output (f32), so the image is packed on the weight-gradient stream -- two small passes
+            # off the critical path for the LDS-DMA kernel (the 256 -> 256 layer at 32x32 outputs is 0.42 ms per step on the converting kernel)
+            dy_ps = dout_ps if dout_ps is not None else net.pack_later(dout)
+            net.wgrad(dy_ps, net.pack_later(x), net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=1)
         else:
             assert dout is not None
             bx3 = _split(net) and ops.wgrad_bx3_eligible(self.cout, self.cin, dout.shape[2], dout.shape[3],
@@ -1376,9 +1382,15 @@ class UNet2DModel(nn.Module):
         def wants_ps(norm, shape):
             """Is the next record on the tape (the consumer of the gradient about to be produced) a pre-split ResnetBlock, and can `norm`'s backward
             kernel write its dx as a pre-split image too?  Then the gradient is handed on in both forms (g, g_ps)."""
-            if not sv or sv[-1][0] != "res" or not isinstance(sv[-1][2][5], ops.PreSplit):
+            if not sv or not norm.ps_ok(shape[2] * shape[3]):
                 return None
-            return ops.presplit_empty(shape, dev) if norm.ps_ok(shape[2] * shape[3]) else None
+            nxt = sv[-1]
+            if nxt[0] == "res" and isinstance(nxt[2][5], ops.PreSplit):
+                return ops.presplit_empty(shape, dev)
+            if (nxt[0] == "us" and self.presplit and self.conv_math == "bf16x3" and self.group_wgrad
+                    and ops.wgrad_presplit_ok(shape[0], nxt[1].cin, nxt[1].cout, shape[3], B_CONV3_UP)):
+                return ops.presplit_empty(shape, dev)            # (the upsampler's weight gradient reads it; its input gradient reads f32)
+            return None
 
         # g_ps: g as a pre-split image when its producer wrote one (consumed by a pre-split block's conv2 gradients), else None
         g_ps = wants_ps(self.norm_out, final.shape)
@@ -1418,7 +1430,7 @@ class UNet2DModel(nn.Module):
             elif kind == "us":
                 layer, x = rec[1], rec[2]
                 dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
-                layer.bwd(g, x, dx, bias_ws=g_rs)
+                layer.bwd(g, x, dx, bias_ws=g_rs, dout_ps=g_ps)
                 g, g_rs, g_ps = dx, None, None
             elif kind == "ds":
                 layer, x = rec[1], rec[2]
