@@ -497,7 +497,7 @@ class _Resnet:
             ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
                      ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
                      a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
-            self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc, extra2=extra2, rowsum=dx_rs)
+            self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
         else:
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dout, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
         return dx
