@@ -557,7 +557,7 @@ static int launch_attn_core(const attn_core_args& a, int nbh, hipStream_t st) {
     const int d = a.d;
     // d = 256 k, backward: eight channel tiles of phase-2 accumulators beside the 128 + 128 score / staging registers spill 101 VGPRs (396 bytes of
     // scratch per lane); two passes of four tiles (VD_ATTN_BWD_DT8=1: the one-pass form) re-stage k once more and spill 4
-    static const int bwd_dt8 = getenv("VD_ATTN_BWD_DT8") ? atoi(getenv("VD_ATTN_BWD_DT8")) : 0;
+    constexpr int bwd_dt8 = 0;            // (the one-pass form spilled 101 VGPRs: profiles/HISTORY.md)
     if (d % 256 == 0 && BWD && !bwd_dt8) hipLaunchKernelGGL((attn_core_kernel<4, BWD>), grid, dim3(256), 0, st, a);
     else if (d % 256 == 0) hipLaunchKernelGGL((attn_core_kernel<8, BWD>), grid, dim3(256), 0, st, a);
     else if (d == 128) hipLaunchKernelGGL((attn_core_kernel<4, BWD>), grid, dim3(256), 0, st, a);
@@ -593,7 +593,7 @@ extern "C" int vd_softmax_col_bwd(const float* P, float* dP, int nb, int N, floa
 extern "C" int vd_attn_small_fwd(const float* qkv, float* out, float* P, int B, int C, int N, float scale, int64_t qkv_bstride,
                                  int64_t out_bstride, void* stream) {
     VD_REQUIRE(qkv && out && B > 0 && C > 0 && N > 0 && N <= 64, "vd_attn_small_fwd: needs N <= 64 (N=%d)", N);
-    static const int nostage = getenv("VD_ATTN_SMALL_NOSTAGE") ? atoi(getenv("VD_ATTN_SMALL_NOSTAGE")) : 0;
+    constexpr int nostage = 0;
     if (!nostage && 3 * C * N <= 12288)
         hipLaunchKernelGGL(attn_small_fwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, out, P, C, N, scale, qkv_bstride, out_bstride);
     else
@@ -605,7 +605,7 @@ extern "C" int vd_attn_small_fwd(const float* qkv, float* out, float* P, int B, 
 extern "C" int vd_attn_small_bwd(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int C, int N,
                                  float scale, int64_t qkv_bstride, int64_t dout_bstride, int64_t dqkv_bstride, void* stream) {
     VD_REQUIRE(qkv && P && dout && dqkv && B > 0 && C > 0 && N > 0 && N <= 64, "vd_attn_small_bwd: needs N <= 64 (N=%d)", N);
-    static const int nostage = getenv("VD_ATTN_SMALL_NOSTAGE") ? atoi(getenv("VD_ATTN_SMALL_NOSTAGE")) : 0;
+    constexpr int nostage = 0;
     if (!nostage && 4 * C * N <= 16384)
         hipLaunchKernelGGL(attn_small_bwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, P, dout, dqkv, C, N, scale, qkv_bstride,
                            dout_bstride, dqkv_bstride);

@@ -668,7 +668,11 @@ int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st) {
         n_cu &= ~7;                                               // whole XCD octets
         if (n_cu < 8) n_cu = 8;
     }
-    static const int flags = env_int("VD_K32P_FLAGS", 0);
+#ifdef VD_K32P_VARIANTS
+    static const int flags = env_int("VD_K32P_FLAGS", 0);       // (bit 0: no stagger of the wave halves -- register-staged variants only)
+#else
+    constexpr int flags = 0;
+#endif
 #ifdef VD_K32P_VARIANTS
     static const int dma = env_int("VD_K32P_DMA", 1);
     static const int pipe = env_int("VD_K32P_PIPE", 1);

@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue4_kernel(const vd_gemm_des
 static void launch_splitk_epilogue(const vd_gemm_desc& d, int splits, hipStream_t st) {
     const int64_t total = (int64_t)d.M * d.N;
     const bool v4 = (d.N & 3) == 0 && (d.NP & 3) == 0 && (d.ldd & 3) == 0 && (d.d_bstride & 3) == 0 && (d.res_bstride & 3) == 0 &&
-                    (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15) == 0 && getenv("VD_SPLITK_EPI_SCALAR") == nullptr;
+                    (((uintptr_t)d.D | (uintptr_t)d.residual | (uintptr_t)d.ws) & 15) == 0;
     if (v4) {
         const int64_t t4 = total >> 2;
         const int g2 = (int)((t4 + 255) / 256 < 2048 ? (t4 + 255) / 256 : 2048);
@@ -997,7 +997,7 @@ static bool smallm_eligible(const vd_gemm_desc& d) {
 
 static int launch_smallm(const vd_gemm_desc& d, hipStream_t st) {
     const int nb = d.N / d.NP;
-    static const int fewout_off = getenv("VD_FEWOUT_OFF") ? atoi(getenv("VD_FEWOUT_OFF")) : 0;
+    constexpr int fewout_off = 0;
     if (!fewout_off && fewout_eligible(d)) {
         const int64_t quads = (int64_t)nb * d.H * (d.W / 4);
         hipLaunchKernelGGL((conv3_fewout_kernel<4>), dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, d, quads);
@@ -1724,14 +1724,14 @@ static int wgrad_patch_kind(const vd_wgrad_desc& d) {
             return 4;                           // wide images: 32-pixel row segments
         return -1;
     }
-    static const bool k64 = getenv("VD_WGRAD_KPIX64") != nullptr;       // experiment: 64-pixel K-steps for the 16 / 32 px layers
+    constexpr bool k64 = false;          // (64-pixel K-steps for the 16 / 32 px layers: measured neutral, profiles/HISTORY.md)
     if (k64 && (d.OW == 16 || d.OW == 32) && ilog2_exact(d.OH) >= 0 && ((int64_t)d.nb * d.NP) % 64 == 0) return 3;
     if (d.OW == 16 || d.OW == 32) return d.OH % (32 / d.OW) == 0 ? 1 : 0;
     if (ilog2_exact(d.OH) < 0 || ((int64_t)d.nb * d.NP) % 32 != 0) return 0;
     if (d.x_bstride * (int64_t)(8 / d.OH + 2) >= (1ll << 31)) return 0;      // 32-bit in-step offsets
     // 4x4 / 8x8 outputs: K = nb*NP is so short that both kernels are prologue/slab bound; measured on MI355X the generic
     // kernel is as fast or faster there (75 vs 71 TF at 8x8, 48 vs 32 TF at 4x4), so the patch variant is opt-in.
-    static const bool small_patch = getenv("VD_WGRAD_SMALL_PATCH") != nullptr;
+    constexpr bool small_patch = false;
     if (d.OW == 4 || d.OW == 8) return small_patch ? 2 : 0;
     if (d.OW >= 64 && d.OW % 32 == 0 && ilog2_exact(d.OW / 32) >= 0) return 2;
     return 0;
@@ -1744,7 +1744,7 @@ static void wgrad_patch_plan(const vd_wgrad_desc& d, int& splits, int& ks_per) {
     const int base = vd_cdiv(d.M, 128) * vd_cdiv(d.C, 64) * 3;
     splits = d.splits;
     if (splits <= 0) {  // ~3 workgroups per CU, at least 8 K-steps per split
-        static const int target = getenv("VD_WGRAD_TARGET") ? atoi(getenv("VD_WGRAD_TARGET")) : 768;
+        constexpr int target = 768;
         splits = vd_cdiv(target, base);
         const int max_splits = ks_total / 8 > 0 ? ks_total / 8 : 1;
         if (splits > max_splits) splits = max_splits;
@@ -2156,8 +2156,8 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             if (bx3_big_split(d)) return 16;                           // 16: 8x8 layers, 128 x 256 tiles with the channel loop split
             if (k32p_pick(d)) return 18;                               // 18: conv3_k32p_kernel (persistent 16x16x32 kernel, any image of 8 x 32 segments)
             const int big = (big_off || d.b_mode == VD_B_CONV3_S2) ? 0 : bx3_big_tile(d, splits);
-            static const int keep_huge = getenv("VD_BX3_K32_KEEP_HUGE") ? atoi(getenv("VD_BX3_K32_KEEP_HUGE")) : 0;
-            static const int k32_up32 = getenv("VD_BX3_K32_UP32") ? atoi(getenv("VD_BX3_K32_UP32")) : 0;
+            constexpr int keep_huge = 0;
+            constexpr int k32_up32 = 0;
             if (big >= 1 && !(big == 2 && (keep_huge || (d.b_mode == VD_B_CONV3_UP && !k32_up32))) && conv3_k32_eligible(d)) return 17;      // 17: conv3_k32_kernel (16x16x32 MFMA, 128 x 256 tile)
             return big == 2 ? 15 : (big == 1 ? 12 : 8);                // 12 / 15: the 128 x 256 / 128 x 512 tile, eight waves
         }
@@ -2166,7 +2166,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
         // >= 2 tiles per resident workgroup (512 slots): the persistent variant walks them with the next tile's loads in flight
         static const int gbig_off = getenv("VD_GEMM_BX3_BIG_OFF") ? atoi(getenv("VD_GEMM_BX3_BIG_OFF")) : 0;
         if (!gbig_off && gemm_bx3_big_tile(d)) return 13;       // 13: the 128 x 256 tile, eight waves
-        static const int persist = getenv("VD_GEMM_BX3_PERSIST") ? atoi(getenv("VD_GEMM_BX3_PERSIST")) : 1;
+        constexpr int persist = 1;
         return (persist && vd_cdiv(d.M, 128) * (d.N / 128) >= 1024) ? 11 : 9;
     }
     if (d.math == 1) return gemm_bx3_act_eligible(d) ? 10 : -1;
@@ -2323,7 +2323,7 @@ static void wgrad_plan(const vd_wgrad_desc& d, int& tile, int& splits, int& kk_p
     const int tiles = vd_cdiv(d.M, bm) * vd_cdiv(Ncols, bn);
     splits = d.splits;
     if (splits <= 0) {  // one full wave of 3 workgroups per CU (768 slots; measured: 528 or 576 WGs leave a half-empty tail)
-        static const int target = getenv("VD_WGRAD_GEN_TARGET") ? atoi(getenv("VD_WGRAD_GEN_TARGET")) : 768;
+        constexpr int target = 768;
         splits = tiles >= target ? 1 : target / tiles;
         const int max_splits = Ktot / (BK * 8) > 0 ? Ktot / (BK * 8) : 1;
         if (splits > max_splits) splits = max_splits;
@@ -2554,30 +2554,7 @@ extern "C" int vd_conv_wgrad_group_plan(const vd_wgrad_desc* descs, int n, void*
     int64_t per = (work + target - 1) / target;                  // K-steps per workgroup
     const int cap = wide1 ? capw : (one ? cap1 : (nine ? cap9 : cap3));
     if (per > cap) per = cap;
-    // The grid runs in ROUNDS of `target` resident workgroups and a partly filled last round costs a whole one (config #2 at 32x32: 84 tiles x 32
-    // K ranges = 2688 workgroups = 3.5 rounds of 768).  VD_WGRAD_QUANT=1: among the K-range lengths up to the cap, take the one that minimises
-    // rounds * (K-steps + a per-round charge for the slabs each workgroup writes and the reduce grid re-reads).  MEASURED NEUTRAL (three interleaved
-    // rounds on one box: 1.46-1.50 ms at 32x32 either way, 20.3-20.7 ms per step either way), so it stays off: the grouped launches are not
-    // paced by their rounds of workgroups.  (Ranges LONGER than the cap lose a lot: the tiles of a K range stay together in L2 only over ~100
-    // steps -- profiles/r03_wgrad_variants.txt.)
-    static const int quant = getenv("VD_WGRAD_QUANT") ? atoi(getenv("VD_WGRAD_QUANT")) : 0;
-    static const int slab_steps = getenv("VD_WGRAD_SLAB_STEPS") ? atoi(getenv("VD_WGRAD_SLAB_STEPS")) : 8;
-    if (quant) {
-        int64_t best_cost = -1, best_per = per;
-        for (int64_t p = per; p >= (per * 2) / 3 && p >= min_ks; --p) {
-            int64_t total = 0;
-            for (int j = 0; j < n; ++j) {
-                total += job_base(descs[j]) * ((job_ks(descs[j]) + p - 1) / p);
-            }
-            const int64_t rounds = (total + target - 1) / target;
-            const int64_t cost = rounds * (p + slab_steps);
-            if (best_cost < 0 || cost < best_cost) {
-                best_cost = cost;
-                best_per = p;
-            }
-        }
-        per = best_per;
-    }
+    // (A round-quantised choice of the K-range length measured neutral and is gone: profiles/HISTORY.md "VD_WGRAD_QUANT".)
     if (per < min_ks) per = min_ks;
     int64_t off = 0;
     int blk = 0, rblk = 0;

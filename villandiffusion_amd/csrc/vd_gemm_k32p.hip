@@ -348,7 +348,7 @@ bool vd_gemm1x1_k32p_pick(const vd_gemm_desc& d) {
     if (nb * d.b_bstride * 4 >= (1ll << 32) || (int64_t)d.K * d.ldb * 4 >= (1ll << 32)) return false;      // 32-bit buffer offsets
     const int nt = vd_cdiv(d.M, 128) * (d.N / 256);               // (the 256 x 128 tiles of M % 256 == 0 problems: the same count)
     const int rounds = vd_cdiv(nt, 256);
-    static const int min_tiles = env_int("VD_G32P_MIN_TILES", 192);
+    constexpr int min_tiles = 192;          // (lower thresholds measured neutral: profiles/r04_g32p_min_tiles.txt)
     if (nt < min_tiles) return false;
     return nt < 192 || 4 * nt >= 3 * rounds * 256;                // every round of 256 workgroup slots at least 75 % full
 }

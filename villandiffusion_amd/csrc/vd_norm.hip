@@ -1277,7 +1277,7 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
                     ((x_bstride | dy_bstride | dx_bstride | extra_bstride | extra2_bstride) & 3) == 0;
     const int S = (al && ws) ? gn_chunks(B, C, HW, G) : 0;
     const bool reg_ok = !S && al && HW % 4 == 0 && slab <= GN_REG_MAX &&
-                        ((L >= 64 && L % 64 == 0) || (L < 64 && (L & (L - 1)) == 0 && L > 0)) && getenv("VD_GN_BWD_GENERIC") == nullptr;
+                        ((L >= 64 && L % 64 == 0) || (L < 64 && (L & (L - 1)) == 0 && L > 0));
     if (reg_ok) {
 #define VD_GN_BWD(NVV, NT)                                                                                                          \
     hipLaunchKernelGGL((gn_bwd_reg_kernel<NVV, NT>), dim3(B * G), dim3(NT), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, \
