@@ -154,6 +154,8 @@ def test_training_forward_with_folded_groupnorm_is_bit_identical(B, stream):
     net = UNet2DModel()
     net.reset_parameters(seed=5)
     net.wgrad_stream = stream
+    net.presplit = False                 # (round 5's default forward takes its GroupNorm statistics in another summation order: this opt-in variant is
+                                         #  defined against, and bit-identical to, the CONVERTING normalise-pass forward)
     x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
     t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(2)).cuda()
     dy = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
@@ -342,9 +344,16 @@ def test_full_size_batch128_properties():
         y4 = net(xc[:4], tc[:4])[0]
         y4_ref = ref(x[:4], t[:4])[0]
     assert torch.equal(yp, yn[perm.cuda()])                                  # permutation equivariance (bit-exact)
-    # the no-grad forward (GroupNorm + SiLU in the convolutions' loaders) with the statistics PASS is the training forward bit for bit; with the
-    # statistics summed in conv1's epilogue (the default) the variance differs in its last bits
-    assert torch.equal(yn0, y1)
+    # the no-grad forward (GroupNorm + SiLU in the convolutions' loaders) with the statistics PASS is the CONVERTING training forward bit for bit
+    # (net.presplit = False: round 4's kernels); the pre-split training forward (default) and the no-grad forward with the statistics summed in
+    # conv1's epilogue (default) take their GroupNorm statistics in other summation orders: equal to rounding
+    net.presplit = False
+    try:
+        y1c, _ = fwd_bwd(1.0)
+    finally:
+        net.presplit = True
+    assert torch.equal(yn0, y1c)
+    assert rel(y1, y1c) < 2e-5
     assert rel(yn, y1) < 2e-5
     e_sub = rel(y1[:4], y4)
     e_ref = rel(y4, y4_ref)
