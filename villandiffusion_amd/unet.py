@@ -336,6 +336,17 @@ class _Resnet:
             net._decl(prefix + ".conv_shortcut.weight", (cout, cin, 1, 1), fan_in=cin)
             net._decl(prefix + ".conv_shortcut.bias", (cout,), fan_in=cin, is_bias=True)
 
+    def _sc_dgrad(self, dout, B, H, W, dev):
+        """dsc = W_sc^T dout: the shortcut's input gradient."""
+        net = self.net
+        wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
+        dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
+        HW = H * W
+        ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
+                 ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
+                 a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
+        return dsc
+
     def ps_plan(self, B, H, W) -> bool:
         """Pre-split operands for this block's two 3x3 convolutions in a TRAINING pass (round 5): both GroupNorms have a pre-split producer kernel,
         all four convolution launches (conv1 / conv2 forward and input gradient) go to the persistent 16x16x32 kernel -- the only reader of
@@ -432,6 +443,14 @@ class _Resnet:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
             return (x, None, m1, r1, h1, None, m2, r2)
         ps = save and self.ps_plan(B, H, W)
+        # The shortcut (a 1x1 convolution of x, HBM-bound) does not depend on the norm1 -> conv1 -> norm2 chain: with net.sc_stream it runs on an
+        # auxiliary stream beside those kernels and is joined before conv2 adds it as the residual
+        sc_aux = self.has_sc and save and net.aux_fork()
+        if sc_aux:
+            with net.aux_scope():
+                ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
+                            net.P[self.prefix + ".conv_shortcut.bias"], out,
+                            a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W, B))
         if ps:                                                # silu(gn(.)) written as the pre-split image its two consumers (convolution, weight gradient) read
             a1, m1, r1 = self.norm1.fwd_ps(x)
         else:
@@ -445,9 +464,12 @@ class _Resnet:
             a2 = torch.empty_like(h1)
             m2, r2 = self.norm2.fwd(h1, a2)
         if self.has_sc:
-            ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
-                        net.P[self.prefix + ".conv_shortcut.bias"], out,
-                        a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W, B))
+            if sc_aux:
+                net.aux_join()
+            else:
+                ops.conv1x1(x, net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin),
+                            net.P[self.prefix + ".conv_shortcut.bias"], out,
+                            a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", False, self.cout, self.cin, H * W, B))
             self.conv2.fwd(a2, out, residual=out)
         else:
             self.conv2.fwd(a2, out, residual=x)
@@ -475,6 +497,10 @@ class _Resnet:
             net.rowsum(dout, bias_ws)
         else:
             bias_ws = dout_rs
+        dsc = None
+        if self.has_sc and net.aux_fork():                    # shortcut input gradient (1x1, HBM-bound; needs dout only) beside the 3x3 chain
+            with net.aux_scope():
+                dsc = self._sc_dgrad(dout, B, H, W, dev)
         da2 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
         self.conv2.bwd(dout, a2, da2, bias_ws=bias_ws)
         dh1 = torch.empty_like(da2)
@@ -488,15 +514,13 @@ class _Resnet:
         da1 = da2 if self.cin == self.cout else torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
         self.conv1.bwd(dh1, a1, da1, bias_ws=dt)
         if self.has_sc:
-            wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
             net.wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
                       math_mode=_wgrad1x1_math(net, dout, x))
             net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout, ld=bias_ws.stride(0))
-            dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
-            HW = H * W
-            ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
-                     ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
-                     a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
+            if dsc is None:
+                dsc = self._sc_dgrad(dout, B, H, W, dev)
+            else:
+                net.aux_join()                            # the shortcut's input gradient ran on the auxiliary stream beside the chain above
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
         else:
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dout, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
@@ -515,6 +539,10 @@ class _Resnet:
             net.rowsum(dout, bias_ws)
         else:
             bias_ws = dout_rs
+        dsc = None
+        if self.has_sc and net.aux_fork():
+            with net.aux_scope():
+                dsc = self._sc_dgrad(dout, B, H, W, dev)
         da2 = torch.empty((B, self.cout, H, W), device=dev, dtype=torch.float32)
         self.conv2.bwd(dout, a2, da2, bias_ws=bias_ws, dout_ps=dout_ps)
         dh1 = ops.presplit_empty((B, self.cout, H, W), dev)
@@ -523,15 +551,13 @@ class _Resnet:
         da1 = da2 if self.cin == self.cout else torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
         self.conv1.bwd(None, a1, da1, bias_ws=dt, dout_ps=dh1)
         if self.has_sc:
-            wsc = net.P[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin)
             net.wgrad(dout, x, net.G[self.prefix + ".conv_shortcut.weight"].view(self.cout, self.cin), B_PLAIN,
                       math_mode=_wgrad1x1_math(net, dout, x))
             net.colsum_later(bias_ws, net.G[self.prefix + ".conv_shortcut.bias"], B, self.cout, ld=bias_ws.stride(0))
-            dsc = torch.empty((B, self.cin, H, W), device=dev, dtype=torch.float32)
-            HW = H * W
-            ops.gemm(wsc, dout, dsc, M=self.cin, N=B * HW, K=self.cout, a_mode=A_COL, b_mode=B_PLAIN, NP=HW, lda=self.cin,
-                     ldb=HW, b_bstride=ops._img(dout)[4], ldd=HW, d_bstride=self.cin * HW,
-                     a_packed=_bx3_packed_1x1(net, self.prefix + ".conv_shortcut", True, self.cin, self.cout, HW, B))
+            if dsc is None:
+                dsc = self._sc_dgrad(dout, B, H, W, dev)
+            else:
+                net.aux_join()                            # the shortcut's input gradient ran on the auxiliary stream beside the chain above
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dsc, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
         else:
             self.norm1.bwd(da1, x, m1, r1, dx, extra=dout, extra2=extra2, rowsum=dx_rs, dx_ps=dx_ps)
@@ -909,6 +935,10 @@ class UNet2DModel(nn.Module):
         # round 5: GroupNorm forward / backward write PRE-SPLIT bf16 (hi, lo) images for the 3x3 convolutions and their weight gradients
         # (csrc/vd_presplit.hip; _Resnet.ps_plan decides per block); VILLAN_PRESPLIT=0: round 4's converting kernels
         self.presplit = os.environ.get("VILLAN_PRESPLIT", "1") != "0"
+        # round 5: the 1x1 shortcut of a ResnetBlock (forward) and its input gradient (backward) on an auxiliary stream beside the block's 3x3
+        # chain (VILLAN_SC_STREAM=0: in line)
+        self.sc_stream = os.environ.get("VILLAN_SC_STREAM", "1") != "0"
+        self._aux_stream = None
         # no-grad forward: the statistics of a ResnetBlock2D's second GroupNorm are summed in the first convolution's epilogue
         # (vd_gemm_desc.gn_part) instead of a read of its output; False: the statistics pass
         self.gn_stats_in_epilogue = os.environ.get("VILLAN_GN_STATS_IN_EPILOGUE", "1") != "0"
@@ -1050,6 +1080,36 @@ class UNet2DModel(nn.Module):
                 norm._fwd_now(xx, yy)
             self._gn_jobs = []
         ops.conv_wgrad(dy, x, dw2d, mode, self.wgrad_ws, accumulate=True, pad=pad, math_mode=math_mode)
+
+    # ---- auxiliary stream: independent HBM-bound launches (the 1x1 shortcut and its input gradient) beside the 3x3 chain of a ResnetBlock ----
+    def aux_fork(self) -> bool:
+        """Make the auxiliary stream wait for everything issued on the current stream so far; False when the overlap is switched off."""
+        if not self.sc_stream or self._dev.type != "cuda":
+            return False
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(device=self._dev)
+        # the packed weight operands are rebuilt lazily by their first user ON THAT USER'S STREAM: make sure that is this one, before the fork
+        # (a rebuild issued from the auxiliary stream would race with the main stream's convolutions reading the same buffer)
+        if _split(self) and self._packed is None:
+            self._packed = _PackedConvWeights(self)
+        if self.conv_math == "f16" and self._packed16 is None:
+            self._packed16 = _PackedConvWeights(self, f16=True)
+        for pk in (self._packed, self._packed16):
+            if pk is not None:
+                pk.refresh(False)
+                pk.refresh(True)
+        self._aux_stream.wait_stream(torch.cuda.current_stream(self._dev))
+        return True
+
+    def aux_scope(self):
+        import contextlib
+        stack = contextlib.ExitStack()
+        stack.enter_context(torch.cuda.stream(self._aux_stream))
+        stack.enter_context(ops.ws_slot(15))                    # its own split-K workspace slot
+        return stack
+
+    def aux_join(self):
+        torch.cuda.current_stream(self._dev).wait_stream(self._aux_stream)
 
     def pack_later(self, t):
         """The pre-split image of `t` (a dY whose producer wrote f32 only) for a queued pre-split weight gradient: packed on the weight-gradient
