@@ -228,3 +228,30 @@ def test_no_split_precision_kernel_is_priced_against_the_f32_peak():
                 assert r["peak"] == (2500.0 if is_split_precision(r["kernel"]) else 157.3), (f, key, r["kernel"], r["peak"])
                 checked += 1
     print(f"[contract] {checked} priced kernel rows checked")
+
+
+def test_round5_lines_carry_ddp_path_and_counted_traffic():
+    """Round-4 review items 3 / 4: the default line reports the multi-rank schedule timed on one GPU (`ddp_path_ms_per_step`, within a few percent
+    of the single-process step) and every committed round-5 line -- the default one and the secondary lines of BASELINE configs #4 / #5 -- carries
+    the dominant kernel's HBM traffic from that configuration's own PMC passes, with a per-kernel traffic / algorithmic table beside it."""
+    d = _line("r05_bench_default.json")
+    assert d["metric"].startswith("train imgs/sec") and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    assert d["ddp_path_ms_per_step"] and 0.95 <= d["ddp_path"]["vs_single_process"] <= 1.05
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] and 0.5 < r["traffic"] / (r["algorithmic_mbytes_per_launch"] * 1e6) < 3.0
+    assert d["parity"]["pass"] is True and d["cpu_baseline"]["kind"] == "port"
+    for tag in ("cfg4", "cfg5"):
+        c = _line(f"r05_bench_{tag}.json")
+        assert c["roofline"]["traffic"] and c["roofline"]["traffic_source"].startswith(f"profiles/r05_pmc_traffic_{tag}.json")
+        with open(os.path.join(P, f"r05_pmc_traffic_{tag}.json")) as f:
+            t = json.load(f)["kernels"]
+        rows = [v for v in t.values() if "traffic_over_algorithmic" in v]
+        assert len(rows) >= 10 and any("MfmaUtil" in v for v in t.values())
+        k = c["roofline"]["kernel"].split("(+")[0].split("@")[0]
+        assert t[k]["traffic_bytes_per_launch"] == c["roofline"]["traffic"]
+    # the pre-split kernels are what the profiled step ran, and the counters see the matrix pipe busier than under the converting kernels
+    with open(os.path.join(P, "r05_pmc_mfma.json")) as f:
+        m = json.load(f)["kernels"]
+    assert m["wgrad_ps_group_kernel<32, 0>"]["MfmaUtil"] > 0.6 and m["wgrad_ps_group_kernel<16, 0>"]["MfmaUtil"] > 0.6

@@ -10,8 +10,15 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection*.csv"), recursi
     with open(f, newline="") as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
-            name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
-            name = re.sub(r"\([^()]*\)$", "", name)          # drop the argument list, keep template arguments
+            name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").strip()
+            if name.endswith(")"):                            # drop the argument list (matched parentheses: `unsigned int __vector(4)*` nests), keep template arguments
+                depth = 0
+                for i in range(len(name) - 1, -1, -1):
+                    depth += name[i] == ")"
+                    depth -= name[i] == "("
+                    if depth == 0:
+                        name = name[:i].rstrip()
+                        break
             if filters and not any(s in name for s in filters):
                 continue
             c = row.get("Counter_Name")

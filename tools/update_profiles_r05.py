@@ -38,8 +38,32 @@ def last_line(p):
 
 
 def norm(name):
-    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
-    return re.sub(r"\([^()]*\)$", "", name)
+    """Kernel symbol without `void `, the anonymous namespace and the ARGUMENT LIST (matched parentheses: `unsigned int __vector(4)*` nests)."""
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").strip()
+    if name.endswith(")"):
+        depth = 0
+        for i in range(len(name) - 1, -1, -1):
+            depth += name[i] == ")"
+            depth -= name[i] == "("
+            if depth == 0:
+                return name[:i].rstrip()
+    return name
+
+
+def load_pmc(path):
+    """A tools/pmc_summary.py file with its kernel names normalised (and entries that collapse onto one name merged by dispatch-weighted mean)."""
+    out = {}
+    for k, v in json.load(open(path)).items():
+        nk = norm(k)
+        if nk not in out:
+            out[nk] = v
+            continue
+        for c, e in v.items():
+            o = out[nk].setdefault(c, {"dispatches": 0, "avg": 0.0})
+            n = o["dispatches"] + e["dispatches"]
+            o["avg"] = (o["avg"] * o["dispatches"] + e["avg"] * e["dispatches"]) / max(n, 1)
+            o["dispatches"] = n
+    return out
 
 
 for name in ("bench_default", "bench_train_under_rocprof", "bench_sample_under_rocprof"):
@@ -86,7 +110,7 @@ for k in detail.get("train_step_kernels") or []:
 
 fp, wp = os.path.join(src, "pmc_FETCH_SIZE.json"), os.path.join(src, "pmc_WRITE_SIZE.json")
 if os.path.exists(fp) and os.path.exists(wp):
-    f, w = json.load(open(fp)), json.load(open(wp))
+    f, w = load_pmc(fp), load_pmc(wp)
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --mode train --serial-wgrad --steps 3 "
                    "--warmup 2 --no-cpu --no-exact --no-roofline: two separate passes, training dispatches only (tools/collect_profiles_r05.sh), reduced to "
                    "per-dispatch averages by tools/pmc_summary.py (KB as rocprofv3 reports them).  traffic_bytes_per_launch = 2 * FETCH_SIZE + "
@@ -113,7 +137,7 @@ if os.path.exists(fp) and os.path.exists(wp):
 
 mp = os.path.join(src, "pmc_mfma.json")
 if os.path.exists(mp):
-    d = json.load(open(mp))
+    d = load_pmc(mp)
     om = {"_how": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 "
                   "SQ_INSTS_VALU_MFMA_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 bench.py --mode train --serial-wgrad --steps 3 --warmup 2 "
                   "--no-cpu --no-exact --no-roofline (its own pass, training dispatches only), per-dispatch averages.  executed GFLOP = 512 * (MOPS_F32 + "
@@ -149,7 +173,7 @@ if os.path.exists(p):
         sdur[norm(r_["Name"])] = float(r_["AverageNs"]) / 1e3
 sf, sw, sm = (os.path.join(src, n) for n in ("pmc_sample_FETCH_SIZE.json", "pmc_sample_WRITE_SIZE.json", "pmc_sample_mfma.json"))
 if all(os.path.exists(x) and os.path.getsize(x) for x in (sf, sw, sm)):
-    f, w, m = json.load(open(sf)), json.load(open(sw)), json.load(open(sm))
+    f, w, m = load_pmc(sf), load_pmc(sw), load_pmc(sm)
     outs = {"_how": "as r05_pmc_traffic.json / r05_pmc_mfma.json, over `bench.py --mode sample --sample-steps 30 --sample-images 128` (the sampler's dispatches only; "
                     "the HIP graph replays kernel by kernel under the profiler); avg_us from r05_sample_kernel_stats.csv", "kernels": {}}
     for k in sorted(set(f) | set(w) | set(m)):
@@ -182,8 +206,8 @@ for cfg, tag in (("celebahq256", "cfg4"), ("ldm64", "cfg5")):
     fp, wp, mp = (os.path.join(src, f"pmc_{cfg}_{c}.json") for c in ("FETCH_SIZE", "WRITE_SIZE", "mfma"))
     if not all(os.path.exists(x) and os.path.getsize(x) for x in (fp, wp)):
         continue
-    f, w = json.load(open(fp)), json.load(open(wp))
-    m = json.load(open(mp)) if os.path.exists(mp) and os.path.getsize(mp) else {}
+    f, w = load_pmc(fp), load_pmc(wp)
+    m = load_pmc(mp) if os.path.exists(mp) and os.path.getsize(mp) else {}
     outc = {"_how": f"as r05_pmc_traffic.json / r05_pmc_mfma.json, over `bench.py --config {cfg} --steps 2 --warmup 2 --serial-wgrad --no-roofline` (separate FETCH_SIZE / "
                     f"WRITE_SIZE / MFMA rocprofv3 --pmc passes, --kernel-trace only); traffic = 2 * FETCH + WRITE (gfx950 correction); avg_us from "
                     f"r05_{tag}_kernel_stats.csv (same command under --kernel-trace --stats); algorithmic bytes from the bench line's per-kernel table", "kernels": {}}
@@ -214,6 +238,17 @@ for cfg, tag in (("celebahq256", "cfg4"), ("ldm64", "cfg5")):
             with open(bp, "w") as fh:
                 fh.write(json.dumps(line) + "\n")
 
+tp = os.path.join(dst, "r05_pmc_traffic.json")           # the default line of the same collection run gets its dominant kernel's counted traffic
+if os.path.exists(tp):
+    tk = json.load(open(tp))["kernels"]
+    for key in ("roofline", "roofline_largest_flops"):
+        rr = bench.get(key) or {}
+        kk = rr.get("kernel", "").split("(+")[0].split("@")[0]
+        if kk in tk and not rr.get("traffic"):
+            rr["traffic"] = tk[kk]["traffic_bytes_per_launch"]
+            rr["traffic_source"] = "profiles/r05_pmc_traffic.json (separate rocprofv3 --pmc passes of the same collection run)"
+    with open(os.path.join(dst, "r05_bench_default.json"), "w") as fh:
+        fh.write(json.dumps(bench) + "\n")
 r = bench["roofline"]
 print(f"value {bench['value']} img/s, {bench['ms_per_step']} ms/step; sample {bench['sample_ddpm1000_images_per_sec']} img/s ({bench['sample_seconds']} s, "
       f"graph={bench.get('sample_hip_graph')}); exact-f32 {bench.get('exact_f32_mode')}; parity {bench.get('parity')}")

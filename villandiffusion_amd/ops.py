@@ -325,7 +325,9 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
     if tl == 10:
         name = f"gemm_bx3_act_kernel<{int(a_mode == A_ROW)}, {int(b_mode == B_KCONTIG)}>"
     elif tl == 19:
-        name = "gemm1x1_k32p_kernel<true>" if d.math == 2 else "gemm1x1_k32p_kernel<false>"
+        # (the 256 x 128 tile where M % 256 == 0: vd_launch_gemm1x1_k32p; symbol names as rocprofv3 prints them)
+        big = d.math != 2 and M % 256 == 0 and N % 128 == 0 and os.environ.get("VD_G32P_BM256", "1") != "0"
+        name = "gemm1x1_k32p_kernel<true, 128>" if d.math == 2 else f"gemm1x1_k32p_kernel<false, {256 if big else 128}>"
     elif tl in (9, 11, 13):
         name = "gemm_bx3_persist_kernel" if tl == 11 else f"gemm_bx3_kernel<{512 if tl == 13 else 256}>"
     elif tl == 17:
