@@ -274,6 +274,7 @@ def bench_secondary_config(args):
         net.conv_math = args.conv_math
     if args.serial_wgrad:
         net.wgrad_stream = False
+        net.sc_stream = False                          # (and no shortcut launches on the auxiliary stream: every kernel's duration is its own)
     fwd_flop = unet_forward_flops(net)
     n_par = sum(p.numel() for p in net.parameters())
     lf = LossFn(sched, sde, psi=1, solver_type="sde")
@@ -327,12 +328,13 @@ def bench_secondary_config(args):
     kernels = None
     if not args.no_roofline:
         ws0, net.wgrad_stream = net.wgrad_stream, False
+        sc0, net.sc_stream = net.sc_stream, False
         for _ in range(2):
             ops.profile_start()
             one_step()
             torch.cuda.synchronize()
             rec = ops.profile_stop()
-        net.wgrad_stream = ws0
+        net.wgrad_stream, net.sc_stream = ws0, sc0
         kernels = summarise(rec)
     if rank == 0:
         split = net.conv_math == "bf16x3"
@@ -456,6 +458,7 @@ def main():
         net.conv_math = args.conv_math
     if args.serial_wgrad:
         net.wgrad_stream = False
+        net.sc_stream = False                          # (and no shortcut launches on the auxiliary stream: every kernel's duration is its own)
     sched = DDPMScheduler(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, clip_sample=False)
     loss_fn = LossFn(sched, "SDE-VP", psi=1, solver_type="sde")
     loss_fn.noise_seed = 1234 + rank
@@ -706,12 +709,13 @@ def main():
     roofline, kernels, sample_kernels = None, None, None
     if not args.no_roofline and do_train:
         ws0, net.wgrad_stream = net.wgrad_stream, False   # per-launch durations: no weight-gradient kernels running beside the bracketed launch
+        sc0, net.sc_stream = net.sc_stream, False         # ... and no shortcut 1x1 on the auxiliary stream
         for _ in range(2):                       # every rank runs the step (it contains the all-reduce); rank 0 reports
             ops.profile_start()
             one_step(10_000)
             torch.cuda.synchronize()
             rec = ops.profile_stop()
-        net.wgrad_stream = ws0
+        net.wgrad_stream, net.sc_stream = ws0, sc0
         barrier()
         if rank == 0:
             kernels = summarise(rec)
