@@ -1,5 +1,7 @@
 """Per-shape timing of the persistent 1x1 kernel on config #2's 1x1 products at B = 128 (forward and input gradient); run once per setting of
-VD_G32P_BM256 (0: 128 x 256 tiles everywhere, 1: 256 x 128 tiles where M % 256 == 0).   python tools/g32p_bm_ab.py"""
+VD_G32P_BM256 (0: 128 x 256 tiles everywhere, 1: 256 x 128 tiles where M % 256 == 0) / VD_G32P_DEPTH (2 | 3 stages of load lead); the hash column is
+over the outputs (the settings only change the schedule: it must not move).   python tools/g32p_bm_ab.py"""
+import hashlib
 import math
 import os
 import sys
@@ -10,7 +12,7 @@ from villandiffusion_amd.lib import A_COL, B_PLAIN
 
 DEV = torch.device("cuda")
 B = 128
-SHAPES = [("qkv", 256, 768, 16), ("attn out / shortcut", 256, 256, 16), ("shortcut", 128, 256, 16), ("shortcut", 512, 256, 16), ("shortcut", 384, 256, 16),
+SHAPES = [("qkv", 256, 768, 16), ("shortcut x3 tiles", 128, 256, 32), ("attn out / shortcut", 256, 256, 16), ("shortcut", 128, 256, 16), ("shortcut", 512, 256, 16), ("shortcut", 384, 256, 16),
           ("shortcut", 384, 128, 32), ("shortcut", 256, 128, 32)]
 
 
@@ -43,5 +45,6 @@ for name, cin, cout, S in SHAPES:
     tile_b = ops.LAST_GEMM_TILE
     byt = 4.0 * (x.numel() + y.numel())
     tot += t_f + t_b
-    print(f"{name:20s} {cin:4d} -> {cout:4d} @{S:2d}: forward {t_f:6.1f} us (tile {tile_f}, {byt / t_f / 1e6:.2f} TB/s)   input gradient {t_b:6.1f} us (tile {tile_b}, {byt / t_b / 1e6:.2f} TB/s)")
-print(f"VD_G32P_BM256={os.environ.get('VD_G32P_BM256', '1')}: sum {tot:.1f} us")
+    hsh = hashlib.sha1(y.cpu().numpy().tobytes() + dx.cpu().numpy().tobytes()).hexdigest()[:10]
+    print(f"{hsh} {name:20s} {cin:4d} -> {cout:4d} @{S:2d}: forward {t_f:6.1f} us (tile {tile_f}, {byt / t_f / 1e6:.2f} TB/s)   input gradient {t_b:6.1f} us (tile {tile_b}, {byt / t_b / 1e6:.2f} TB/s)")
+print(f"VD_G32P_BM256={os.environ.get('VD_G32P_BM256', '1')} VD_G32P_DEPTH={os.environ.get('VD_G32P_DEPTH', '3')}: sum {tot:.1f} us")
