@@ -1,5 +1,5 @@
 """Where a tile of the persistent 16x16x32 convolution spends its time: in-kernel s_memrealtime / s_memtime stamps (diagnostic build,
--DVD_K32P_STAMPS; see tools/r04_stamps.sh) per workgroup: start, prologue done, then per tile: channel loop done, epilogue issued.
+-DVD_K32P_STAMPS; see tools/attic/r04_stamps.sh) per workgroup: start, prologue done, then per tile: channel loop done, epilogue issued.
     python tools/k32p_stamps.py"""
 import math
 import os

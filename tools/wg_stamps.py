@@ -1,5 +1,5 @@
 """Where a K-step of the split-precision 3x3 weight gradient (wgrad_bx3_body) spends its time: per-wave s_memtime sums around the loop's
-segments (diagnostic build -DVD_WG_STAMPS, tools/diag/libvillan_hip_wgstamps.so; see tools/r04_wg_stamps.sh).  The grouped launch of
+segments (diagnostic build -DVD_WG_STAMPS, tools/diag/libvillan_hip_wgstamps.so; see tools/attic/r04_wg_stamps.sh).  The grouped launch of
 BASELINE config #2's ten 32x32 layers (or the four 16x16 ones) at B = 128.
     python tools/wg_stamps.py [32|16]"""
 import ctypes as C
