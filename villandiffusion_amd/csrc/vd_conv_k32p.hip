@@ -99,6 +99,29 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
 #define VD_STAMP()
 #endif
     VD_STAMP();                                                   // 0: workgroup start
+#ifdef VD_K32P_STAMPS      // per-wave segment sums of the stage pipeline (shader cycles): [issue, mfma, patch switch, vmcnt wait, barrier, epilogue];
+                           // every tick is one s_memtime round trip on the wave's critical path (~100-200 cycles): read differences, not absolutes
+    unsigned long long fs[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, ft_prev = 0ull;
+    auto ftick = [&](int k) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (k >= 0) fs[k] += t - ft_prev;
+        ft_prev = t;
+    };
+#define VD_FTICK(k)                                 \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        ftick(k);                                   \
+        __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+#else
+#define VD_FTICK(k)
+#endif
+#ifdef VD_K32P_VARIANTS    // timing-only ablations (WRONG results) of the diagnostic build (tools/build_k32p_diag.sh): VD_K32P_FLAGS bits 2 / 4 / 8 / 16
+    const bool fl_nopatch = a.flags & 2, fl_nodma = a.flags & 4, fl_noepi = a.flags & 8, fl_nomfma = a.flags & 16;
+#else
+    constexpr bool fl_nopatch = false, fl_nodma = false, fl_noepi = false, fl_nomfma = false;
+#endif
 
     // ---- this workgroup's tile list: XCD x = blockIdx % 8 owns the contiguous range [xs, xs + xn), slot j = blockIdx / 8 walks xs + j, + G/8, ...
     const int G8 = gridDim.x >> 3;                                // workgroups per XCD (gridDim.x % 8 == 0)
@@ -522,6 +545,7 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
     }
     __syncthreads();
     VD_STAMP();                                                   // 1: prologue done
+    VD_FTICK(-1);
 
     int t = 0;                                                    // stage parity across tiles
     while (true) {
@@ -540,14 +564,14 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                 const int sm1 = stage_m0(cp, r, 1, m0, m0n, scp1, sr1, ex1, has_next);
                 const int sm2 = stage_m0(cp, r, 2, m0, m0n, scp2, sr2, ex2, has_next);
                 if constexpr (DMA) {
-                    if (ex1) load_a(sm1, scp1, sr1, buf ^ 1);     // As[buf ^ 1] was last read by M(s-1): every wave has left the barrier behind it
+                    if (ex1 && !fl_nodma) load_a(sm1, scp1, sr1, buf ^ 1);     // As[buf ^ 1] was last read by M(s-1): every wave has left the barrier behind it
                 } else if (late) {
                     if (ex1) store_a(buf ^ 1);                    // W(s+1)
                     if (ex2) load_a(sm2, scp2, sr2, 0);           // G(s+2)
                 } else if (ex1) {
                     load_a(sm1, scp1, sr1, 0);                    // G(s+1)
                 }
-                if (r == 1 && pnext) {
+                if (r == 1 && pnext && !fl_nopatch) {
                     if (more) {
                         load_p(cp + 1);
                     } else {                                      // the next tile's first patch
@@ -556,35 +580,49 @@ __global__ __launch_bounds__(512, 2) void conv3_k32p_kernel(const k32p_args a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (r == 2 && pnext) {                            // VALU work beside the MFMAs of this tap row
+                VD_FTICK(0);
+                if (r == 2 && pnext && !fl_nopatch) {             // VALU work beside the MFMAs of this tap row
                     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT) : "memory");   // the patch loads (older than this stage's DMAs)
                     convert_p(more ? cp + 1 : 0);
                 }
-                if constexpr (F16) mfma_row_f16(r, buf);
-                else if constexpr (PIPE) mfma_row_pipe(r, buf);
-                else mfma_row(r, buf);
+                if (!fl_nomfma) {
+                    if constexpr (F16) mfma_row_f16(r, buf);
+                    else if constexpr (PIPE) mfma_row_pipe(r, buf);
+                    else mfma_row(r, buf);
+                }
+                VD_FTICK(1);
                 if (!DMA && !late && ex1) store_a(buf ^ 1);       // W(s+1)
-                if (r == 2 && pnext) {
+                if (r == 2 && pnext && !fl_nopatch) {
                     __syncthreads();                              // every wave has finished reading the patch
                     write_p();
                 }
+                VD_FTICK(2);
                 if constexpr (DMA) {
                     // this stage's DMAs (issued before any patch load of this stage) must have landed before the barrier that releases M(s+1)
-                    if (r == 1 && pnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LOADS) : "memory");
+                    if (r == 1 && pnext && !fl_nopatch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LOADS) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                VD_FTICK(3);
                 __syncthreads();
+                VD_FTICK(4);
             }
         }
         VD_STAMP();                                               // 2, 4, ...: a tile's channel loop done
-        epilogue(m0, b0, y0, x0, tix);
+        if (!fl_noepi) epilogue(m0, b0, y0, x0, tix);
         VD_STAMP();                                               // 3, 5, ...: its epilogue issued
+        VD_FTICK(5);
         if (!has_next) break;
         id += G8;
         m0 = m0n, b0 = b0n, y0 = y0n, x0 = x0n, tix = tixn;
         has_next = id + G8 < id_end;
         if (has_next) decode(id + G8, m0n, b0n, y0n, x0n, tixn);
     }
+#ifdef VD_K32P_STAMPS
+    if (a.stamps != nullptr && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.stamps[256 * 32 + (blockIdx.x * 8 + wave) * 8 + k] = fs[k];
+    }
+#endif
 }
 
 // f16 packed weights (math = 2): unit ((cc * T + t) * 2 + q) * Mpad + m = the 8 channels cc * 16 + q * 8 + j of tap t, row m, as f16 (one plane:
