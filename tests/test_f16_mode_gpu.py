@@ -148,6 +148,7 @@ def test_f16_training_mode_tracks_the_default_arithmetic():
     steps_before, sched_before = tr.opt.step_count, tr.sched_step
     tr.check_skipped(force=True)                               # the lazy check (every `scale_check_every` steps in a run)
     assert tr.loss_scale == 2048.0 and tr.overflow_steps_seen == 1
+    assert tr._recheck                                         # a check that found skipped steps is repeated after EVERY step until one passes clean
     assert tr.opt.step_count == steps_before - 1               # the refused step does not count for the bias correction ...
     assert tr.sched_step == max(0, sched_before - 1)           # ... nor for the LR schedule (GradScaler / accelerate skip both)
     net.zero_grad()
@@ -156,8 +157,13 @@ def test_f16_training_mode_tracks_the_default_arithmetic():
     l2 = float(tr.train_step(batch, t))
     assert lf.grad_scale == 2048.0 / tr.grad_accum and tr._step_scale == 2048.0
     assert math.isfinite(l2) and not torch.equal(net.flat_param, p_before)
-    # the scale state survives a checkpoint
+    assert not tr._recheck                                     # (that step was clean: back to the `scale_check_every` cadence)
+    # the scale state survives a checkpoint; saving one reads the skip counter but is NOT an optimiser step (advisor r5: it used to advance the
+    # growth interval, so a checkpoint every few steps shortened the 2000-step interval)
+    growth_before, scale_before = tr._since_growth, tr.loss_scale
     sd = tr.state_dict()
+    sd = tr.state_dict()
+    assert tr._since_growth == growth_before and tr.loss_scale == scale_before and sd["since_growth"] == growth_before
     tr2 = Trainer(net, lf, lr=1e-4, total_steps=100, warmup_steps=0)
     tr2.load_state_dict(sd)
     assert tr2.loss_scale == 2048.0 and tr2.overflow_steps_seen == 1

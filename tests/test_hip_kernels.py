@@ -323,6 +323,17 @@ except L.VillanHipError as e:
     assert "poll timeout" in str(e) and "-110" in str(e), str(e)
 else:
     raise AssertionError("the sticky GroupNorm error did not fail the next call")
+# the pre-split producers (the default training GroupNorm at 16x16 / 32x32) honour the flag too (advisor r5: only vd_norm.hip checked it)
+xs = torch.randn(2, 128, 32, 32, device=dev)
+ys = ops.presplit_empty(xs.shape, dev)
+for call in (lambda: ops.groupnorm_fwd_presplit(xs, gamma, beta, ys, mean, rstd, 32, 1e-6, True),
+             lambda: ops.groupnorm_bwd_presplit(xs, xs, mean, rstd, gamma, beta, None, ys, torch.empty(2 * 128, device=dev), torch.empty(2 * 128, device=dev), 32, True)):
+    try:
+        call()
+    except L.VillanHipError as e:
+        assert "poll timeout" in str(e) and "-110" in str(e), str(e)
+    else:
+        raise AssertionError("a pre-split GroupNorm entry point ignored the sticky error")
 assert L.load().vd_async_errors(1) == n and L.load().vd_async_errors(0) == 0
 print("GN sticky ok")
 """

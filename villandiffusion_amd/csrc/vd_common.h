@@ -9,6 +9,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void vd_set_error(const char* fmt, ...);
+// vd_norm.hip: VD_ETIMEDOUT (with the message set) while an asynchronous GroupNorm poll timeout is pending (vd_async_errors), else 0 -- the check at the
+// top of EVERY vd_groupnorm_* entry point, the pre-split producers of vd_presplit.hip included
+int vd_gn_sticky(const char* who);
 
 #define VD_REQUIRE(cond, ...)              \
     do {                                   \

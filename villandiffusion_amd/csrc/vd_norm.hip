@@ -1093,7 +1093,7 @@ static int gn_chunk1_capacity() {
 }
 
 // a timeout reported by an earlier polling launch fails every later GroupNorm call until vd_async_errors(1) clears it
-static int gn_sticky(const char* who) {
+int gn_sticky_impl(const char* who) {
     const unsigned n = gn_flag_read();
     if (n == 0) return 0;
     vd_set_error("%s: %u GroupNorm poll timeout(s) reported by an earlier one-launch chunked kernel (statistics were NaN); "
@@ -1102,6 +1102,9 @@ static int gn_sticky(const char* who) {
 }
 
 }  // namespace
+
+// (vd_common.h) every vd_groupnorm_* entry point, the pre-split ones of vd_presplit.hip included, fails while the flag is set
+int vd_gn_sticky(const char* who) { return gn_sticky_impl(who); }
 
 extern "C" int vd_async_errors(int clear) {
     const unsigned n = gn_flag_read();
@@ -1126,7 +1129,7 @@ extern "C" int vd_groupnorm_fwd(const float* x, const float* gamma, const float*
                     ((((uintptr_t)y) & 15) == 0);
     const bool reg_ok = al && slab <= GN_REG_MAX;
     const int S = (al && ws) ? gn_chunks(B, C, HW, G, true) : 0;
-    if (const int rc = gn_sticky("vd_groupnorm_fwd")) return rc;
+    if (const int rc = vd_gn_sticky("vd_groupnorm_fwd")) return rc;
     if (S && gn_chunk1_ok((hipStream_t)stream, S)) {       // one launch: the chunk stays in registers between statistics and apply
         unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + 4 * (int64_t)B * G * S);
         unsigned* flag = gn_flag_dev();
@@ -1270,7 +1273,7 @@ extern "C" int vd_groupnorm_bwd_fused(const float* dy, const float* x, const flo
     VD_REQUIRE(dy && x && mean && rstd && gamma && beta && dx && dgamma_ws && dbeta_ws, "vd_groupnorm_bwd: null pointer");
     VD_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= 64, "vd_groupnorm_bwd: bad dims");
     VD_REQUIRE(!rowsum || rowsum_ld >= C, "vd_groupnorm_bwd: rowsum_ld < C");
-    if (const int rc = gn_sticky("vd_groupnorm_bwd")) return rc;
+    if (const int rc = vd_gn_sticky("vd_groupnorm_bwd")) return rc;
     const int64_t slab = (int64_t)(C / G) * HW;
     const int L = HW / 4;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)extra) | ((uintptr_t)extra2)) & 15) == 0 &&

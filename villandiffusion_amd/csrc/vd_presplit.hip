@@ -670,6 +670,7 @@ extern "C" int vd_groupnorm_fwd_presplit(const float* x, const float* gamma, con
     VD_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0, "vd_groupnorm_fwd_presplit: null pointer");
     VD_REQUIRE(vd_groupnorm_fwd_presplit_ok(C, HW, G), "vd_groupnorm_fwd_presplit: no kernel for C=%d HW=%d G=%d (vd_groupnorm_fwd_presplit_ok)", C, HW, G);
     VD_REQUIRE((((uintptr_t)y) & 15) == 0 && (y_bstride & 3) == 0, "vd_groupnorm_fwd_presplit: the pair image must be 16-byte aligned");
+    if (const int rc = vd_gn_sticky("vd_groupnorm_fwd_presplit")) return rc;      // a poll timeout elsewhere: its NaN statistics must not be consumed here either
     const int cpg = C / G;
     hipStream_t st = (hipStream_t)stream;
     u32x4* yy = reinterpret_cast<u32x4*>(y);
@@ -701,6 +702,7 @@ extern "C" int vd_groupnorm_bwd_presplit(const float* dy, const float* x, const 
     VD_REQUIRE(vd_groupnorm_fwd_presplit_ok(C, HW, G), "vd_groupnorm_bwd_presplit: no kernel for C=%d HW=%d G=%d (vd_groupnorm_fwd_presplit_ok)", C, HW, G);
     VD_REQUIRE(!dx_ps || ((((uintptr_t)dx_ps) & 15) == 0 && (ps_bstride & 3) == 0), "vd_groupnorm_bwd_presplit: the pair image must be 16-byte aligned");
     VD_REQUIRE(!rowsum || rowsum_ld >= C, "vd_groupnorm_bwd_presplit: rowsum_ld < C");
+    if (const int rc = vd_gn_sticky("vd_groupnorm_bwd_presplit")) return rc;
     const int cpg = C / G;
     hipStream_t st = (hipStream_t)stream;
     u32x4* pp = reinterpret_cast<u32x4*>(dx_ps);

@@ -204,6 +204,7 @@ def groupnorm_bwd_presplit(dy, x, mean, rstd, gamma, beta, dx, dx_ps, dgamma_ws,
 # --------------------------------------------------------------------------------------------- GEMM family
 _GEMM_WS = {}
 _WS_SLOT = 0
+AUX_WS_SLOT = -1       # the UNet's auxiliary stream (unet.aux_scope): outside the non-negative slots pipelines.sample_concurrent hands to its streams
 
 
 class ws_slot:

@@ -125,7 +125,8 @@ class GraphedMicroStep:
         if _DEBUG:
             print("[graph] warm-up done", flush=True)
         net.flat_grad.copy_(keep)                         # the warm-up passes accumulated gradients: undo
-        self._keep = (ops.gemm_ws_buffer(dev, 0), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws, getattr(net, "_packed16", None))
+        self._keep = (ops.gemm_ws_buffer(dev, 0), ops._WG_WS.get(dev), getattr(net, "_packed", None), net.wgrad_ws, getattr(net, "_packed16", None),
+                      ops.gemm_ws_buffer(dev, ops.AUX_WS_SLOT))      # (the auxiliary stream's workspace: its address is baked into the capture too)
         self.graph = torch.cuda.CUDAGraph()
         ops.capture_begin(dev)                            # job tables built during the capture are uploaded right after it (ops.upload_table)
         try:
@@ -144,7 +145,7 @@ class GraphedMicroStep:
     def valid(self) -> bool:
         dev = self.net.device
         return (self.key == self._key() and self._keep[0] is ops.gemm_ws_buffer(dev, 0) and self._keep[1] is ops._WG_WS.get(dev)
-                and self._keep[3] is self.net.wgrad_ws)
+                and self._keep[3] is self.net.wgrad_ws and self._keep[5] is ops.gemm_ws_buffer(dev, ops.AUX_WS_SLOT))
 
     def _body(self):
         net, lf = self.net, self.trainer.loss_fn
@@ -196,6 +197,7 @@ class Trainer:
         self._since_growth = 0
         self.overflow_steps_seen = 0
         self._skipped_seen = 0                    # value of opt.skipped at the last lazy check
+        self._recheck = False                     # the last lazy check found skipped steps: read the counter after every step until one passes clean
         self.loss_fn.grad_scale = self._scale() / self.grad_accum
         self._pending = []                        # async all-reduce handles of the current optimiser step
         self._sync_now = False
@@ -219,17 +221,23 @@ class Trainer:
     def _scale(self) -> float:
         return self.loss_scale if getattr(self.model, "conv_math", None) == "f16" else 1.0
 
-    def check_skipped(self, force: bool = False):
+    def check_skipped(self, force: bool = False, count_step: bool = True):
         """Lazy finite-gradient check, every arithmetic: the Adam kernel leaves the parameters alone when the gradient norm is not finite and
         counts the step on the device; that counter is read back every `scale_check_every` optimiser steps (and from `state_dict`).
 
         * f16 mode (GradScaler semantics, reference VillanDiffusion.py:260-264 -> accelerate): ANY skipped step since the last check halves the
           loss scale and restarts the growth interval; skipped steps are taken back out of Adam's bias-correction count and the LR schedule
-          (GradScaler / accelerate skip both), at the check rather than at the step -- the price of not synchronising every step;
+          (GradScaler / accelerate skip both), at the check rather than at the step -- the price of not synchronising every step.  After a check
+          that found skipped steps the counter is read after EVERY step until a step passes clean (a persistent overflow then costs one step
+          per halving, as under GradScaler, not `scale_check_every` steps);
         * every other arithmetic has no scale to lower: a non-finite gradient norm is a broken run (NaN statistics out of a GroupNorm poll
-          timeout, a diverged model, ...) and raises instead of training on silently."""
-        self._since_growth += 1
-        if not force and self.sched_step % self.scale_check_every:
+          timeout, a diverged model, ...) and raises instead of training on silently.
+
+        count_step: this call follows an optimiser step (train_step).  A forced read from `state_dict` passes False: it applies what the
+        counter already holds (a checkpoint never records steps the kernel refused) but advances neither the growth interval nor the scale."""
+        if count_step:
+            self._since_growth += 1
+        if not force and not self._recheck and self.sched_step % self.scale_check_every:
             return
         if self.opt.max_grad_norm is None and self._scale() == 1.0:
             return                                   # no norm kernel in this configuration: nothing was counted
@@ -240,13 +248,14 @@ class Trainer:
             raise FloatingPointError(f"{new} optimiser step(s) had a non-finite gradient norm and were skipped by the Adam kernel "
                                      f"(arithmetic {getattr(self.model, 'conv_math', '?')!r}; asynchronous kernel errors, e.g. GroupNorm poll "
                                      f"timeouts: {ops.L.load().vd_async_errors(0)}; last library error: {ops.L.last_error()!r})")
+        self._recheck = new > 0
         if new > 0:
             self.loss_scale = max(1.0, self.loss_scale * 0.5)
             self.overflow_steps_seen += new
             self._since_growth = 0
             self.opt.step_count = max(0, self.opt.step_count - new)
             self.sched_step = max(0, self.sched_step - new)
-        elif self._scale() != 1.0 and self._since_growth >= self.scale_growth_every:
+        elif count_step and self._scale() != 1.0 and self._since_growth >= self.scale_growth_every:
             self.loss_scale = min(float(2 ** 24), self.loss_scale * 2.0)
             self._since_growth = 0
 
@@ -307,7 +316,7 @@ class Trainer:
 
     def state_dict(self) -> Dict:
         if getattr(self.model, "device", torch.device("cpu")).type == "cuda":
-            self.check_skipped(force=True)            # a checkpoint never records steps the kernel refused
+            self.check_skipped(force=True, count_step=False)      # a checkpoint never records steps the kernel refused
         return {"optimizer": self.opt.state_dict(), "micro": self.micro, "sched_step": self.sched_step,
                 "loss_scale": self.loss_scale, "since_growth": self._since_growth, "overflow_steps_seen": self.overflow_steps_seen}
 

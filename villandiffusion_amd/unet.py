@@ -1105,7 +1105,7 @@ class UNet2DModel(nn.Module):
         import contextlib
         stack = contextlib.ExitStack()
         stack.enter_context(torch.cuda.stream(self._aux_stream))
-        stack.enter_context(ops.ws_slot(15))                    # its own split-K workspace slot
+        stack.enter_context(ops.ws_slot(ops.AUX_WS_SLOT))       # its own split-K workspace slot (never one of the sampler streams')
         return stack
 
     def aux_join(self):
