@@ -7,6 +7,9 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from villandiffusion_amd import lib as _L
+if os.environ.get("G32P_LIB"):                      # a diagnostic / previous-round library for A/B runs (tools/diag/)
+    _L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["G32P_LIB"])
 from villandiffusion_amd import ops
 from villandiffusion_amd.lib import A_COL, B_PLAIN
 
@@ -30,6 +33,7 @@ def timed(fn, n=20):
 
 
 tot = 0.0
+torch.manual_seed(0)                                  # the hash column is comparable across processes / libraries
 for name, cin, cout, S in SHAPES:
     HW = S * S
     x = torch.randn(B, cin, S, S, device=DEV)

@@ -50,11 +50,20 @@ for a, b in zip(adam[:-1], adam[1:]):
         prev = t
         k += d
     conc[k] += t1 - prev
+# the tail: last kernel of the busiest (main) queue before adam -> adam start, and what ran meanwhile
+main_q = max(qbusy, key=qbusy.get)
+tails = []
+for a, b in zip(adam[:-1], adam[1:]):
+    seg = rows[a + 1:b]
+    last_main = max((e for s_, e, n_, q in seg if q == main_q and "adam" not in n_), default=rows[b][0])
+    first_bwd = None
+    tails.append((rows[b][0] - last_main) / 1e3)
+print("tail (last main-queue kernel end -> adam start), us per step:", " ".join(f"{t:.0f}" for t in tails))
 n = len(adam) - 1
 print(f"{n} steps, span {span / n / 1e6:.3f} ms per step")
 print("time with k kernels in flight (ms per step): " + "  ".join(f"{k}: {v / n / 1e6:.3f}" for k, v in sorted(conc.items())))
 for q, v in sorted(qbusy.items(), key=lambda kv: -kv[1]):
     print(f"queue {q}: busy {v / n / 1e6:.3f} ms per step")
     fam = sorted(((k[1], v2) for k, v2 in agg.items() if k[0] == q), key=lambda kv: -kv[1][0])
-    for name, (tt, cnt) in fam[:28]:
+    for name, (tt, cnt) in fam[:int(sys.argv[3]) if len(sys.argv) > 3 else 28]:
         print(f"     {tt / n / 1e3:9.1f} us  {cnt / n:6.1f} x {tt / cnt / 1e3:8.1f} us   {name}")

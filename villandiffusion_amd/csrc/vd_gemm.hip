@@ -1889,7 +1889,16 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ X
     float s = 0.f;
     if ((P & 3) == 0 && ((((uintptr_t)x) & 15) == 0)) {
         const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-        for (int i = lane; i < (P >> 2); i += 64) {
+        const int Q = P >> 2;
+        int i = lane;
+        for (; i + 192 < Q; i += 256) {                             // four independent 16-byte loads in flight per lane (a 32x32 row is exactly one round);
+            const f32x4 v0 = x4[i], v1 = x4[i + 64], v2 = x4[i + 128], v3 = x4[i + 192];      // the additions keep the order of the one-load loop
+            s += (v0[0] + v0[1]) + (v0[2] + v0[3]);
+            s += (v1[0] + v1[1]) + (v1[2] + v1[3]);
+            s += (v2[0] + v2[1]) + (v2[2] + v2[3]);
+            s += (v3[0] + v3[1]) + (v3[2] + v3[3]);
+        }
+        for (; i < Q; i += 64) {
             f32x4 v = x4[i];
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }

@@ -4,8 +4,8 @@
 // The structure of vd_conv_k32p.hip with one tap and no halo: a workgroup of eight 64 x 64 waves owns 128 output channels x 256 consecutive
 // pixels, one workgroup per CU walks the tiles of its XCD's range, a stage is ONE chunk pair (32 input channels):
 //     As[buf][c2][part][q][128 m]   16 KB x 2   the packed weights, global -> LDS by LDS-DMA (lane-linear image: a straight copy of 8 runs of 2 KB)
-//     Ps[buf][c2][part][q][256 px]  32 KB x 2   the activations, split into bf16 (hi, lo) where they are written (8 pixel-coalesced dword loads per
-//                                               k-octet item, as the convolution's patch loader)
+//     Ps[buf][c2][part][q][272 u]   34 KB x 2   the activations, split into bf16 (hi, lo) where they are written (round 6: one 16-byte load per channel and
+//                                               pixel quad; a plane is four slices of 68 units, pixel n at (n & 3) * 68 + (n >> 2))
 // Both images are double-buffered, so a stage costs ONE barrier: the DMA of stage s+1 and the global loads of the activations of stage s+2 (two
 // register sets) are issued before the 48 MFMAs of stage s, the conversion + LDS write of stage s+1's activations after them, then the counted
 // wait for the DMA and the barrier.  Fragment
@@ -63,8 +63,15 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     constexpr int NPART = F16 ? 1 : 2;
     constexpr int A_UNITS = 2 * NPART * 2 * BM;                   // 1024 units = 16 KB per stage: [c2][part][q][m] (f16: 8 KB; BM = 256: 32 KB)
     constexpr int A_IT = A_UNITS / NTH;                           // 2 (1; BM = 256: 4)
-    constexpr int P_UNITS = 4 * NPART * NPIX;                     // 2048 units = 32 KB per stage: [c2][part][q][pixel] (f16: 16 KB; BM = 256: 16 KB)
-    constexpr int P_IT = 4 * NPIX / NTH;                          // (k-octet, pixel) items per thread: 4 octets x NPIX pixels / 512 threads = 2 | 1
+    // activations (round 6): a thread loads CH_T channels x 4 CONSECUTIVE pixels (one 16-byte load per channel: 1 KB per wave instruction instead of the
+    // 256 B of round 5's dword loads -- the CU's vector-memory address path takes one wave instruction per ~16-25 cycles whatever its width, and 128 of them per
+    // 1536-cycle stage made the loop issue-bound) and writes its CH_T-channel slice of the four pixels' units.  A plane keeps pixel n at unit
+    // (n & 3) * PS4 + (n >> 2): the four pixels of a thread go to four slices PS4 = NPIX / 4 + 4 units apart, so a write instruction covers consecutive
+    // units and a fragment read (16 consecutive pixels) four 64-byte runs on disjoint banks (272 | 144 dwords apart).
+    constexpr int CH_T = NPIX == 256 ? 4 : 2;                     // 4 octets x (8 / CH_T) channel groups x NPIX / 4 pixel quads = 512 threads
+    constexpr int PS4 = NPIX / 4 + 4;
+    constexpr int PL = 4 * PS4;                                   // units per plane
+    constexpr int P_UNITS = 4 * NPART * PL;                       // [c2][part][q][plane]: 34 KB per stage (BM = 256: 18 KB)
     __shared__ u32x4 lds[2 * A_UNITS + 2 * P_UNITS];              // ONE LDS object (see vd_conv_k32p.hip)
     u32x4* const As = lds;
     u32x4* const Ps = lds + 2 * A_UNITS;
@@ -97,64 +104,68 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, dst, 16, aoff[i], so, 0, 0);
         }
     };
-    // activations: item (cq = wave >> 1, pixel (tid & 127) + 128 i): channels cp * 32 + cq * 8 + j, j = 0..7
+    // activations: thread = (octet cq = wave >> 1, channel group sub, pixel quad): channels cp * 32 + cq * 8 + sub * CH_T + k, pixels n0 + 4 quad + {0..3}
     const int cq = wave >> 1;
-    unsigned poff[P_IT];
-    int pdst[P_IT];
-#pragma unroll
-    for (int i = 0; i < P_IT; ++i) pdst[i] = ((cq >> 1) * 2 * NPART + (cq & 1)) * NPIX + (tid & 127) + 128 * i;   // plane (c2, part 0, q); lo: + 2 planes
+    const int quad = tid % (NPIX / 4), sub = (tid / (NPIX / 4)) % (8 / CH_T);
+    unsigned poff;
+    const int pdst = ((cq >> 1) * 2 * NPART + (cq & 1)) * PL + quad;          // plane (c2, part 0, q), slice 0; the lo plane: + 2 planes; pixel pp: + pp * PS4
     auto set_tile_px = [&](int n0_) {
-#pragma unroll
-        for (int i = 0; i < P_IT; ++i) {
-            const int n = n0_ + (tid & 127) + 128 * i;
-            const int b = n / d.NP, p = n - b * d.NP;
-            poff[i] = 4u * (unsigned)((int64_t)b * d.b_bstride + p) + (unsigned)(cq * 8) * ldb4;
-        }
+        const int n = n0_ + 4 * quad;                             // NP % 4 == 0: a quad never straddles images
+        const int b = n / d.NP, p = n - b * d.NP;
+        poff = 4u * (unsigned)((int64_t)b * d.b_bstride + p) + (unsigned)(cq * 8 + sub * CH_T) * ldb4;
     };
     // Two register sets: the loads of stage s + 2 are issued at the start of stage s and converted at the end of stage s + 1 (two stages of MFMAs,
     // ~1.6 us, between a load and its use: a single stage does not cover an HBM round trip under load -- measured 2.4 us per 0.8-us stage).
-    float rp[2][P_IT][8];
+    f32x4 rp[2][CH_T];
     // The activation loads are inline asm with hand-counted waits: hipcc's own counter model waits vmcnt(0) where a register set loaded a stage
-    // earlier is consumed (it does not see that 18 younger operations may stay in flight), which would drain the next stage's loads every stage
-    // (cdna_hip_programming.md §5.7 item 1).  wait_p ties the wait to the 16 destination registers so that no use can be scheduled above it.
+    // earlier is consumed (it does not see that younger operations may stay in flight), which would drain the next stage's loads every stage
+    // (cdna_hip_programming.md §5.7 item 1).  wait_p ties the wait to the destination registers so that no use can be scheduled above it.
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const uint64_t xaddr = reinterpret_cast<uint64_t>(d.B);
     const i32x4 xdesc = {(int)(uint32_t)xaddr, (int)(uint32_t)((xaddr >> 32) & 0xFFFF), (int)0xFFFFFFF0, 0x00020000};   // raw buffer over the whole tensor, no stride
-    auto load_p = [&](int cp, float (&r)[P_IT][8]) {
+    auto load_p = [&](int cp, f32x4 (&r)[CH_T]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned so = (unsigned)(cp * 32 + j) * ldb4;                                 // wave-uniform
-#pragma unroll
-            for (int i = 0; i < P_IT; ++i)
-                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(r[i][j]) : "v"(poff[i]), "s"(xdesc), "s"(so) : "memory");
+        for (int k = 0; k < CH_T; ++k) {
+            const unsigned so = (unsigned)(cp * 32 + k) * ldb4;                                 // wave-uniform
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(r[k]) : "v"(poff), "s"(xdesc), "s"(so) : "memory");
         }
     };
-    auto wait_p = [&](float (&r)[P_IT][8], auto LEFT) {          // all but the LEFT youngest vector-memory operations have completed
+    auto wait_p = [&](f32x4 (&r)[CH_T], auto LEFT) {             // all but the LEFT youngest vector-memory operations have completed
         constexpr int left = decltype(LEFT)::value;
-        if constexpr (P_IT == 2) {
-            asm volatile("s_waitcnt vmcnt(%16)"
-                         : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7]),
-                           "+v"(r[P_IT - 1][0]), "+v"(r[P_IT - 1][1]), "+v"(r[P_IT - 1][2]), "+v"(r[P_IT - 1][3]), "+v"(r[P_IT - 1][4]), "+v"(r[P_IT - 1][5]),
-                           "+v"(r[P_IT - 1][6]), "+v"(r[P_IT - 1][7])
-                         : "n"(left)
-                         : "memory");
+        if constexpr (CH_T == 4) {
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[CH_T - 1]) : "n"(left) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(%8)"
-                         : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7])
-                         : "n"(left)
-                         : "memory");
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[CH_T - 1]) : "n"(left) : "memory");
         }
     };
-    auto write_p = [&](int buf, const float (&r)[P_IT][8]) {
+    auto write_p = [&](int buf, const f32x4 (&r)[CH_T]) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16xc __attribute__((ext_vector_type(CH_T)));
+        typedef _Float16 f16xc __attribute__((ext_vector_type(CH_T)));
+        char* const base = reinterpret_cast<char*>(Ps + buf * P_UNITS + pdst) + sub * CH_T * 2;
 #pragma unroll
-        for (int i = 0; i < P_IT; ++i) {
+        for (int pp = 0; pp < 4; ++pp) {
             if constexpr (F16) {
-                Ps[buf * P_UNITS + pdst[i]] = to_f16x8(r[i]);
+                f16xc h;
+#pragma unroll
+                for (int k = 0; k < CH_T; ++k) h[k] = (_Float16)r[k][pp];
+                if constexpr (CH_T == 4) *reinterpret_cast<u32x2*>(base + pp * PS4 * 16) = __builtin_bit_cast(u32x2, h);
+                else *reinterpret_cast<unsigned*>(base + pp * PS4 * 16) = __builtin_bit_cast(unsigned, h);
             } else {
-                u32x4 hi, lo;
-                split8(r[i], hi, lo);
-                Ps[buf * P_UNITS + pdst[i]] = hi;
-                Ps[buf * P_UNITS + pdst[i] + 2 * NPIX] = lo;
+                bf16xc h, l;
+#pragma unroll
+                for (int k = 0; k < CH_T; ++k) {
+                    const __bf16 t = (__bf16)r[k][pp];
+                    h[k] = t;
+                    l[k] = (__bf16)(r[k][pp] - (float)t);
+                }
+                if constexpr (CH_T == 4) {
+                    *reinterpret_cast<u32x2*>(base + pp * PS4 * 16) = __builtin_bit_cast(u32x2, h);
+                    *reinterpret_cast<u32x2*>(base + (pp * PS4 + 2 * PL) * 16) = __builtin_bit_cast(u32x2, l);
+                } else {
+                    *reinterpret_cast<unsigned*>(base + pp * PS4 * 16) = __builtin_bit_cast(unsigned, h);
+                    *reinterpret_cast<unsigned*>(base + (pp * PS4 + 2 * PL) * 16) = __builtin_bit_cast(unsigned, l);
+                }
             }
         }
     };
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     const int wm = wave / WN, wn = wave % WN;
     const int c2 = g >> 1, q = g & 1;
     const u32x4* __restrict__ a_base = As + (c2 * 2 * NPART + q) * BM + wm * 64 + l15;
-    const u32x4* __restrict__ p_base = Ps + (c2 * 2 * NPART + q) * NPIX + wn * 64 + l15;
+    const u32x4* __restrict__ p_base = Ps + (c2 * 2 * NPART + q) * PL + (l15 & 3) * PS4 + wn * 16 + (l15 >> 2);      // pixel wn * 64 + ni * 16 + l15: + ni * 4
 
     // 48 MFMAs of one stage; the next pixel tile's fragments are read before the current tile's 12 MFMAs (see vd_conv_k32p.hip mfma_row_pipe)
     auto mfma_stage = [&](int buf) {
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
             for (int ni = 0; ni < 4; ++ni) {
                 const int cur = ni & 1, nxt = cur ^ 1;
                 if (ni < 3) {
-                    xh[nxt] = __builtin_bit_cast(f16x8, p_cur[(ni + 1) * 16]);
+                    xh[nxt] = __builtin_bit_cast(f16x8, p_cur[(ni + 1) * 4]);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
 #pragma unroll
@@ -196,14 +207,14 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
             wl[mi] = __builtin_bit_cast(bf16x8, a_cur[2 * BM + mi * 16]);
         }
         xh[0] = __builtin_bit_cast(bf16x8, p_cur[0]);
-        xl[0] = __builtin_bit_cast(bf16x8, p_cur[2 * NPIX]);
+        xl[0] = __builtin_bit_cast(bf16x8, p_cur[2 * PL]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int cur = ni & 1, nxt = cur ^ 1;
             if (ni < 3) {
-                xh[nxt] = __builtin_bit_cast(bf16x8, p_cur[(ni + 1) * 16]);
-                xl[nxt] = __builtin_bit_cast(bf16x8, p_cur[2 * NPIX + (ni + 1) * 16]);
+                xh[nxt] = __builtin_bit_cast(bf16x8, p_cur[(ni + 1) * 4]);
+                xl[nxt] = __builtin_bit_cast(bf16x8, p_cur[2 * PL + (ni + 1) * 4]);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
 #pragma unroll
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     // Stage s of a tile (nst is even, so s & 1 is also the parity of the global stage count):
     //   invariant at its start: As[s & 1] / Ps[s & 1] hold stage s; rp[(s + 1) & 1] holds the in-flight loads of stage s + 1
     //   DMA A(s + 1) -> As[(s + 1) & 1];  loads X(s + 2) -> rp[s & 1];  48 MFMAs;  convert rp[(s + 1) & 1] -> Ps[(s + 1) & 1];
-    //   wait for the DMA (the 16 younger activation loads stay in flight across the barrier);  barrier
+    //   wait for the DMA (the CH_T younger activation loads stay in flight across the barrier);  barrier
     // "s + 1" / "s + 2" run into the next tile of this workgroup at a tile's end (its m-tile for the weights, its pixels for the activations).
     auto stage = [&](int cp, auto PAR, int m0_, int m0n_, int n0n_, bool has_next_) {
         constexpr int par = decltype(PAR)::value;
@@ -283,14 +294,14 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
             else dma_a(m0n_, 0, par ^ 1);
         }
         if (e2 && cp + 2 == nst) set_tile_px(n0n_);              // this tile's activation loads are all issued: switch to the next tile's pixels
-        // ALWAYS 16 loads per stage (past the end of the work: the last stage's again, never used): the hand-counted wait below is then the same
+        // ALWAYS CH_T loads per stage (past the end of the work: the last stage's again, never used): the hand-counted wait below is then the same
         // instruction on every path -- two asm statements on two branches would make hipcc merge their register operands with copies it may
         // place in front of the wait, i.e. copies of registers whose loads are still in flight
         load_p(e2 ? (cp + 2 < nst ? cp + 2 : cp + 2 - nst) : nst - 1, rp[par]);
         __builtin_amdgcn_sched_barrier(0);
         mfma_stage(par);
         // stage s + 1's activations (loaded a stage ago) and its DMA (issued before this stage's 16 loads) have landed
-        wait_p(rp[par ^ 1], std::integral_constant<int, 8 * P_IT>{});
+        wait_p(rp[par ^ 1], std::integral_constant<int, CH_T>{});
         if (e1) write_p(par ^ 1, rp[par ^ 1]);
         // this wave's LDS writes are done.  Raw s_barrier: __syncthreads() would drain the vector-memory queue (vmcnt(0)) and with it the
         // two-stage lead of the activation loads.
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     dma_a(m0, 0, 0);
     load_p(0, rp[0]);
     load_p(1, rp[1]);                                              // (nst >= 2: K % 64 == 0)
-    wait_p(rp[0], std::integral_constant<int, 8 * P_IT>{});
+    wait_p(rp[0], std::integral_constant<int, CH_T>{});
     write_p(0, rp[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -343,6 +354,7 @@ bool vd_gemm1x1_k32p_pick(const vd_gemm_desc& d) {
     if (d.K % 64 != 0 || d.N % 256 != 0 || d.NP % 4 != 0 || d.M < 64 || d.a_packed_mpad < d.M || (d.a_packed_mpad & 127)) return false;
     if (d.bias_on_n || d.d_trans || d.nb2 > 1 || d.a_bstride != 0 || d.rowadd || d.gn_ss || d.gn_part || d.debug || d.tile || d.act || d.pool2) return false;
     if ((d.ldd & 3) || (d.d_bstride & 3) || (((uintptr_t)d.D) & 15) || (((uintptr_t)d.a_packed) & 15)) return false;
+    if ((d.ldb & 3) || (d.b_bstride & 3) || (((uintptr_t)d.B) & 15)) return false;      // 16-byte activation loads (four consecutive pixels of a channel)
     if (d.residual && ((d.res_bstride & 3) || (((uintptr_t)d.residual) & 15))) return false;
     const int64_t nb = d.N / d.NP;
     if (nb * d.b_bstride * 4 >= (1ll << 32) || (int64_t)d.K * d.ldb * 4 >= (1ll << 32)) return false;      // 32-bit buffer offsets
