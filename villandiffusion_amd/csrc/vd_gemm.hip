@@ -21,6 +21,9 @@ bool vd_conv3_k32p_eligible(const vd_gemm_desc& d);
 int vd_launch_conv3_k32p(const vd_gemm_desc& d, int mode, hipStream_t st);
 // vd_presplit.hip: the grouped 3x3 weight gradient with both operands pre-split (LDS-DMA + transposed reads)
 int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int up, int blocks, hipStream_t st);
+// vd_conv_sm.hip: the whole-K 16x16x32 split-precision 3x3 convolution of the 8x8 / 4x4 levels (round 6)
+bool vd_conv3_sm_eligible(const vd_gemm_desc& d);
+int vd_launch_conv3_sm(const vd_gemm_desc& d, hipStream_t st);
 // vd_gemm_k32p.hip: the persistent 16x16x32 split-precision 1x1 convolution / plain product
 bool vd_gemm1x1_k32p_pick(const vd_gemm_desc& d);
 int vd_launch_gemm1x1_k32p(const vd_gemm_desc& d, hipStream_t st);
@@ -2139,6 +2142,7 @@ extern "C" int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc) {
     }
     if (desc && desc->a_packed) {
         if (!bx3_eligible(*desc)) return 0;
+        if (vd_conv3_sm_eligible(*desc)) return 0;               // whole K per workgroup: no slabs
         int splits, c_per;
         bx3_plan(*desc, splits, c_per);
         return splits > 1 ? (int64_t)splits * desc->M * desc->N : 0;
@@ -2162,6 +2166,7 @@ extern "C" int vd_gemm_tile(const vd_gemm_desc* desc) {
             int splits, c_per;
             bx3_plan(d, splits, c_per);
             static const int big_off = getenv("VD_BX3_BIG_OFF") ? atoi(getenv("VD_BX3_BIG_OFF")) : 0;
+            if (vd_conv3_sm_eligible(d)) return 20;                    // 20: conv3_sm_kernel (8x8 / 4x4 levels: 64-channel x 2 | 4-image tiles, whole K, no split)
             if (bx3_big_split(d)) return 16;                           // 16: 8x8 layers, 128 x 256 tiles with the channel loop split
             if (k32p_pick(d)) return 18;                               // 18: conv3_k32p_kernel (persistent 16x16x32 kernel, any image of 8 x 32 segments)
             const int big = (big_off || d.b_mode == VD_B_CONV3_S2) ? 0 : bx3_big_tile(d, splits);
@@ -2244,6 +2249,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* desc, void* stream) {
         case 7: rc = launch_smallm(d, st); break;
         case 8: case 12: case 15: case 16: case 17: case 18: rc = launch_bx3(d, st); break;
         case 19: rc = vd_launch_gemm1x1_k32p(d, st) == 0 ? 0 : VD_EINVAL; break;
+        case 20: rc = vd_launch_conv3_sm(d, st) == 0 ? 0 : VD_EINVAL; break;
         case 10: launch_gemm_bx3_act(d, st); rc = 0; break;
         case 13:
             hipLaunchKernelGGL(gemm_bx3_kernel<512>, dim3(vd_cdiv(d.M, 128) * (d.N / 256)), dim3(512), 0, st, d, 1 << 30);

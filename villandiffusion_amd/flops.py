@@ -52,7 +52,7 @@ def unet_forward_flops(net, breakdown: bool = False):
 # ---- which matrix pipe a kernel symbol runs on (bench.py prices a kernel against the dense peak of the arithmetic it executes) ----
 # Split-precision kernels: every algorithmic product term is three bf16 MFMAs (hi*hi + hi*lo + lo*hi) -> 2500 TFLOP/s dense bf16 peak on
 # ALGORITHMIC FLOPs, x3 for the executed fraction.  Everything else that `ops` records with kind "mfma" runs on v_mfma_f32_32x32x2_f32 (157.3).
-SPLIT_PRECISION_FAMILIES = ("bx3", "attn_core", "attn_flash", "k32", "wgrad9", "wgrad1x1_wide", "wgrad_ps", "presplit")
+SPLIT_PRECISION_FAMILIES = ("bx3", "attn_core", "attn_flash", "k32", "wgrad9", "wgrad1x1_wide", "wgrad_ps", "presplit", "conv3_sm")
 EXACT_F32_FAMILIES = ("gemm_kernel<", "gemm_plain_kernel", "conv3_patch_kernel", "wgrad_patch_kernel", "wgrad_patch_gen_kernel", "wgrad_kernel<",
                       "wgrad_small_kernel", "conv3_fewout_kernel", "conv3_smallm_kernel", "attn_small")
 
