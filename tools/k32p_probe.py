@@ -26,6 +26,9 @@ from villandiffusion_amd.lib import B_CONV3, B_CONV3_T  # noqa: E402
 B = int(os.environ.get("K32P_B", "128"))
 STAMPS = "--stamps" in sys.argv
 CHECK = "--check" in sys.argv
+F32IN = "--f32" in sys.argv                 # f32 NCHW input (the converting loader) instead of the pre-split image; modes 0, 1 and 3 (GroupNorm folded)
+import hashlib  # noqa: E402
+torch.manual_seed(0)
 SHAPES = [(128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16)]
 flags = int(os.environ.get("VD_K32P_FLAGS", "0"))
 print(f"# lib {os.path.basename(L.LIB_PATH)}  VD_K32P_FLAGS={flags}  B={B}")
@@ -33,7 +36,10 @@ stamps = torch.zeros(256 * 32 + 256 * 8 * 8, dtype=torch.int64, device="cuda")
 SEG = ["issue", "mfma", "switch", "vmwait", "barrier", "epilogue"]
 tot_us = 0.0
 for cin, cout, H in SHAPES:
-    for mode in (B_CONV3, B_CONV3_T):
+    for mode in ((B_CONV3, B_CONV3_T, "gn") if F32IN else (B_CONV3, B_CONV3_T)):
+        gn = mode == "gn"
+        if gn:
+            mode = B_CONV3
         x = torch.randn(B, cin, H, H, device="cuda")
         w = torch.randn(cout, cin * 9, device="cuda") / math.sqrt(cin * 9)
         if os.environ.get("K32P_ZERO"):                     # DVFS check: all-zero activations (1) / also all-zero weights (2)
@@ -42,23 +48,30 @@ for cin, cout, H in SHAPES:
                 w.zero_()
         out = torch.empty(B, cout, H, H, device="cuda")
         pk = ops.conv3_pack_weights(w, cout, cin, transposed=False)
-        xp = ops.presplit_pack(x)
+        xp = x if F32IN else ops.presplit_pack(x)
+        ss = None
+        if gn:
+            ss = torch.empty(B, cin, 2, device="cuda")
+            ops.groupnorm_stats(x, torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1, ss, torch.empty(B * 32, device="cuda"),
+                                torch.empty(B * 32, device="cuda"), 32, 1e-6)
+        _conv = ops.conv3x3
+        ops_conv3x3 = (lambda a_, w_, b_, o_, mode, a_packed: _conv(a_, w_, b_, o_, mode=mode, a_packed=a_packed, gn_ss=ss))
         for _ in range(10):
-            ops.conv3x3(xp, w, None, out, mode=mode, a_packed=pk)
+            ops_conv3x3(xp, w, None, out, mode=mode, a_packed=pk)
         assert ops.LAST_GEMM_TILE == 18
         torch.cuda.synchronize()
         n = 40
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
-            ops.conv3x3(xp, w, None, out, mode=mode, a_packed=pk)
+            ops_conv3x3(xp, w, None, out, mode=mode, a_packed=pk)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
         tot_us += us
         gf = 2.0 * cout * cin * 9 * B * H * H / 1e9
-        line = f"{cin:4d}->{cout:3d} @{H:2d} mode {mode}: {us:7.1f} us  {3e3 * gf / us:6.0f} TF/s executed"
-        if CHECK:
+        line = f"{cin:4d}->{cout:3d} @{H:2d} mode {'2+gn' if gn else mode}: {us:7.1f} us  {3e3 * gf / us:6.0f} TF/s executed  sha1 {hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:10]}"
+        if CHECK and not F32IN:
             ref = torch.empty_like(out)
             ops.conv3x3(x, w, None, ref, mode=mode, a_packed=pk)
             torch.cuda.synchronize()
