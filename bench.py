@@ -355,11 +355,12 @@ def bench_secondary_config(args):
             mf = [k for k in kernels if k["mfma_peak"]]
             k0 = mf[0]
             sp = is_split(k0["kernel"])
-            # HBM bytes per launch of the dominant kernel from this configuration's committed PMC passes (tools/collect_profiles_r05.sh:
+            # HBM bytes per launch of the dominant kernel from this configuration's committed PMC passes (tools/collect_profiles_r06.sh:
             # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this same command; rocprofv3 cannot run inside this process)
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{'cfg4' if args.config == 'celebahq256' else 'cfg5'}.json")
-            if os.path.exists(pmc):
+            tag = 'cfg4' if args.config == 'celebahq256' else 'cfg5'
+            pmc = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_{tag}.json") for r in (6, 5)) if os.path.exists(f)), "")
+            if pmc:
                 with open(pmc) as f:
                     traffic = json.load(f)["kernels"].get(k0["kernel"].split("(+")[0].split("@")[0], {}).get("traffic_bytes_per_launch")
                 traffic_src = os.path.relpath(pmc, ROOT) if traffic else None
@@ -374,7 +375,7 @@ def bench_secondary_config(args):
             out["profiled_kernels_ms"] = round(sum(k["ms"] for k in kernels), 2)
             for k in kernels[:14]:
                 log(f"{k['ms']:8.3f} ms {k['launches']:4d}x {k['avg_us']:8.1f} us  {k['tflops']:7.1f} TF {k['bound']:4s} frac {k['frac']:.3f}  {k['kernel']}")
-            path = os.environ.get("VD_BENCH_DETAIL")       # full per-kernel table (tools/update_profiles_r05.py joins it with the PMC passes)
+            path = os.environ.get("VD_BENCH_DETAIL")       # full per-kernel table (tools/update_profiles_r06.py joins it with the PMC passes)
             if path:
                 with open(path, "w") as f:
                     json.dump(dict(out, train_step_kernels=kernels), f)
@@ -732,7 +733,7 @@ def main():
         net.sampler_graph = g0
         if rank == 0:
             sample_kernels = summarise(rec_s)
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
 
     def traffic_of(kname):      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:

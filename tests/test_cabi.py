@@ -87,7 +87,10 @@ def test_split_precision_planner_agrees_with_the_python_side_eligibility():
                     d.lda, d.b_bstride, d.ldd, d.d_bstride, d.alpha = Cc * 9, Cc * H * H, OH * OW, M * OH * OW, 1.0
                     want = ops.bx3_eligible(M, Cc, OH, OW, mode)
                     got = h.vd_gemm_tile(C.byref(d))
-                    assert (got in (8, 12, 15, 16, 17, 18)) == want and got in (8, 12, 15, 16, 17, 18, -1), (mode, OW, M, Cc, nb, got, want)      # 17 / 18: the 16x16x32-MFMA kernels
+                    # 17 / 18: the 16x16x32-MFMA kernels; 20: the whole-K kernel of the 8x8 / 4x4 levels (round 6)
+                    assert (got in (8, 12, 15, 16, 17, 18, 20)) == want and got in (8, 12, 15, 16, 17, 18, 20, -1), (mode, OW, M, Cc, nb, got, want)
+                    if got == 20:                                     # no split-K slabs; only the stride-1 kinds at 8x8 / 4x4 on grids that fill the chip
+                        assert h.vd_gemm_ws_floats(C.byref(d)) == 0 and OW in (4, 8) and mode in (B_CONV3, B_CONV3_T) and Cc % 32 == 0, (mode, OW, M, Cc, nb)
                     if mode == B_CONV3_T and ops.bx3_pool2_eligible(M, Cc, OH, OW, nb):      # pool2 needs the unsplit grid
                         assert got in (8, 12, 15, 17, 18) and h.vd_gemm_ws_floats(C.byref(d)) == 0, (OW, M, Cc, nb)
                     if mode in (B_CONV3, B_CONV3_UP):
