@@ -88,9 +88,10 @@ def cpu_baseline(batch: int = 128, n_steps: int = 3, state_dict=None, gpu_side=N
     from oracle.loss_ref import LossFnRef, SDE_VP
     from oracle.schedulers_ref import DDPMSchedulerRef, sample_loop
     from oracle.unet_ref import UNet2DModelRef
-    # cores this process may run on, capped at 32: on the 256-thread GPU host oneDNN gets SLOWER beyond ~32 threads for
-    # these 32x32 convolutions (measured: 8 thr 0.28 s, 32 thr 0.39 s, 64 thr 0.79 s per B=8 fwd+bwd)
-    ncpu = min(len(os.sched_getaffinity(0)), 32)
+    # cores this process may run on, capped at 16: on the 256-thread GPU host oneDNN gets SLOWER with more threads for these 32x32
+    # convolutions -- the B = 128 oracle step takes 6.0 s on 16 threads, 6.9 s on 32, 11.0 s on 64, 21 s on 128 and more than 15 minutes on
+    # 256 (profiles/r06_cpu_threads.txt, tools/cpu_thread_sweep.py); the line states the count it used (`cores`)
+    ncpu = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(max(1, ncpu))
     torch.manual_seed(0)
     net = UNet2DModelRef()
