@@ -144,7 +144,10 @@ int64_t vd_gemm_ws_floats(const vd_gemm_desc* desc);
  * channels, 8 / 9 / 10: split-precision bf16 3x3 convolution / plain product (a_packed) / activation product (math = 1), 11: the persistent
  * variant of 9 (grids of >= 1024 tiles), 12 / 15 / 16: the 128 x 256 / 128 x 512 / split 128 x 256 tiles of 8, 13: the 128 x 256 tile of 9,
  * 17: the 16x16x32-MFMA 3x3 convolution (32-channel K-steps, 128 x 256 tile), 18: its persistent variant (LDS-DMA weight stages, 8 x 32 pixel
- * segments of images of any size), 19: the persistent 16x16x32 kernel for 9's problems, -1: a_packed given for an unsupported problem (profiling / tests). */
+ * segments of images of any size), 19: the persistent 16x16x32 kernel for 9's problems, 20 (round 6): the whole-K 16x16x32 kernel of the 8x8 level
+ * (and of 4x4 grids that fill the chip): 64 channels x 2 | 4 whole images per workgroup, no split-K workspace, f32 input, VD_B_CONV3 / VD_B_CONV3_T,
+ * bias / rowadd / residual / accumulate; its sums run over all channels in one chain, so it agrees with the split kernels (8 / 16) to the path's
+ * tolerance, not bit for bit, -1: a_packed given for an unsupported problem (profiling / tests). */
 int vd_gemm_tile(const vd_gemm_desc* desc);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (K2/K5/K6/K7 backward, deterministic split-K):
