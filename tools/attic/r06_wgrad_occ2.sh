@@ -1,0 +1,14 @@
+#!/bin/bash
+O=gpurun_out/r06
+mkdir -p $O
+rm -f $O/wgrad_occ2_ab.txt
+run() {
+  env "$@" python bench.py --mode train --no-cpu --no-exact --no-f16 --no-roofline --no-ddp-path --steps 40 --warmup 10 2>$O/wgrad_occ_err.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['value'], d['ms_per_step'])" >> $O/wgrad_occ2_ab.txt
+}
+for rep in 1 2 3 4; do
+run VD_WGRAD_PS_LDS_PAD=0
+run VD_WGRAD_PS_LDS_PAD=12288
+done
+cat $O/wgrad_occ2_ab.txt
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
+python bench.py --mode sample --no-cpu --no-f16 --no-roofline --no-secondary 2>/dev/null | tail -1 | cut -c1-400

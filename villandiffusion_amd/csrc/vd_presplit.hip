@@ -728,10 +728,16 @@ extern "C" int vd_groupnorm_bwd_presplit(const float* dy, const float* x, const 
 // vd_gemm.hip's grouped launch (class 3000 + 4 W + 2 * upsample-fused): both operands pre-split
 int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int up, int blocks, hipStream_t st) {
     const vd_wgrad_job* jb = reinterpret_cast<const vd_wgrad_job*>(jobs);
+    // 12 KB of (unused) dynamic LDS on top of the kernel's 76 KB: ONE workgroup per CU instead of two.  Two of them hold a CU's whole LDS and register
+    // file for ~90 us at a time, and the backward pass on the main stream -- latency-bound 8x8 / 4x4 kernels, GroupNorm passes -- only gets a CU when
+    // one retires; with one per CU every CU keeps half its registers and 72 KB of LDS for the main stream's workgroups all the time.  The weight
+    // gradients themselves lose nothing measurable (they are power-bound beside the convolutions).  Same box, interleaved, four rounds:
+    // 16.56 against 16.69 ms per training step (profiles/r06_wgrad_occupancy_ab.txt).  VD_WGRAD_PS_LDS_PAD=0: two per CU.
+    static const int pad = getenv("VD_WGRAD_PS_LDS_PAD") ? atoi(getenv("VD_WGRAD_PS_LDS_PAD")) : 12288;
 #define VD_WG_PS(WW)                                                                                                \
     case WW:                                                                                                        \
-        if (up) hipLaunchKernelGGL((wgrad_ps_group_kernel<WW, 2>), dim3(blocks), dim3(256), 0, st, jb, n);          \
-        else hipLaunchKernelGGL((wgrad_ps_group_kernel<WW, 0>), dim3(blocks), dim3(256), 0, st, jb, n);             \
+        if (up) hipLaunchKernelGGL((wgrad_ps_group_kernel<WW, 2>), dim3(blocks), dim3(256), pad, st, jb, n);        \
+        else hipLaunchKernelGGL((wgrad_ps_group_kernel<WW, 0>), dim3(blocks), dim3(256), pad, st, jb, n);           \
         return 0;
     switch (W) {
         VD_WG_PS(32) VD_WG_PS(16) VD_WG_PS(8)

@@ -370,7 +370,11 @@ class _Resnet:
         B, _, H, W = x.shape
         dev = x.device
         fuse = net.fuse_gn_inference if net.fuse_gn_inference is not None else _split(net)
-        if not save and fuse and ops.gn_fusable(x, self.cout) and self.cin * H * W // net.groups <= 12288 \
+        # no-grad forward: the folded loader normalises + splits every activation once per 128-channel tile of the OUTPUT; from two tiles on, the
+        # pre-split producer (one pass, one split) + the copying loader are cheaper (profiles/r06_sampler_presplit_ab.txt: +0.9 % sampler throughput
+        # with the 16x16 level's 256-channel blocks on this path; the 128-channel 32x32 blocks lose 1.4 % on it and stay folded)
+        ps_ng = not save and net.nograd_presplit and self.cout > 128 and self.ps_plan(B, H, W)
+        if not save and not ps_ng and fuse and ops.gn_fusable(x, self.cout) and self.cin * H * W // net.groups <= 12288 \
                 and self.cout * H * W // net.groups <= 12288:
             # inference: GroupNorm + SiLU folded into the convolutions' patch loaders -- a statistics pass (one read) replaces the
             # normalise pass (read + write) and the normalised activations never reach HBM
@@ -442,7 +446,7 @@ class _Resnet:
             else:
                 self.conv2.fwd(h1, out, residual=x, gn_ss=ss2)
             return (x, None, m1, r1, h1, None, m2, r2)
-        ps = save and self.ps_plan(B, H, W)
+        ps = (save and self.ps_plan(B, H, W)) or ps_ng
         # The shortcut (a 1x1 convolution of x, HBM-bound) does not depend on the norm1 -> conv1 -> norm2 chain: with net.sc_stream it runs on an
         # auxiliary stream beside those kernels and is joined before conv2 adds it as the residual
         sc_aux = self.has_sc and save and net.aux_fork()
@@ -935,6 +939,7 @@ class UNet2DModel(nn.Module):
         # round 5: GroupNorm forward / backward write PRE-SPLIT bf16 (hi, lo) images for the 3x3 convolutions and their weight gradients
         # (csrc/vd_presplit.hip; _Resnet.ps_plan decides per block); VILLAN_PRESPLIT=0: round 4's converting kernels
         self.presplit = os.environ.get("VILLAN_PRESPLIT", "1") != "0"
+        self.nograd_presplit = os.environ.get("VILLAN_NOGRAD_PRESPLIT", "1") != "0"
         # round 5: the 1x1 shortcut of a ResnetBlock (forward) and its input gradient (backward) on an auxiliary stream beside the block's 3x3
         # chain (VILLAN_SC_STREAM=0: in line)
         self.sc_stream = os.environ.get("VILLAN_SC_STREAM", "1") != "0"
