@@ -47,6 +47,9 @@ struct g32p_args {
     vd_gemm_desc d;
     int n_tiles;
     int tiles_m;
+#ifdef VD_G32P_VARIANTS
+    int flags;                    // diagnostic build (tools/build_k32p_diag.sh) only: timing-only ablations, VD_G32P_FLAGS
+#endif
 };
 
 // F16 (vd_gemm_desc.math = 2, opt-in mixed precision): single f16 planes for both operands (packed weights: vd_conv3_pack_weights_f16_multi), one
@@ -78,6 +81,11 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef VD_G32P_VARIANTS    // timing-only ablations (WRONG results): 2 no epilogue stores, 4 no activation loads, 8 no weight DMA, 16 no MFMAs, 32 no split + LDS write
+    const bool fl_nostore = a.flags & 2, fl_noload = a.flags & 4, fl_nodma = a.flags & 8, fl_nomfma = a.flags & 16, fl_nowrite = a.flags & 32;
+#else
+    constexpr bool fl_nostore = false, fl_noload = false, fl_nodma = false, fl_nomfma = false, fl_nowrite = false;
+#endif
 
     const int G8 = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -97,6 +105,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) aoff[i] = 16u * (unsigned)(((tid + i * NTH) / BM) * Mpad + ((tid + i * NTH) % BM));
     auto dma_a = [&](int m0_, int cp, int buf) {
+        if (fl_nodma) return;
         const unsigned so = 16u * (unsigned)(cp * 4 * NPART * Mpad + m0_);                    // wave-uniform
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
     const uint64_t xaddr = reinterpret_cast<uint64_t>(d.B);
     const i32x4 xdesc = {(int)(uint32_t)xaddr, (int)(uint32_t)((xaddr >> 32) & 0xFFFF), (int)0xFFFFFFF0, 0x00020000};   // raw buffer over the whole tensor, no stride
     auto load_p = [&](int cp, f32x4 (&r)[CH_T]) {
+        if (fl_noload) return;
 #pragma unroll
         for (int k = 0; k < CH_T; ++k) {
             const unsigned so = (unsigned)(cp * 32 + k) * ldb4;                                 // wave-uniform
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
         typedef __bf16 bf16xc __attribute__((ext_vector_type(CH_T)));
         typedef _Float16 f16xc __attribute__((ext_vector_type(CH_T)));
         char* const base = reinterpret_cast<char*>(Ps + buf * P_UNITS + pdst) + sub * CH_T * 2;
+        if (fl_nowrite) return;
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             if constexpr (F16) {
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
 
     // 48 MFMAs of one stage; the next pixel tile's fragments are read before the current tile's 12 MFMAs (see vd_conv_k32p.hip mfma_row_pipe)
     auto mfma_stage = [&](int buf) {
+        if (fl_nomfma) return;
         const u32x4* __restrict__ a_cur = a_base + buf * A_UNITS;
         const u32x4* __restrict__ p_cur = p_base + buf * P_UNITS;
         if constexpr (F16) {
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_k32p_kernel(const g32p_args a)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) val[ni] += t[ni];
             }
-            if (m < d.M) {
+            if (m < d.M && !(fl_nostore && val[0][0] != 12345.f)) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(dst + po[ni]) = val[ni];
             }
@@ -378,6 +390,9 @@ int vd_launch_gemm1x1_k32p(const vd_gemm_desc& d, hipStream_t st) {
     static const int bm256 = env_int("VD_G32P_BM256", 1);         // A/B switch: 0 = the 128 x 256 tile everywhere (round 4)
     const bool big_m = bm256 && d.math != 2 && d.M % 256 == 0 && d.N % 128 == 0;
     g32p_args a;
+#ifdef VD_G32P_VARIANTS
+    a.flags = env_int("VD_G32P_FLAGS", 0);
+#endif
     a.d = d;
     a.tiles_m = vd_cdiv(d.M, big_m ? 256 : 128);
     a.n_tiles = a.tiles_m * (d.N / (big_m ? 128 : 256));
