@@ -904,12 +904,12 @@ __global__ __launch_bounds__(256) void conv3_smallm_kernel(const vd_gemm_desc d)
 
 // The same convolution without LDS: a lane owns FOUR consecutive output pixels of a row for all (<= 4) output channels, the four waves of a
 // workgroup split the input channels and their partial sums meet in LDS at the end.  Per channel a lane loads three rows of (1 + 4 + 1)
-// pixels straight from global memory (the float4 is aligned; the two edge pixels hit the lines the neighbouring lanes fetch) and the 27
+// pixels (the float4 is aligned, straight from global memory; the two edge pixels come from the neighbouring lanes' registers) and the 27
 // weights arrive as scalar loads (wave-uniform address): 9 loads feed 36 * M FMAs, against 18 LDS reads per 9 * M FMAs in the kernel
 // above, which is LDS-issue bound (85 us at B = 128 for a 17 us read of the input).  W % 4 == 0.
-template <int MM>
-__global__ __launch_bounds__(256) void conv3_fewout_kernel(const vd_gemm_desc d, int64_t quads) {
-    __shared__ float red[3][MM][4][64];
+template <int MM, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3_fewout_kernel(const vd_gemm_desc d, int64_t quads) {
+    __shared__ float red[NW - 1][MM][4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = d.W, H = d.H, W4 = W >> 2, HWs = H * W;
     const int64_t gq = (int64_t)blockIdx.x * 64 + lane;
@@ -921,6 +921,8 @@ __global__ __launch_bounds__(256) void conv3_fewout_kernel(const vd_gemm_desc d,
     const float* __restrict__ xb = d.B + (int64_t)b * d.b_bstride + y * W + 4 * x4;
     const bool rowok[3] = {y > 0, true, y < H - 1};
     const bool lf = x4 > 0, rt = x4 < W4 - 1;
+    const bool xch = W4 <= 16 && (64 % W4) == 0;          // uniform (rows of up to 64 pixels; measured: 31.2 against 34.8 us at 32 x 32, B = 128 -- and 147 against 136 us
+                                                          // with the 64-quad rows of 256 x 256 images, which keep the loads)
     int roff[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) roff[r] = rowok[r] ? (r - 1) * W : 0;
@@ -929,8 +931,8 @@ __global__ __launch_bounds__(256) void conv3_fewout_kernel(const vd_gemm_desc d,
     for (int m = 0; m < MM; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
-    const int cper = (d.C + 3) / 4;
-    const int c_begin = wave * cper, c_end = min(d.C, c_begin + cper);
+    const int cper = (d.C + NW - 1) / NW;
+    const int c_begin = min(d.C, wave * cper), c_end = min(d.C, c_begin + cper);
     const float* __restrict__ Wp = d.A;
 #pragma unroll 2
     for (int c = c_begin; c < c_end; ++c) {
@@ -940,7 +942,10 @@ __global__ __launch_bounds__(256) void conv3_fewout_kernel(const vd_gemm_desc d,
         for (int r = 0; r < 3; ++r) {
             const float* __restrict__ q = p + roff[r];
             const f32x4 v = *reinterpret_cast<const f32x4*>(q);
-            const float l = q[lf ? -1 : 0], rr = q[rt ? 4 : 3];
+            // the two edge pixels are the neighbouring lanes' (lane - 1: the quad to the left in the same row, whenever lf; lane + 1 likewise): a lane
+            // exchange instead of two more loads per row
+            // (rows that do not divide the 64 quads of a workgroup -- W = 48 -- have row neighbours in other workgroups: loads, as before)
+            const float l = xch ? __shfl_up(v[3], 1) : q[lf ? -1 : 0], rr = xch ? __shfl_down(v[0], 1) : q[rt ? 4 : 3];
             e[r][0] = (rowok[r] && lf) ? l : 0.f;
             e[r][5] = (rowok[r] && rt) ? rr : 0.f;
 #pragma unroll
@@ -975,7 +980,10 @@ __global__ __launch_bounds__(256) void conv3_fewout_kernel(const vd_gemm_desc d,
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = ((acc[m][j] + red[0][m][j][lane]) + (red[1][m][j][lane] + red[2][m][j][lane])) * d.alpha;   // fixed order
+                    float v = acc[m][j];
+#pragma unroll
+                    for (int k = 0; k < NW - 1; ++k) v += red[k][m][j][lane];                                            // fixed order
+                    v *= d.alpha;
                     if (d.bias) v += d.bias[m];
                     o[j] = v;
                 }
@@ -1003,7 +1011,9 @@ static int launch_smallm(const vd_gemm_desc& d, hipStream_t st) {
     constexpr int fewout_off = 0;
     if (!fewout_off && fewout_eligible(d)) {
         const int64_t quads = (int64_t)nb * d.H * (d.W / 4);
-        hipLaunchKernelGGL((conv3_fewout_kernel<4>), dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, d, quads);
+        // eight waves per 256 pixels (round 6; four until then): 31 against 48 us for conv_out at B = 128 -- the loop is a latency chain (loads -> 100 FMAs per
+        // channel) and four waves per workgroup left two per SIMD; sixteen: 34 us
+        hipLaunchKernelGGL((conv3_fewout_kernel<4, 8>), dim3((unsigned)((quads + 63) / 64)), dim3(512), 0, st, d, quads);
         return 0;
     }
     if (d.W % 32 == 0) {

@@ -351,7 +351,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = f"gemm_plain_kernel<{a_mode}>"
     elif tl == 7:
         few = d.W % 4 == 0 and d.C >= 16 and d.b_bstride % 4 == 0 and d.d_bstride % 4 == 0 and d.ldd % 4 == 0      # fewout_eligible() of vd_gemm.hip
-        name = "conv3_fewout_kernel<4>" if few else f"conv3_smallm_kernel<{32 if d.W % 32 == 0 else 16}, 4>"
+        name = "conv3_fewout_kernel<4, 8>" if few else f"conv3_smallm_kernel<{32 if d.W % 32 == 0 else 16}, 4>"
     else:
         name = f"gemm_kernel<{_TILE_NAMES[tl]},{'ROW' if a_mode == A_ROW else 'COL'},{_B_NAMES[b_mode]}>"
     _PROF.append({"name": name, "flops": flops, "bytes": nbytes, "e0": e0, "e1": e1, "kind": "mfma", "shape": (M, K, d.NP, N // d.NP, d.OH, d.OW)})
