@@ -226,7 +226,9 @@ class _Conv:
         elif self.mode == B_CONV3_UP:
             B, _, OH, OW = dout.shape
             if pk is not None and ops.bx3_pool2_eligible(self.cin, self.cout, OH, OW, B):
-                ops.conv3x3(dout, wt, None, dx, mode=B_CONV3_T, a_packed=pk, pool2=True)     # 2x2 sums in the epilogue: no 4x tensor
+                # (round 6: the pre-split image of dout -- written for the weight gradient by dout's producer -- feeds the input gradient too)
+                src = dout_ps if (dout_ps is not None and net.us_dgrad_presplit and ops.conv_presplit_ok(B, self.cout, self.cin, OH, OW, B_CONV3_T)) else dout
+                ops.conv3x3(src, wt, None, dx, mode=B_CONV3_T, a_packed=pk, pool2=True)     # 2x2 sums in the epilogue: no 4x tensor
             else:
                 dU = torch.empty((B, self.cin, OH, OW), device=dout.device, dtype=torch.float32)
                 ops.conv3x3(dout, wt, None, dU, mode=B_CONV3_T, a_packed=pk)
@@ -940,6 +942,7 @@ class UNet2DModel(nn.Module):
         # (csrc/vd_presplit.hip; _Resnet.ps_plan decides per block); VILLAN_PRESPLIT=0: round 4's converting kernels
         self.presplit = os.environ.get("VILLAN_PRESPLIT", "1") != "0"
         self.nograd_presplit = os.environ.get("VILLAN_NOGRAD_PRESPLIT", "1") != "0"
+        self.us_dgrad_presplit = os.environ.get("VILLAN_US_DGRAD_PRESPLIT", "1") != "0"
         # round 5: the 1x1 shortcut of a ResnetBlock (forward) and its input gradient (backward) on an auxiliary stream beside the block's 3x3
         # chain (VILLAN_SC_STREAM=0: in line)
         self.sc_stream = os.environ.get("VILLAN_SC_STREAM", "1") != "0"
