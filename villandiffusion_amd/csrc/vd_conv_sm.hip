@@ -37,6 +37,9 @@ struct sm_args {
     int n_tiles;      // tiles_m * tiles_n
     int tiles_n;      // ceil(B / IMGS)
     int nb;           // images
+#ifdef VD_SM_STAMPS
+    unsigned long long* stamps;   // diagnostic build (tools/build_k32p_diag.sh) only: per-wave segment sums in shader cycles, [grid][4 waves][8]
+#endif
 };
 
 // KH: chunk pairs (32 input channels each) per stage.  Shipped: 1 (KH = 2 halves the number of barriers and was measured 3-25 % slower).
@@ -61,6 +64,24 @@ __global__ __launch_bounds__(256, 2) void conv3_sm_kernel(const sm_args a) {
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef VD_SM_STAMPS      // per-wave segment sums: [issue, patch convert, mfma, patch switch, vmcnt wait, barrier, epilogue, total]; every tick is an s_memtime round trip
+    unsigned long long fs[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, ft_prev = 0ull, ft_first = 0ull;
+    auto ftick = [&](int k) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (k >= 0) fs[k] += t - ft_prev;
+        else ft_first = t;
+        ft_prev = t;
+    };
+#define VD_FTICK(k)                                 \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        ftick(k);                                   \
+        __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+#else
+#define VD_FTICK(k)
+#endif
 
     // tile: the workgroups of an XCD (blockIdx % 8 under round-robin dispatch: speed only) take a contiguous range of the m-major tile order, i.e. few m-tiles
     int t = blockIdx.x;
@@ -217,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3_sm_kernel(const sm_args a) {
     write_p();
     __syncthreads();
     int st = 0;
+    VD_FTICK(-1);
     for (int cg = 0; cg < ngroups; ++cg) {
         const bool more = cg + 1 < ngroups;
 #pragma unroll
@@ -227,20 +249,26 @@ __global__ __launch_bounds__(256, 2) void conv3_sm_kernel(const sm_args a) {
             const bool ld = more && (KH == 2 ? r < 2 : r == 1);   // this stage loads one chunk pair of the next group's patch
             if (ld) load_p(cg + 1, KH == 2 ? r : 0);
             __builtin_amdgcn_sched_barrier(0);
+            VD_FTICK(0);
             if (r == 2 && more) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT) : "memory");       // the patch loads (older than this stage's DMAs)
                 convert_p();
             }
+            VD_FTICK(1);
 #pragma unroll
             for (int kh = 0; kh < KH; ++kh) mfma_row(r, buf, kh);
+            VD_FTICK(2);
             if (r == 2 && more) {
                 __syncthreads();                                  // every wave has finished reading the patch
                 write_p();
             }
+            VD_FTICK(3);
             // this stage's DMAs (issued before any patch load of this stage) must have landed before the barrier that releases the next stage
             if (ld) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VD_FTICK(4);
             __syncthreads();
+            VD_FTICK(5);
         }
     }
 
@@ -265,6 +293,15 @@ __global__ __launch_bounds__(256, 2) void conv3_sm_kernel(const sm_args a) {
             *reinterpret_cast<f32x4*>(dst) = val;
         }
     }
+#ifdef VD_SM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VD_FTICK(6);
+    if (a.stamps != nullptr && lane == 0) {
+        fs[7] = ft_prev - ft_first;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a.stamps[(blockIdx.x * 4 + wave) * 8 + k] = fs[k];
+    }
+#endif
 }
 
 int env_int(const char* name, int dflt) {
@@ -305,6 +342,9 @@ bool vd_conv3_sm_eligible(const vd_gemm_desc& d) {
 int vd_launch_conv3_sm(const vd_gemm_desc& d, hipStream_t st) {
     sm_args a;
     a.d = d;
+#ifdef VD_SM_STAMPS
+    a.stamps = reinterpret_cast<unsigned long long*>(d.ws);       // the diagnostic build borrows the (unused) split-K workspace pointer
+#endif
     a.nb = d.N / d.NP;
     const int imgs = sm_imgs(d);
     a.tiles_n = vd_cdiv(a.nb, imgs);

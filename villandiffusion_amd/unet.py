@@ -185,11 +185,24 @@ class _Conv:
         return ops.conv3x3(x, self.w2d(), self.net.P[self.prefix + ".bias"], out, mode=self.mode, rowadd=rowadd,
                            rowadd_bstride=rowadd_bstride, residual=residual, pad=self.pad, gn_ss=gn_ss, a_packed=pk, gn_part=gn_part, act_out=act_out)
 
+    def us_input(self, h, save):
+        """Upsample2D's convolution (round 6): its input -- a block output, f32 -- as a pre-split image when the persistent kernel reads one for this shape.
+        The pack pass (one read, one write of the HALF-resolution tensor) used to run on the weight-gradient stream for the weight gradient alone; made
+        here, the forward convolution copies (hi, lo) units too instead of splitting every element once per tap row and channel tile."""
+        net = self.net
+        B, _, H, W = h.shape
+        if (self.mode != B_CONV3_UP or not net.us_fwd_presplit or not getattr(net, "presplit", False) or net.conv_math != "bf16x3" or H != W
+                or not ops.conv_presplit_ok(B, self.cin, self.cout, 2 * H, 2 * W, B_CONV3_UP)
+                or (save and not (net.group_wgrad and ops.wgrad_presplit_ok(B, self.cin, self.cout, 2 * H, B_CONV3_UP)))):
+            return h
+        return ops.presplit_pack(h)
+
     def bwd(self, dout, x, dx, bias_ws=None, skip_bias=False, dout_ps=None):
         """dW, db (accumulated into the flat gradient) and, if dx is given, the input gradient.  x a PreSplit image (round 5): the weight gradient
         then wants dY pre-split too -- `dout_ps` when the producer of dout wrote one (dout itself may then be None), else a pack pass queued on the
         weight-gradient stream -- and the input gradient reads `dout_ps` when it is there."""
         net = self.net
+        dout_f32 = dout                                       # (the bias gradient's row sums read the f32 tensor)
         if isinstance(x, ops.PreSplit):
             dy_ps = dout_ps if dout_ps is not None else net.pack_later(dout)
             net.wgrad(dy_ps, x, net.G[self.prefix + ".weight"].view(self.cout, self.cin * 9), self.mode, pad=self.pad, math_mode=1)
@@ -210,7 +223,8 @@ class _Conv:
             B = dout.shape[0]
             ws = bias_ws if bias_ws is not None else net.scratch_bc(B, self.cout)
             if bias_ws is None:
-                net.rowsum(dout, ws)
+                assert dout_f32 is not None
+                net.rowsum(dout_f32, ws)
             net.colsum_later(ws, net.G[self.prefix + ".bias"], B, self.cout, ld=(ws.stride(0) if ws.dim() == 2 else self.cout))
         if dx is None:
             return None
@@ -943,6 +957,7 @@ class UNet2DModel(nn.Module):
         self.presplit = os.environ.get("VILLAN_PRESPLIT", "1") != "0"
         self.nograd_presplit = os.environ.get("VILLAN_NOGRAD_PRESPLIT", "1") != "0"
         self.us_dgrad_presplit = os.environ.get("VILLAN_US_DGRAD_PRESPLIT", "1") != "0"
+        self.us_fwd_presplit = os.environ.get("VILLAN_US_FWD_PRESPLIT", "1") != "0"
         # round 5: the 1x1 shortcut of a ResnetBlock (forward) and its input gradient (backward) on an auxiliary stream beside the block's 3x3
         # chain (VILLAN_SC_STREAM=0: in line)
         self.sc_stream = os.environ.get("VILLAN_SC_STREAM", "1") != "0"
@@ -1412,9 +1427,10 @@ class UNet2DModel(nn.Module):
             if blk["us"] is not None:
                 sp *= 2
                 dest = cats[slot][:, :up_slots[slot][0]]
-                blk["us"].fwd(h, dest)
+                hp = blk["us"].us_input(h, save)
+                blk["us"].fwd(hp, dest)
                 if save:
-                    sv.append(("us", blk["us"], h))
+                    sv.append(("us", blk["us"], hp))
                 h = dest
             else:
                 final = h
