@@ -69,4 +69,4 @@ tail -1 $O/bench_default.json | cut -c1-600
 head -8 $O/train_kernel_stats.csv | cut -c1-160
 head -8 $O/sample_kernel_stats.csv | cut -c1-160
 # CPU-oracle thread sweep (review Weak 9): the B = 128 oracle training step at 16 .. 256 host threads
-timeout 1500 python3 tools/cpu_thread_sweep.py > $O/cpu_threads.txt 2>&1
+if [ -z "${SKIP_CPU_SWEEP:-}" ]; then timeout 1500 python3 tools/cpu_thread_sweep.py > $O/cpu_threads.txt 2>&1; fi
