@@ -33,16 +33,11 @@ CASES = [
     # The kernel takes 8x8 grids of >= 64 tiles and 4x4 grids of >= 256 tiles (vd_conv3_sm_eligible): every case is one in the forward direction.
     (128, 256, 256, 8), (128, 512, 256, 8), (128, 256, 512, 4), (256, 512, 256, 4),
     (33, 256, 256, 8), (35, 64, 200, 8), (205, 96, 320, 4), (1024, 32, 64, 4), (16, 1024, 512, 8),
-    (128, 256, 256, 4), (129, 256, 256, 4),                     # 4x4 with up to 256 input channels: two-image tiles where four-image tiles would not fill the chip
 ]
 
 
-def takes(M, B, S, C):
-    """vd_conv3_sm_eligible's grid rule (C: the channels the direction contracts)."""
-    if S == 8:
-        return M >= 64 and -(-M // 64) * -(-B // 2) >= 64
-    imgs = 2 if (-(-M // 64) * -(-B // 4) < 256 and C <= 256) else 4
-    return M >= 64 and -(-M // 64) * -(-B // imgs) >= 256
+def takes(M, B, S):
+    return M >= 64 and -(-M // 64) * -(-B // (2 if S == 8 else 4)) >= (64 if S == 8 else 256)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,S", CASES)
@@ -60,7 +55,7 @@ def test_whole_k_convolution_forward_epilogue_and_input_gradient(B, Cin, Cout, S
     xbuf[:, 3:] = x.detach().to(DEV)
     obuf = torch.full((B, Cout + 8, S, S), 7.0, device=DEV)
     ops.conv3x3(xbuf[:, 3:], wd, b.to(DEV), obuf[:, 4:4 + Cout], rowadd=temb.to(DEV)[:, 2:], rowadd_bstride=Cout + 5, residual=res.to(DEV), a_packed=pk)
-    assert takes(Cout, B, S, Cin) and ops.LAST_GEMM_TILE == 20, ops.LAST_GEMM_TILE
+    assert takes(Cout, B, S) and ops.LAST_GEMM_TILE == 20, ops.LAST_GEMM_TILE
     check(obuf[:, 4:4 + Cout], y_ref, TOL, f"whole-K conv {Cin}->{Cout}@{S} B={B}")
     assert float((obuf[:, :4] - 7).abs().max()) == 0 and float((obuf[:, 4 + Cout:] - 7).abs().max()) == 0      # nothing outside the slice
     o32 = torch.empty(B, Cout, S, S, device=DEV)
@@ -80,7 +75,7 @@ def test_whole_k_convolution_forward_epilogue_and_input_gradient(B, Cin, Cout, S
     wt = torch.empty(Cin, Cout * 9, device=DEV)                  # shape carrier only: the kernel reads pkt
     dx = torch.empty(B, Cin, S, S, device=DEV)
     ops.conv3x3(dy.to(DEV), wt, None, dx, mode=B_CONV3_T, a_packed=pkt)
-    assert (ops.LAST_GEMM_TILE == 20) == takes(Cin, B, S, Cout), ops.LAST_GEMM_TILE      # (smaller grids stay on the split kernels)
+    assert (ops.LAST_GEMM_TILE == 20) == takes(Cin, B, S), ops.LAST_GEMM_TILE      # (smaller grids stay on the split kernels)
     check(dx, x.grad, TOL, f"whole-K input gradient {Cout}->{Cin}@{S}")
 
 
@@ -93,13 +88,9 @@ def test_small_grids_keep_the_split_kernels():
     pk = ops.conv3_pack_weights(w, 256, 256)
     ops.conv3x3(x, w, None, out, a_packed=pk)
     assert ops.LAST_GEMM_TILE != 20
-    x4 = torch.randn(128, 512, 4, 4, device=DEV)
-    w5 = torch.randn(256, 512 * 9, device=DEV) / 68
-    ops.conv3x3(x4, w5, None, torch.empty(128, 256, 4, 4, device=DEV), a_packed=ops.conv3_pack_weights(w5, 256, 512))
-    assert ops.LAST_GEMM_TILE != 20                              # 4x4 at M = 256, B = 128, 512 input channels: 128 four-image tiles, no two-image form
-    x4b = torch.randn(64, 256, 4, 4, device=DEV)
-    ops.conv3x3(x4b, w, None, torch.empty(64, 256, 4, 4, device=DEV), a_packed=pk)
-    assert ops.LAST_GEMM_TILE != 20                              # ... and 128 two-image tiles at B = 64
+    x4 = torch.randn(128, 256, 4, 4, device=DEV)
+    ops.conv3x3(x4, w, None, torch.empty(128, 256, 4, 4, device=DEV), a_packed=pk)
+    assert ops.LAST_GEMM_TILE != 20                              # 4x4 at M = 256, B = 128: 128 tiles
     x16 = torch.randn(128, 256, 16, 16, device=DEV)
     o16 = torch.empty(128, 256, 16, 16, device=DEV)
     ops.conv3x3(x16, w, None, o16, a_packed=pk)

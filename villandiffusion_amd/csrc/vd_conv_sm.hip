@@ -312,15 +312,6 @@ int env_int(const char* name, int dflt) {
 }  // namespace
 
 // vd_gemm.hip asks: is this one of the 8x8 / 4x4 stride-1 problems the whole-K kernel takes?  (vd_gemm_tile() == 20)
-// Images per tile.  8x8: two.  4x4: four where that fills the chip (M = 512 at B = 128); else TWO for up to 256 input channels (M = 256, B = 128: 256 tiles of
-// 64 channels x 32 pixels: 19.0 / 18.7 us against the split kernels' 22.5 / 23.1 forward / input gradient, no epilogue launch); with 512 input channels the
-// two-image tiles lose (33.5 against 28.1 us: a wave then runs 48 stages on two accumulator chains) and the split kernels stay (profiles/r06_conv_sm_ab.txt).
-static int sm_imgs(const vd_gemm_desc& d) {
-    if (d.OW == 8) return 2;
-    const int nb = d.N / d.NP;
-    return (vd_cdiv(d.M, 64) * vd_cdiv(nb, 4) < 256 && d.C <= 256) ? 2 : 4;
-}
-
 bool vd_conv3_sm_eligible(const vd_gemm_desc& d) {
     static const int off = env_int("VD_CONV_SM_OFF", 0);          // 1: rounds 2-5's split-K kernels (A/B switch)
     if (off || !d.a_packed || d.math == 2 || d.b_presplit) return false;
@@ -331,11 +322,11 @@ bool vd_conv3_sm_eligible(const vd_gemm_desc& d) {
     if ((d.ldd & 3) || (d.d_bstride & 3) || (((uintptr_t)d.D) & 15) || (((uintptr_t)d.a_packed) & 15)) return false;
     if (d.residual && ((d.res_bstride & 3) || (((uintptr_t)d.residual) & 15))) return false;
     if ((d.b_bstride & 3) || (((uintptr_t)d.B) & 15)) return false;                // 16-byte row loads
-    const int imgs = sm_imgs(d);
+    const int imgs = d.OW == 8 ? 2 : 4;
     if ((int64_t)imgs * d.b_bstride * 4 >= (1ll << 31)) return false;             // 32-bit buffer offsets inside one tile's images
     const int nb = d.N / d.NP;
-    // 8x8: from 64 tiles on; 4x4 (36 | 18 MFMAs per wave and stage behind the same 24 KB of weights): only where the grid fills the chip -- below that the
-    // split kernels are as fast or faster (profiles/r06_conv_sm_ab.txt)
+    // 8x8: from 64 tiles on; 4x4 (36 MFMAs per wave and stage behind the same 24 KB of weights): only where the grid fills the chip (M = 512 at B = 128) --
+    // below that the split kernels are as fast or faster; two-image tiles (256 tiles at M = 256) win alone and lose inside the step (profiles/r06_conv_sm_ab.txt)
     return vd_cdiv(d.M, 64) * vd_cdiv(nb, imgs) >= (d.OW == 8 ? 64 : 256);
 }
 
@@ -346,7 +337,7 @@ int vd_launch_conv3_sm(const vd_gemm_desc& d, hipStream_t st) {
     a.stamps = reinterpret_cast<unsigned long long*>(d.ws);       // the diagnostic build borrows the (unused) split-K workspace pointer
 #endif
     a.nb = d.N / d.NP;
-    const int imgs = sm_imgs(d);
+    const int imgs = d.OW == 8 ? 2 : 4;
     a.tiles_n = vd_cdiv(a.nb, imgs);
     a.n_tiles = vd_cdiv(d.M, 64) * a.tiles_n;
     const int mode = d.b_mode == VD_B_CONV3_T ? 1 : 0;
@@ -357,7 +348,7 @@ int vd_launch_conv3_sm(const vd_gemm_desc& d, hipStream_t st) {
         hipLaunchKernelGGL((conv3_sm_kernel<WW, MD, IM, 1>), dim3(a.n_tiles), dim3(256), 0, st, a);              \
         return 0;                                                                                                \
     }
-    VD_SM_CASE(8, 0, 2) VD_SM_CASE(8, 1, 2) VD_SM_CASE(4, 0, 4) VD_SM_CASE(4, 1, 4) VD_SM_CASE(4, 0, 2) VD_SM_CASE(4, 1, 2)
+    VD_SM_CASE(8, 0, 2) VD_SM_CASE(8, 1, 2) VD_SM_CASE(4, 0, 4) VD_SM_CASE(4, 1, 4)
 #undef VD_SM_CASE
     return -1;
 }

@@ -339,7 +339,7 @@ def gemm(A, B, D, *, M, N, K, a_mode=A_ROW, b_mode=B_PLAIN, NP=None, lda=0, a_bs
         name = (f"conv3_k32p_kernel<{16 if d.OW == 16 else 32}, {md}, true, true, {'true' if d.math == 2 else 'false'}, {'true' if d.b_presplit else 'false'}>"
                 + (f"@{d.OW}" if d.OW > 32 else ""))
     elif tl == 20:          # the whole-K kernel of the 8x8 / 4x4 levels
-        imgs = 2 if (d.OW == 8 or (-(-M // 64) * -(-(N // d.NP) // 4) < 256 and d.C <= 256)) else 4        # (vd_conv_sm.hip sm_imgs)
+        imgs = 2 if d.OW == 8 else 4
         name = f"conv3_sm_kernel<{d.OW}, {1 if b_mode == B_CONV3_T else 0}, {imgs}, 1>"
     elif tl in (8, 12, 15, 16):
         md = (3 if gn_ss is not None else 0) if b_mode == B_CONV3 else (1 if b_mode == B_CONV3_T else (4 if b_mode == B_CONV3_S2 else 2))
