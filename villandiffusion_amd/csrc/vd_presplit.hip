@@ -728,12 +728,13 @@ extern "C" int vd_groupnorm_bwd_presplit(const float* dy, const float* x, const 
 // vd_gemm.hip's grouped launch (class 3000 + 4 W + 2 * upsample-fused): both operands pre-split
 int vd_launch_wgrad_ps_group(const void* jobs, int n, int W, int up, int blocks, hipStream_t st) {
     const vd_wgrad_job* jb = reinterpret_cast<const vd_wgrad_job*>(jobs);
-    // 12 KB of (unused) dynamic LDS on top of the kernel's 76 KB: ONE workgroup per CU instead of two.  Two of them hold a CU's whole LDS and register
-    // file for ~90 us at a time, and the backward pass on the main stream -- latency-bound 8x8 / 4x4 kernels, GroupNorm passes -- only gets a CU when
-    // one retires; with one per CU every CU keeps half its registers and 72 KB of LDS for the main stream's workgroups all the time.  The weight
-    // gradients themselves lose nothing measurable (they are power-bound beside the convolutions).  Same box, interleaved, four rounds:
-    // 16.56 against 16.69 ms per training step (profiles/r06_wgrad_occupancy_ab.txt).  VD_WGRAD_PS_LDS_PAD=0: two per CU.
-    static const int pad = getenv("VD_WGRAD_PS_LDS_PAD") ? atoi(getenv("VD_WGRAD_PS_LDS_PAD")) : 12288;
+    // 4.5 KB of (unused) dynamic LDS on top of the kernel's 76 KB: ONE workgroup per CU instead of two (2 x 80.5 KB > 160 KB).  Two of them hold a CU's whole
+    // LDS and register file for ~90 us at a time, and the backward pass on the main stream -- latency-bound 8x8 / 4x4 kernels, GroupNorm passes -- only gets a CU
+    // when one retires; with one per CU every CU keeps half its registers and 79.5 KB of LDS for the main stream's workgroups all the time: enough for a 74-KB
+    // workgroup of the whole-K 8x8 convolution (a 12-KB pad, the first version, left 72 KB: 17.07 against 17.005 ms per step, six interleaved pairs).  The weight
+    // gradients themselves lose nothing measurable (they are power-bound beside the convolutions).  Against two per CU, same box, interleaved: -0.04 / -0.13 /
+    // -0.07 ms per training step on three boxes with the 12-KB pad (profiles/r06_wgrad_occupancy_ab.txt).  VD_WGRAD_PS_LDS_PAD=0: two per CU.
+    static const int pad = getenv("VD_WGRAD_PS_LDS_PAD") ? atoi(getenv("VD_WGRAD_PS_LDS_PAD")) : 4608;
 #define VD_WG_PS(WW)                                                                                                \
     case WW:                                                                                                        \
         if (up) hipLaunchKernelGGL((wgrad_ps_group_kernel<WW, 2>), dim3(blocks), dim3(256), pad, st, jb, n);        \
